@@ -1,0 +1,176 @@
+"""Generate golden vectors by running the REFERENCE's own code on tiny local-config models.
+
+Runs only in the build container (``/root/reference`` does not exist on the GPU box).  Output:
+``tests/golden/ref_tiny_{llama,qwen3}.safetensors`` — weights, one batch, and the outputs the
+reference's ``DeSTA25AudioModel.forward`` / ``WhisperPerception.forward_whisper`` /
+``QformerConnector.forward`` produce for it (fp32, dropout off), plus connector grads.
+
+How the reference is made importable here (recorded in DESIGN.md):
+* ``librosa`` / ``soundfile`` / ``pydub`` are absent; ``desta/utils/audio.py`` imports them at
+  module import.  They are only used for FILE decode (out of scope), so empty
+  stub modules are pre-seeded in ``sys.modules`` (``soundfile.available_formats`` returns {}).
+* Every public constructor resolves model NAMES from the HF hub (unavailable offline), so the
+  objects are built with ``__new__`` + ``nn.Module.__init__`` and the same sub-modules the
+  constructors would create, from LOCAL config objects (``modeling_desta25.py:148-168, 505-512,
+  713-732``), then the reference's forward code runs unmodified.
+* Version trap H1: the reference indexes ``layer_outputs[0]`` (4.x tuple API,
+  ``modeling_desta25.py:585``); transformers 5.15 returns a bare tensor.  Encoder layers are
+  wrapped to return a 1-tuple so the reference code sees 4.x semantics.
+"""
+import os
+import sys
+import types
+
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def _stub_missing():
+    for name in ("librosa", "soundfile", "pydub", "pydub.exceptions"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            sys.modules[name] = m
+    sys.modules["soundfile"].available_formats = lambda: {}
+    sys.modules["pydub"].AudioSegment = object
+    sys.modules["pydub.exceptions"].CouldntDecodeError = Exception
+    sys.modules["librosa"].__path__ = []
+
+
+def build_reference_model(d, w):
+    """Assemble the reference classes around local-config HF modules and load weights ``w``."""
+    # transformers probes optional packages with find_spec at import: import it BEFORE stubbing
+    from transformers import WhisperConfig, WhisperForConditionalGeneration, LlamaConfig, Qwen3Config
+    from transformers import LlamaForCausalLM, Qwen3ForCausalLM, AutoTokenizer, AutoProcessor  # noqa: F401
+    from transformers import PretrainedConfig, PreTrainedModel, AutoModelForCausalLM, AutoConfig, BertConfig  # noqa: F401
+    from transformers.models.bert.modeling_bert import BertEncoder  # noqa: F401
+    _stub_missing()
+    sys.path.insert(0, REF)
+    from desta.models import modeling_desta25 as M
+
+    enc_cfg = WhisperConfig(num_mel_bins=d.n_mels, d_model=d.enc_d, encoder_layers=d.enc_layers,
+                            encoder_attention_heads=d.enc_heads, encoder_ffn_dim=d.enc_ffn,
+                            max_source_positions=d.enc_T, decoder_layers=1, decoder_attention_heads=d.enc_heads,
+                            decoder_ffn_dim=d.enc_ffn, vocab_size=64, dropout=0.0, attention_dropout=0.0,
+                            activation_dropout=0.0, pad_token_id=0, bos_token_id=1, eos_token_id=2,
+                            decoder_start_token_id=1)
+    enc_cfg._attn_implementation = "eager"
+    if d.qk_norm:
+        llm_cfg = Qwen3Config(vocab_size=d.vocab, hidden_size=d.llm_h, intermediate_size=d.llm_inter,
+                              num_hidden_layers=d.llm_layers, num_attention_heads=d.llm_hq,
+                              num_key_value_heads=d.llm_hkv, head_dim=d.llm_hd, rms_norm_eps=d.rms_eps,
+                              rope_parameters={"rope_type": "default", "rope_theta": d.rope_theta},
+                              tie_word_embeddings=False, attention_bias=False, max_position_embeddings=4096)
+        llm = Qwen3ForCausalLM(llm_cfg)
+    else:
+        f, lo, hi, old = d.rope_llama3
+        llm_cfg = LlamaConfig(vocab_size=d.vocab, hidden_size=d.llm_h, intermediate_size=d.llm_inter,
+                              num_hidden_layers=d.llm_layers, num_attention_heads=d.llm_hq,
+                              num_key_value_heads=d.llm_hkv, head_dim=d.llm_hd, rms_norm_eps=d.rms_eps,
+                              rope_parameters={"rope_type": "llama3", "rope_theta": d.rope_theta, "factor": f,
+                                               "low_freq_factor": lo, "high_freq_factor": hi,
+                                               "original_max_position_embeddings": old},
+                              tie_word_embeddings=False, attention_bias=False, max_position_embeddings=4096)
+        llm = LlamaForCausalLM(llm_cfg)
+    llm_cfg._attn_implementation = "eager"
+    llm.config._attn_implementation = "eager"
+
+    cfg = types.SimpleNamespace(
+        encoder_model_id="openai/whisper-tiny", llm_model_id="local", connector_mode="qformer_1",
+        qformer_num_hidden_layers=d.qf_layers, prompt_size=d.prompt_size, encoder_config=enc_cfg,
+        llm_config=llm_cfg, orca_enabled=False, use_lora=False)
+
+    # BertConfig() default intermediate_size is 3072; the tiny golden overrides it through the
+    # class default so the reference constructor code itself stays untouched.
+    from transformers import BertConfig
+    _orig_init = BertConfig.__init__
+
+    def _patched(self, *a, **k):
+        k.setdefault("intermediate_size", d.qf_inter)
+        k.setdefault("hidden_dropout_prob", 0.0)
+        k.setdefault("attention_probs_dropout_prob", 0.0)
+        _orig_init(self, *a, **k)
+    BertConfig.__init__ = _patched
+    try:
+        connector = M.QformerConnector(cfg)
+    finally:
+        BertConfig.__init__ = _orig_init
+    assert list(cfg.target_layer_ids) == list(d.taps)
+
+    perception = M.WhisperPerception.__new__(M.WhisperPerception)
+    torch.nn.Module.__init__(perception)
+    perception.config = cfg
+    perception.whisper = WhisperForConditionalGeneration(enc_cfg)
+    perception.connector = connector
+    # H1: give the reference the 4.x tuple API it was written against
+    for layer in perception.whisper.model.encoder.layers:
+        orig = layer.forward
+        layer.forward = (lambda o: (lambda *a, **k: (o(*a, **{kk: vv for kk, vv in k.items()
+                                                               if kk not in ("layer_head_mask", "output_attentions")}),)))(orig)
+
+    model = M.DeSTA25AudioModel.__new__(M.DeSTA25AudioModel)
+    torch.nn.Module.__init__(model)
+    model.config = cfg
+    model.llm_model = llm
+    model.perception = perception
+    model.configure_trainable_parameters()
+
+    sd = {k: v for k, v in w.items()}
+    missing, unexpected = torch.nn.Module.load_state_dict(model, sd, strict=False)
+    missing = [m for m in missing if "decoder" not in m and "proj_out" not in m and "encoder.layer_norm" not in m]
+    assert not missing, missing
+    assert not unexpected, unexpected
+    model.eval()
+    return model, M
+
+
+def main():
+    import desta_oracle as O
+    from safetensors.torch import save_file
+
+    for name, d in (("llama", O.tiny_dims(False)), ("qwen3", O.tiny_dims(True))):
+        torch.manual_seed(0)
+        w = O.init_weights(d, seed=7)
+        model, M = build_reference_model(d, w)
+        batch = O.synthetic_batch(d, B=2, S_ctx=5, S_tgt=12, seed=11, pad=[3, 0])
+        starts = [(b, torch.tensor(s)) for b, s in batch["batch_start_positions"]]
+        out = M.DeSTA25AudioModel.forward(
+            model, input_ids=batch["input_ids"], attention_mask=batch["attention_mask"],
+            batch_features=batch["batch_features"], batch_transcription_ids=batch["batch_transcription_ids"],
+            batch_start_positions=starts, labels=batch["labels"], metadata=None)
+        out.loss.backward()
+        trainable = sorted(model.trainable_parameter_names)
+        assert trainable == sorted(O.trainable_names(d)), set(trainable) ^ set(O.trainable_names(d))
+        # state_dict() (trainable-only) key check
+        sd_keys = sorted(M.DeSTA25AudioModel.state_dict(model).keys())
+        assert sd_keys == trainable
+        grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
+        with torch.no_grad():
+            audio_features = model.perception.forward_whisper(batch["batch_features"])
+            inputs_embeds = model._prepare_inputs_for_llm(
+                input_ids=batch["input_ids"], attention_mask=batch["attention_mask"],
+                batch_features=batch["batch_features"], batch_transcription_ids=batch["batch_transcription_ids"],
+                batch_start_positions=starts)
+            # standalone QformerConnector.forward on a list of per-layer states (modeling_desta25.py:178-205)
+            g = torch.Generator().manual_seed(3)
+            states = [torch.randn(2, d.enc_T, d.enc_d, generator=g) for _ in range(d.enc_layers)]
+            conn_out = model.perception.connector(states)
+        blob = {"loss": out.loss.detach().reshape(1), "logits": out.logits.detach().contiguous(),
+                "audio_features": audio_features.contiguous(), "inputs_embeds": inputs_embeds.contiguous(),
+                "input_ids": batch["input_ids"], "attention_mask": batch["attention_mask"],
+                "labels": batch["labels"], "batch_features": batch["batch_features"],
+                "starts": torch.tensor([[b, int(s)] for b, s in batch["batch_start_positions"]]),
+                "conn_states": torch.stack(states), "conn_out": conn_out.contiguous()}
+        for n, gv in grads.items():
+            blob["grad::" + n] = gv.contiguous()
+        # only the trainable weights + seed are stored; frozen weights are regenerated from seed 7
+        path = os.path.join(HERE, f"ref_tiny_{name}.safetensors")
+        save_file({k: v.contiguous() for k, v in blob.items()}, path)
+        print(name, "loss", float(out.loss), "->", path, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,142 @@
+"""Pin the CPU oracle (oracle/desta_oracle.py):
+ (1) against goldens produced by the REFERENCE's own classes (tests/golden/make_golden_from_reference.py),
+ (2) against the installed third-party blocks the reference calls (transformers 5.15 / torch).
+CPU only."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+from safetensors.torch import load_file
+
+import desta_oracle as O
+
+
+def _load(golden_dir, name):
+    return load_file(os.path.join(golden_dir, f"ref_tiny_{name}.safetensors"))
+
+
+@pytest.mark.parametrize("name", ["llama", "qwen3"])
+def test_oracle_matches_reference_forward_backward(golden_dir, name):
+    g = _load(golden_dir, name)
+    d = O.tiny_dims(name == "qwen3")
+    w = O.init_weights(d, seed=7)
+    batch = {"input_ids": g["input_ids"], "attention_mask": g["attention_mask"], "labels": g["labels"],
+             "batch_features": g["batch_features"],
+             "batch_start_positions": [(int(b), int(s)) for b, s in g["starts"].tolist()],
+             "batch_transcription_ids": [torch.zeros(1, 0, dtype=torch.long) for _ in range(g["starts"].shape[0])]}
+    names = O.trainable_names(d)
+    for n in names:
+        w[n].requires_grad_(True)
+    keep = {}
+    loss, logits = O.model_forward(w, d, batch, keep)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 2e-5
+    torch.testing.assert_close(keep["audio_features"], g["audio_features"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(keep["inputs_embeds"], g["inputs_embeds"], rtol=1e-4, atol=2e-5)
+    # logits at non-pad positions (pad-query rows are unspecified: fully masked softmax rows)
+    m = g["attention_mask"].bool()
+    torch.testing.assert_close(logits[m], g["logits"][m], rtol=2e-4, atol=2e-4)
+    for n in names:
+        gr = g["grad::" + n]
+        torch.testing.assert_close(w[n].grad, gr, rtol=2e-3, atol=1e-6 + 1e-4 * float(gr.abs().max()))
+
+
+def test_oracle_connector_matches_reference_standalone(golden_dir):
+    g = _load(golden_dir, "llama")
+    d = O.tiny_dims(False)
+    w = O.init_weights(d, seed=7)
+    states = list(g["conn_states"].unbind(0))
+    outs = [O.qformer(w, d, j, states[t]) for j, t in enumerate(d.taps)]
+    out = O.mix_proj(w, d, outs)
+    torch.testing.assert_close(out, g["conn_out"], rtol=1e-4, atol=2e-5)
+
+
+def test_mel_filters_and_logmel_match_transformers():
+    from transformers import WhisperFeatureExtractor
+    from transformers.audio_utils import mel_filter_bank
+    for n_mels in (80, 128):
+        ref = mel_filter_bank(num_frequency_bins=201, num_mel_filters=n_mels, min_frequency=0.0,
+                              max_frequency=8000.0, sampling_rate=16000, norm="slaney", mel_scale="slaney")
+        np.testing.assert_allclose(O.mel_filter_bank(n_mels), ref, rtol=1e-6, atol=1e-9)
+    g = torch.Generator().manual_seed(0)
+    wave = (0.1 * torch.randn(2, 480000, generator=g)).clamp(-1, 1)
+    wave[1, 300000:] = 0.0
+    fe = WhisperFeatureExtractor(feature_size=128)
+    ref = fe([w.numpy() for w in wave], sampling_rate=16000, return_tensors="pt").input_features
+    out = O.logmel(wave, 128)
+    assert out.shape == (2, 128, 3000)
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
+    # short clip is zero padded to 30 s, like the extractor does
+    ref_s = fe([wave[0, :16000].numpy()], sampling_rate=16000, return_tensors="pt").input_features
+    torch.testing.assert_close(O.logmel(wave[:1, :16000], 128), ref_s, rtol=1e-4, atol=1e-4)
+
+
+def test_adafactor_clip_schedule_match_transformers():
+    from transformers.optimization import Adafactor, get_linear_schedule_with_warmup
+    g = torch.Generator().manual_seed(1)
+    shapes = [(1, 16, 24), (24, 40), (40,), (16, 4), (7,)]
+    p_ref = [torch.nn.Parameter(torch.randn(*s, generator=g)) for s in shapes]
+    p_o = [p.detach().clone() for p in p_ref]
+    wd = [0.01, 0.01, 0.0, 0.01, 0.0]
+    opt = Adafactor([{"params": [p], "weight_decay": w_} for p, w_ in zip(p_ref, wd)], lr=1e-4,
+                    scale_parameter=False, relative_step=False)
+    sched = get_linear_schedule_with_warmup(opt, 5, 50)
+    st = O.adafactor_init(p_o)
+    for step in range(6):
+        grads = [torch.randn(*s, generator=g) * (10.0 if step == 2 else 0.05) for s in shapes]
+        for p, gr in zip(p_ref, grads):
+            p.grad = gr.clone()
+        n_ref = torch.nn.utils.clip_grad_norm_(p_ref, 1.0)
+        go = [gr.clone() for gr in grads]
+        n_o = O.clip_grad_norm(go, 1.0)
+        assert abs(float(n_ref) - float(n_o)) < 1e-5 * max(1.0, float(n_ref))
+        lr = O.linear_warmup_lr(step, 1e-4, 5, 50)
+        assert abs(lr - sched.get_last_lr()[0]) < 1e-12
+        opt.step()
+        sched.step()
+        O.adafactor_step(p_o, go, st, lr, wd)
+        for a, b in zip(p_ref, p_o):
+            torch.testing.assert_close(a.detach(), b, rtol=1e-6, atol=1e-7)
+
+
+def test_decay_mask_matches_trainer_rule():
+    """HF Trainer: decay = params not in LayerNorm modules and without 'bias' in the name."""
+    from transformers.trainer_pt_utils import get_parameter_names
+    d = O.tiny_dims(False)
+    names = O.trainable_names(d)
+    mask = dict(zip(names, O.decay_mask(names)))
+    assert mask[O.CON + "layer_weights"] and mask[O.CON + "layer_prompts.0"]
+    assert not mask[O.CON + "proj.0.weight"] and not mask[O.CON + "proj.0.bias"]
+    assert mask[O.CON + "proj.1.weight"] and not mask[O.CON + "proj.1.bias"]
+    assert not mask[O.CON + "qformer.layer.0.attention.output.LayerNorm.weight"]
+    assert mask[O.CON + "qformer.layer.0.crossattention.self.key.weight"]
+    # cross-check on an equivalent module tree
+    import torch.nn as nn
+    from transformers import BertConfig
+    from transformers.models.bert.modeling_bert import BertEncoder
+    cfg = BertConfig(num_hidden_layers=d.qf_layers, num_attention_heads=d.qf_heads, hidden_size=d.enc_d,
+                     intermediate_size=d.qf_inter, add_cross_attention=True, is_decoder=True)
+
+    class C(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.layer_prompts = nn.ParameterList([nn.Parameter(torch.zeros(1, 4, d.enc_d)) for _ in d.taps])
+            self.layer_weights = nn.Parameter(torch.zeros(4, 4))
+            self.qformer = BertEncoder(cfg)
+            self.proj = nn.Sequential(nn.LayerNorm(d.enc_d), nn.Linear(d.enc_d, d.llm_h))
+
+    class P(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.connector = C()
+
+    class Mdl(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.perception = P()
+    m = Mdl()
+    dec = get_parameter_names(m, [nn.LayerNorm], ["bias", "layernorm", "rmsnorm", "(?:^|\\.)norm(?:$|\\.)", "_norm(?:$|\\.)"])
+    for n in names:
+        assert mask[n] == (n in dec), n
