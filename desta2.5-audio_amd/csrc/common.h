@@ -1,0 +1,95 @@
+// Shared device helpers for the DeSTA2.5 gfx950 kernels (wave = 64 lanes, CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;                                            // raw bf16 bits in HBM
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;          // MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4;            // 16x16 accumulator
+typedef __attribute__((ext_vector_type(16))) float f32x16;          // 32x32 accumulator
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+
+#define DESTA_OK 0
+#define DESTA_EINVAL (-1)
+#define DESTA_ELAUNCH (-2)
+
+void desta_set_error(const char* fmt, ...);
+
+#define DESTA_CHECK_ARG(cond, ...)                  \
+    do {                                            \
+        if (!(cond)) {                              \
+            desta_set_error(__VA_ARGS__);           \
+            return DESTA_EINVAL;                    \
+        }                                           \
+    } while (0)
+
+#define DESTA_CHECK_LAUNCH(name)                                                  \
+    do {                                                                          \
+        hipError_t e__ = hipGetLastError();                                       \
+        if (e__ != hipSuccess) {                                                  \
+            desta_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return DESTA_ELAUNCH;                                                 \
+        }                                                                         \
+    } while (0)
+
+// f32 -> bf16, round-to-nearest-even; plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaN.
+__device__ __forceinline__ bf16_t f2bf(float x) {
+    __bf16 b = (__bf16)x;
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float bf2f(bf16_t b) {
+    return __builtin_bit_cast(float, ((unsigned)b) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide sum for blockDim.x == NT (multiple of 64); `red` is NT/64 floats of LDS.
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) t += red[i];
+    return t;
+}
+template <int NT>
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float t = red[0];
+#pragma unroll
+    for (int i = 1; i < NT / 64; ++i) t = fmaxf(t, red[i]);
+    return t;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// XCD-aware bijective remap of a 1-D block id: blocks that share an XCD (id % 8) get a contiguous
+// chunk of the logical grid so neighbouring tiles hit the same L2 (guide T1, bijective form).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}

@@ -1,0 +1,151 @@
+"""GPU parity tests of the individual HIP kernels against the CPU oracle / plain torch fp32.
+All calls go through the C ABI (desta._hip ctypes binding)."""
+import math
+
+import pytest
+import torch
+
+import desta_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    from desta import _hip
+    return _hip
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (200, 136, 192), (1500, 1280, 384), (77, 4, 64)])
+def test_gemm_plain(hip, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = _bf(torch.randn(M, K, generator=g)).cuda()
+    B = _bf(torch.randn(N, K, generator=g)).cuda()
+    ref = A.float() @ B.float().T
+    out = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    hip.gemm(A, B, out, M, N, K)
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-3)
+    outb = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    hip.gemm(A, B, outb, M, N, K)
+    torch.testing.assert_close(outb.float(), ref, rtol=1e-2, atol=1e-2 * math.sqrt(K))
+
+
+def test_gemm_asymmetric_identity(hip):
+    """A = I with an asymmetric B catches a swapped C-write or fragment map."""
+    K = 128
+    A = _bf(torch.eye(K)).cuda()
+    B = _bf(torch.arange(256 * K).reshape(256, K).float() % 251 - 100).cuda()
+    out = torch.empty(K, 256, dtype=torch.float32, device="cuda")
+    hip.gemm(A, B, out, K, 256, K)
+    torch.testing.assert_close(out, B.float().T, rtol=0, atol=0)
+
+
+def test_gemm_epilogues_and_batch(hip):
+    g = torch.Generator().manual_seed(5)
+    M, N, K, nb = 192, 256, 128, 3
+    A = _bf(torch.randn(nb, M, K, generator=g)).cuda()
+    B = _bf(torch.randn(N, K, generator=g) / math.sqrt(K)).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    res32 = torch.randn(nb, M, N, generator=g).cuda()
+    resb = _bf(torch.randn(M, N, generator=g)).cuda()
+    pre_ref = A.float() @ B.float().T * 0.5 + bias
+    # gelu + fp32 residual (batched) + preact copy
+    out = torch.empty(nb, M, N, dtype=torch.float32, device="cuda")
+    pre = torch.empty(nb, M, N, dtype=torch.bfloat16, device="cuda")
+    hip.gemm(A, B, out, M, N, K, bias=bias, residual=res32, act=1, preact=pre, alpha=0.5, batch=nb,
+             stride_a=M * K, stride_c=M * N, stride_r=M * N, stride_p=M * N)
+    ref = torch.nn.functional.gelu(pre_ref) + res32
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(pre.float(), pre_ref, rtol=1e-2, atol=1e-2)
+    # bf16 residual shared across the batch (stride 0), bf16 out
+    outb = torch.empty(nb, M, N, dtype=torch.bfloat16, device="cuda")
+    hip.gemm(A, B, outb, M, N, K, bias=bias, residual=resb, alpha=0.5, batch=nb, stride_a=M * K, stride_c=M * N)
+    torch.testing.assert_close(outb.float(), pre_ref + resb.float(), rtol=2e-2, atol=2e-2)
+
+
+def test_gemm_overlapping_rows_im2col(hip):
+    """lda < K: rows of A overlap (zero-copy im2col of a k=3 stride-2 conv over channel-last input)."""
+    g = torch.Generator().manual_seed(9)
+    T, Cc, Co = 64, 64, 128
+    x = _bf(torch.randn(2 * T + 1, Cc, generator=g)).cuda()          # padded row 0 .. 2T
+    W = _bf(torch.randn(Co, 3 * Cc, generator=g) / math.sqrt(3 * Cc)).cuda()
+    out = torch.empty(T, Co, dtype=torch.float32, device="cuda")
+    hip.gemm(x, W, out, T, Co, 3 * Cc, lda=2 * Cc)
+    cols = torch.stack([x[2 * t:2 * t + 3].reshape(-1) for t in range(T)]).float()
+    torch.testing.assert_close(out, cols @ W.float().T, rtol=1e-4, atol=1e-4)
+
+
+def test_gemm_rejects_bad_shapes(hip):
+    A = torch.zeros(64, 96, dtype=torch.bfloat16, device="cuda")
+    out = torch.zeros(64, 64, dtype=torch.float32, device="cuda")
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        hip.gemm(A, A, out, 64, 64, 96)
+
+
+@pytest.mark.parametrize("n_mels", [80, 128])
+def test_logmel_matches_oracle(hip, n_mels):
+    g = torch.Generator().manual_seed(1234)
+    wave = (0.1 * torch.randn(3, 480000, generator=g)).clamp(-1, 1)
+    wave[1, 200000:] = 0.0                         # long silence: exercises the max-8 clamp
+    wave[2] *= torch.linspace(0, 1, 480000)
+    ref = O.logmel(wave, n_mels)
+    out = hip.logmel(wave.cuda(), n_mels).cpu()
+    assert out.shape == (3, n_mels, 3000)
+    torch.testing.assert_close(out, ref, rtol=0, atol=2e-4)          # fp32, tolerance stated by the HF docstring: 1e-5..1e-4
+
+
+def test_logmel_short_and_long_clips(hip):
+    g = torch.Generator().manual_seed(7)
+    short = 0.1 * torch.randn(2, 16000 * 3 + 17, generator=g)
+    torch.testing.assert_close(hip.logmel(short.cuda(), 128).cpu(), O.logmel(short, 128), rtol=0, atol=2e-4)
+    long = 0.1 * torch.randn(1, 480000 + 5000, generator=g)
+    torch.testing.assert_close(hip.logmel(long.cuda(), 128).cpu(), O.logmel(long, 128), rtol=0, atol=2e-4)
+
+
+def _run_adafactor_case(hip, shapes, steps, gscale):
+    from desta.optim import ParamArena, FusedAdafactor
+    g = torch.Generator().manual_seed(3)
+    names = [f"t{i}.{'bias' if len(s) == 1 else 'weight'}" for i, s in enumerate(shapes)]
+    arena = ParamArena(list(zip(names, shapes)), "cuda")
+    p_o = []
+    for n, s in zip(names, shapes):
+        v = torch.randn(*s, generator=g)
+        arena.param(n).copy_(v)
+        p_o.append(v.clone())
+    opt = FusedAdafactor(arena, weight_decay=0.01)
+    wd = [0.01 if m else 0.0 for m in O.decay_mask(names)]
+    st = O.adafactor_init(p_o)
+    for step in range(steps):
+        grads = [torch.randn(*s, generator=g) * gscale[step % len(gscale)] for s in shapes]
+        for n, gr in zip(names, grads):
+            arena.grad(n).copy_(gr)
+        lr = O.linear_warmup_lr(step + 1, 1e-2, 3, 20)
+        opt.step(lr)
+        go = [x.clone() for x in grads]
+        n_o = O.clip_grad_norm(go, 1.0)
+        O.adafactor_step(p_o, go, st, lr, wd)
+        assert abs(float(opt.grad_norm()) - float(n_o)) <= 2e-6 * max(1.0, float(n_o))
+        for n, ref in zip(names, p_o):
+            torch.testing.assert_close(arena.param(n).cpu(), ref, rtol=2e-6, atol=2e-7)
+    return arena, opt
+
+
+def test_adafactor_matches_oracle_small(hip):
+    _run_adafactor_case(hip, [(1, 16, 24), (24, 40), (40,), (16, 4), (7,), (130, 260)], steps=5, gscale=[0.05, 10.0, 1e-3])
+
+
+def test_adafactor_connector_shapes(hip):
+    """Shapes of the real connector tensors (largest: 1280x3072, 4096x1280) incl. the 3-D prompts."""
+    shapes = [(64, 4), (1, 64, 1280), (3072, 1280), (3072,), (1280, 3072), (1280,), (4096, 1280), (4096,)]
+    _run_adafactor_case(hip, shapes, steps=2, gscale=[0.02, 3.0])
+
+
+def test_adafactor_is_deterministic(hip):
+    a1, _ = _run_adafactor_case(hip, [(300, 520), (520,)], steps=3, gscale=[1.0])
+    a2, _ = _run_adafactor_case(hip, [(300, 520), (520,)], steps=3, gscale=[1.0])
+    assert torch.equal(a1.params, a2.params)
