@@ -1,0 +1,504 @@
+// Flash-style attention for the three attention shapes of the DeSTA2.5 step on gfx950 (MFMA 32x32x16,
+// fp32 online softmax, no S x S matrix in HBM), forward + backward:
+//   Whisper encoder self-attention (non-causal, D=64)   TF:models/whisper/modeling_whisper.py:241-357
+//   Q-Former self-/cross-attention (non-causal, D=64)   TF:models/bert/modeling_bert.py:100-293 (eager)
+//   Llama / Qwen3 GQA causal attention with left-pad key mask (D=128 or 64)
+//                                                       TF:models/llama/modeling_llama.py:179-281
+// and their autograd backward (dQ, dK, dV).
+//
+// Orientation ("key on the register rows, query on the lane"): S^T = K·Q^T is computed with K as the
+// MFMA A operand (ds_read_b128 rows of an XOR-swizzled LDS image) and Q as the B operand (registers),
+// so every lane owns ONE query column: row max / row sum / rescale are lane-local scalars.  The fp32
+// S^T accumulator converts pairwise to bf16 and is used directly as the B operand of O^T += V^T·P^T
+// (no LDS round trip); V^T fragments come from the row-major V image with ds_read_b64_tr_b16.
+// K/V tiles are register-staged (global load of tile t+1 issued before the MFMAs of tile t).
+// Backward = two kernels without atomics (deterministic): dq (same skeleton as forward) and dkdv
+// (one wave owns 32 keys, sweeps the query heads of its GQA group and 32-row query slices).
+//
+// Fully masked query rows (left-pad positions) produce O = 0 and lse = +inf (their gradients are 0).
+#include "common.h"
+#include "desta_hip.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+struct AttnArgs {
+    const bf16_t* Q; const bf16_t* K; const bf16_t* V; bf16_t* O;
+    const bf16_t* dO; bf16_t* dQ; bf16_t* dK; bf16_t* dV;
+    float* lse; const float* delta;
+    long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;           // batch / row strides (elements)
+    long do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
+    int B, Hq, Hkv, Sq, Sk;
+    int causal;
+    const int* kv_start;                                             // [B] first valid key (left padding) or null
+    float scale_log2;                                                // softmax scale * log2(e)
+    float scale;
+};
+
+template <int D>
+__device__ __forceinline__ int img_off(int row, int ch) {
+    const int sw = (D == 128) ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
+    return row * (D * 2) + ((ch ^ sw) << 4);
+}
+
+// global -> registers for a ROWS x D bf16 tile (16-B chunks), rows clamped to [0, max_row]
+template <int D, int ROWS>
+__device__ __forceinline__ void tile_load(const bf16_t* base, long rs, int row0, int max_row, uint4* regs) {
+    constexpr int CH = D / 8, N = ROWS * CH / 256;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int id = i * 256 + threadIdx.x;
+        const int r = id / CH, c = id % CH;
+        const int gr = min(row0 + r, max_row);
+        regs[i] = *(const uint4*)(base + (long)gr * rs + c * 8);
+    }
+}
+template <int D, int ROWS>
+__device__ __forceinline__ void tile_store(char* img, const uint4* regs) {
+    constexpr int CH = D / 8, N = ROWS * CH / 256;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int id = i * 256 + threadIdx.x;
+        const int r = id / CH, c = id % CH;
+        *(uint4*)(img + img_off<D>(r, c)) = regs[i];
+    }
+}
+
+// A operand (32x32x16) read by rows: lane (row = row0 + (lane&31), k = 16*ks + 8*(lane>>5) + j)
+template <int D>
+__device__ __forceinline__ bf16x8 frag_rows(const char* img, int row0, int ks, int lane) {
+    const int r = row0 + (lane & 31);
+    return *(const bf16x8*)(img + img_off<D>(r, 2 * ks + (lane >> 5)));
+}
+
+// Transposed operand from a row-major [row][col] image: returns, for lane (c = col0 + (lane&31), h = lane>>5),
+// the 8 elements img[row0 + 8*(j>>2) + 4*h + (j&3)][c], j = 0..7  (the k order of an accumulator-fed MFMA).
+template <int D>
+__device__ __forceinline__ bf16x8 frag_tr(const char* img, int row0, int col0, int lane) {
+    const int i = lane & 15, g = (lane >> 4) & 1, h = lane >> 5;
+    const int q = i >> 2, pp = i & 3;
+    const int c = col0 + 16 * g + 4 * pp;                  // first column of this lane's 4-element piece
+    const int r_lo = row0 + 4 * h + q;
+    const int a0 = img_off<D>(r_lo, c >> 3) + ((c & 4) << 1);
+    const int a1 = img_off<D>(r_lo + 8, c >> 3) + ((c & 4) << 1);
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(img + a0));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(img + a1));
+    bf16x8 out;
+    out[0] = lo[0]; out[1] = lo[1]; out[2] = lo[2]; out[3] = lo[3];
+    out[4] = hi[0]; out[5] = hi[1]; out[6] = hi[2]; out[7] = hi[3];
+    return out;
+}
+
+// accumulator registers 8s..8s+7 -> bf16 fragment of k-step s
+__device__ __forceinline__ bf16x8 acc_frag(const f32x16& x, int s) {
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (__bf16)x[8 * s + j];
+    return o;
+}
+
+__device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// ------------------------------------------------------------------------------------------ forward
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * 64 * D * 2];
+    char* kimg = lds;
+    char* vimg = lds + 64 * D * 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h2 = lane >> 5;
+    const int qb0 = blockIdx.x * 128, q0 = qb0 + wave * 32;
+    const int h = blockIdx.y, b = blockIdx.z, hk = h / (p.Hq / p.Hkv);
+    const int qcol = q0 + (lane & 31);
+
+    const bf16_t* qptr = p.Q + (long)b * p.q_bs + (long)min(qcol, p.Sq - 1) * p.q_rs + (long)h * D;
+    bf16x8 qf[D / 16];
+#pragma unroll
+    for (int ds = 0; ds < D / 16; ++ds) qf[ds] = *(const bf16x8*)(qptr + 16 * ds + 8 * h2);
+
+    const int coff = p.Sk - p.Sq;
+    const int kv_lo = p.kv_start ? p.kv_start[b] : 0;
+    int kv_hi = p.Sk;
+    if (p.causal) kv_hi = min(p.Sk, min(qb0 + 127, p.Sq - 1) + coff + 1);
+    const int t_lo = kv_lo / 64, t_hi = (kv_hi + 63) / 64;
+    const int q_abs = qcol + coff;
+    const int wave_kmax = p.causal ? min(q0 + 31, p.Sq - 1) + coff : p.Sk - 1;   // last key any row of this wave may see
+
+    const bf16_t* kbase = p.K + (long)b * p.k_bs + (long)hk * D;
+    const bf16_t* vbase = p.V + (long)b * p.v_bs + (long)hk * D;
+
+    f32x16 oacc[D / 32];
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+
+    constexpr int NCH = 64 * (D / 8) / 256;
+    uint4 kr[NCH], vr[NCH];
+    if (t_lo < t_hi) {
+        tile_load<D, 64>(kbase, p.k_rs, t_lo * 64, p.Sk - 1, kr);
+        tile_load<D, 64>(vbase, p.v_rs, t_lo * 64, p.Sk - 1, vr);
+    }
+    for (int kt = t_lo; kt < t_hi; ++kt) {
+        __syncthreads();                                   // previous tile's LDS reads are done
+        tile_store<D, 64>(kimg, kr);
+        tile_store<D, 64>(vimg, vr);
+        __syncthreads();
+        if (kt + 1 < t_hi) {
+            tile_load<D, 64>(kbase, p.k_rs, (kt + 1) * 64, p.Sk - 1, kr);
+            tile_load<D, 64>(vbase, p.v_rs, (kt + 1) * 64, p.Sk - 1, vr);
+        }
+        if (kt * 64 > wave_kmax) continue;                 // wave-uniform: nothing visible in this tile
+        f32x16 st[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+#pragma unroll
+            for (int ds = 0; ds < D / 16; ++ds)
+                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(kimg, kb * 32, ds, lane), qf[ds], st[kb], 0, 0, 0);
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 64 + kb * 32 + acc_row(r, lane);
+                const bool ok = key < p.Sk && key >= kv_lo && (!p.causal || key <= q_abs);
+                const float s = ok ? st[kb][r] * p.scale_log2 : -INFINITY;
+                st[kb][r] = s;
+                tmax = fmaxf(tmax, s);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mnew = fmaxf(m, tmax);
+        const float muse = (mnew == -INFINITY) ? 0.f : mnew;
+        const float alpha = exp2f(m - muse);
+        float rs = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = exp2f(st[kb][r] - muse);
+                st[kb][r] = pv;
+                rs += pv;
+            }
+        rs += __shfl_xor(rs, 32, 64);
+        l = l * alpha + rs;
+        m = mnew;
+#pragma unroll
+        for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 pb = acc_frag(st[kb], s);
+#pragma unroll
+                for (int i = 0; i < D / 32; ++i)
+                    oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(vimg, kb * 32 + 16 * s, i * 32, lane), pb, oacc[i], 0, 0, 0);
+            }
+    }
+
+    if (qcol < p.Sq) {
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        bf16_t* optr = p.O + (long)b * p.o_bs + (long)qcol * p.o_rs + (long)h * D;
+#pragma unroll
+        for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                u16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = f2bf(oacc[i][4 * rq + e] * inv);
+                *(u16x4*)(optr + i * 32 + 8 * rq + 4 * h2) = o;
+            }
+        if (p.lse && h2 == 0) p.lse[((long)b * p.Hq + h) * p.Sq + qcol] = l > 0.f ? m + log2f(l) : INFINITY;
+    }
+}
+
+// delta[b,h,q] = sum_d dO[q,d] * O[q,d]
+template <int D>
+__global__ __launch_bounds__(256) void attn_delta_k(AttnArgs p, float* __restrict__ delta) {
+    constexpr int G = D / 8;                               // lanes per row
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long rowid = gid / G;
+    const int j = (int)(gid % G);
+    const long total = (long)p.B * p.Hq * p.Sq;
+    const bool active = rowid < total;
+    const long rr = active ? rowid : 0;
+    const int q = (int)(rr % p.Sq), h = (int)((rr / p.Sq) % p.Hq), b = (int)(rr / ((long)p.Sq * p.Hq));
+    const u16x8 o = *(const u16x8*)(p.O + (long)b * p.o_bs + (long)q * p.o_rs + (long)h * D + 8 * j);
+    const u16x8 g = *(const u16x8*)(p.dO + (long)b * p.do_bs + (long)q * p.do_rs + (long)h * D + 8 * j);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += bf2f(o[e]) * bf2f(g[e]);
+#pragma unroll
+    for (int o2 = 1; o2 < G; o2 <<= 1) s += __shfl_xor(s, o2, 64);
+    if (active && j == 0) delta[rowid] = s;
+}
+
+// ------------------------------------------------------------------------------------------ backward: dQ
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_k(AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * 64 * D * 2];
+    char* kimg = lds;
+    char* vimg = lds + 64 * D * 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h2 = lane >> 5;
+    const int qb0 = blockIdx.x * 128, q0 = qb0 + wave * 32;
+    const int h = blockIdx.y, b = blockIdx.z, hk = h / (p.Hq / p.Hkv);
+    const int qcol = q0 + (lane & 31), qc = min(qcol, p.Sq - 1);
+
+    const bf16_t* qptr = p.Q + (long)b * p.q_bs + (long)qc * p.q_rs + (long)h * D;
+    const bf16_t* gptr = p.dO + (long)b * p.do_bs + (long)qc * p.do_rs + (long)h * D;
+    bf16x8 qf[D / 16], gf[D / 16];
+#pragma unroll
+    for (int ds = 0; ds < D / 16; ++ds) {
+        qf[ds] = *(const bf16x8*)(qptr + 16 * ds + 8 * h2);
+        gf[ds] = *(const bf16x8*)(gptr + 16 * ds + 8 * h2);
+    }
+    const long stat = ((long)b * p.Hq + h) * p.Sq + qc;
+    const float lse = p.lse[stat], dlt = p.delta[stat];
+
+    const int coff = p.Sk - p.Sq;
+    const int kv_lo = p.kv_start ? p.kv_start[b] : 0;
+    int kv_hi = p.Sk;
+    if (p.causal) kv_hi = min(p.Sk, min(qb0 + 127, p.Sq - 1) + coff + 1);
+    const int t_lo = kv_lo / 64, t_hi = (kv_hi + 63) / 64;
+    const int q_abs = qcol + coff;
+    const int wave_kmax = p.causal ? min(q0 + 31, p.Sq - 1) + coff : p.Sk - 1;
+
+    const bf16_t* kbase = p.K + (long)b * p.k_bs + (long)hk * D;
+    const bf16_t* vbase = p.V + (long)b * p.v_bs + (long)hk * D;
+
+    f32x16 dq[D / 32];
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
+
+    constexpr int NCH = 64 * (D / 8) / 256;
+    uint4 kr[NCH], vr[NCH];
+    if (t_lo < t_hi) {
+        tile_load<D, 64>(kbase, p.k_rs, t_lo * 64, p.Sk - 1, kr);
+        tile_load<D, 64>(vbase, p.v_rs, t_lo * 64, p.Sk - 1, vr);
+    }
+    for (int kt = t_lo; kt < t_hi; ++kt) {
+        __syncthreads();
+        tile_store<D, 64>(kimg, kr);
+        tile_store<D, 64>(vimg, vr);
+        __syncthreads();
+        if (kt + 1 < t_hi) {
+            tile_load<D, 64>(kbase, p.k_rs, (kt + 1) * 64, p.Sk - 1, kr);
+            tile_load<D, 64>(vbase, p.v_rs, (kt + 1) * 64, p.Sk - 1, vr);
+        }
+        if (kt * 64 > wave_kmax) continue;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16 st, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ds = 0; ds < D / 16; ++ds) {
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(kimg, kb * 32, ds, lane), qf[ds], st, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(vimg, kb * 32, ds, lane), gf[ds], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 64 + kb * 32 + acc_row(r, lane);
+                const bool ok = key < p.Sk && key >= kv_lo && (!p.causal || key <= q_abs);
+                const float pv = ok ? exp2f(st[r] * p.scale_log2 - lse) : 0.f;
+                st[r] = pv * (dp[r] - dlt) * p.scale;      // dS^T
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 dsf = acc_frag(st, s);
+#pragma unroll
+                for (int i = 0; i < D / 32; ++i)
+                    dq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(kimg, kb * 32 + 16 * s, i * 32, lane), dsf, dq[i], 0, 0, 0);
+            }
+        }
+    }
+    if (qcol < p.Sq) {
+        bf16_t* optr = p.dQ + (long)b * p.dq_bs + (long)qcol * p.dq_rs + (long)h * D;
+#pragma unroll
+        for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                u16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = f2bf(dq[i][4 * rq + e]);
+                *(u16x4*)(optr + i * 32 + 8 * rq + 4 * h2) = o;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward: dK, dV
+// block = 128 keys of one (batch, kv head); wave w owns keys [k0 + 32w, k0 + 32w + 32)
+template <int D>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_k(AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * 32 * D * 2 + 2 * 32 * 4];
+    char* qimg = lds;
+    char* gimg = lds + 32 * D * 2;
+    float* lse_s = (float*)(lds + 2 * 32 * D * 2);
+    float* dlt_s = lse_s + 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h2 = lane >> 5;
+    const int kb0 = blockIdx.x * 128, k0 = kb0 + wave * 32;
+    const int hk = blockIdx.y, b = blockIdx.z, group = p.Hq / p.Hkv;
+    const int kcol = k0 + (lane & 31), kc = min(kcol, p.Sk - 1);
+    const int kv_lo = p.kv_start ? p.kv_start[b] : 0;
+    const int coff = p.Sk - p.Sq;
+
+    const bf16_t* kptr = p.K + (long)b * p.k_bs + (long)kc * p.k_rs + (long)hk * D;
+    const bf16_t* vptr = p.V + (long)b * p.v_bs + (long)kc * p.v_rs + (long)hk * D;
+    bf16x8 kf[D / 16], vf[D / 16];
+#pragma unroll
+    for (int ds = 0; ds < D / 16; ++ds) {
+        kf[ds] = *(const bf16x8*)(kptr + 16 * ds + 8 * h2);
+        vf[ds] = *(const bf16x8*)(vptr + 16 * ds + 8 * h2);
+    }
+    const bool key_ok = kcol < p.Sk && kcol >= kv_lo;
+
+    f32x16 dk[D / 32], dv[D / 32];
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+
+    // first query row that can see any key of this block
+    const int q_first = p.causal ? max(0, kb0 - coff) : 0;
+    const int qt_lo = q_first / 32, qt_hi = (p.Sq + 31) / 32;
+    constexpr int NCH = 32 * (D / 8) / 256;
+    uint4 qr[NCH > 0 ? NCH : 1], gr[NCH > 0 ? NCH : 1];
+
+    for (int hh = 0; hh < group; ++hh) {
+        const int h = hk * group + hh;
+        const bf16_t* qbase = p.Q + (long)b * p.q_bs + (long)h * D;
+        const bf16_t* gbase = p.dO + (long)b * p.do_bs + (long)h * D;
+        const long stat0 = ((long)b * p.Hq + h) * p.Sq;
+        for (int qt = qt_lo; qt < qt_hi; ++qt) {
+            __syncthreads();
+            if (NCH > 0) {
+                tile_load<D, 32>(qbase, p.q_rs, qt * 32, p.Sq - 1, qr);
+                tile_load<D, 32>(gbase, p.do_rs, qt * 32, p.Sq - 1, gr);
+                tile_store<D, 32>(qimg, qr);
+                tile_store<D, 32>(gimg, gr);
+            }
+            if (threadIdx.x < 32) {
+                const int q = min(qt * 32 + (int)threadIdx.x, p.Sq - 1);
+                lse_s[threadIdx.x] = p.lse[stat0 + q];
+                dlt_s[threadIdx.x] = p.delta[stat0 + q];
+            }
+            __syncthreads();
+            // wave-uniform skip: under the causal mask this wave's keys are all in the future of this q tile
+            if (p.causal && k0 > qt * 32 + 31 + coff) continue;
+            f32x16 st, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ds = 0; ds < D / 16; ++ds) {
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(qimg, 0, ds, lane), kf[ds], st, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(gimg, 0, ds, lane), vf[ds], dp, 0, 0, 0);
+            }
+            // st[r]: S[q = qt*32 + acc_row(r)][key = kcol]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ql = acc_row(r, lane), q = qt * 32 + ql;
+                const bool ok = key_ok && q < p.Sq && (!p.causal || kcol <= q + coff);
+                const float pv = ok ? exp2f(st[r] * p.scale_log2 - lse_s[ql]) : 0.f;
+                st[r] = pv;                                                  // P
+                dp[r] = pv * (dp[r] - dlt_s[ql]) * p.scale;                  // dS
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 pf = acc_frag(st, s), dsf = acc_frag(dp, s);
+#pragma unroll
+                for (int i = 0; i < D / 32; ++i) {
+                    dv[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, frag_tr<D>(gimg, 16 * s, i * 32, lane), dv[i], 0, 0, 0);
+                    dk[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf, frag_tr<D>(qimg, 16 * s, i * 32, lane), dk[i], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // dk[i][r]: dK[key = k0 + acc_row(r)][d = i*32 + (lane&31)]
+    bf16_t* dkp = p.dK + (long)b * p.dk_bs + (long)hk * D;
+    bf16_t* dvp = p.dV + (long)b * p.dv_bs + (long)hk * D;
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + acc_row(r, lane);
+            if (key < p.Sk) {
+                dkp[(long)key * p.dk_rs + i * 32 + (lane & 31)] = f2bf(dk[i][r]);
+                dvp[(long)key * p.dv_rs + i * 32 + (lane & 31)] = f2bf(dv[i][r]);
+            }
+        }
+}
+
+int fill_args(const desta_attn_desc* d, AttnArgs& a) {
+    DESTA_CHECK_ARG(d && d->Q && d->K && d->V, "attention: null operand");
+    DESTA_CHECK_ARG(d->head_dim == 64 || d->head_dim == 128, "attention: head_dim %d unsupported (64 or 128)", d->head_dim);
+    DESTA_CHECK_ARG(d->batch > 0 && d->n_q_heads > 0 && d->n_kv_heads > 0 && d->n_q_heads % d->n_kv_heads == 0,
+                    "attention: bad head counts");
+    DESTA_CHECK_ARG(d->seq_q > 0 && d->seq_k > 0, "attention: bad sequence lengths");
+    DESTA_CHECK_ARG(!d->causal || d->seq_k >= d->seq_q, "attention: causal needs seq_k >= seq_q");
+    DESTA_CHECK_ARG(d->q_row_stride % 8 == 0 && d->k_row_stride % 8 == 0 && d->v_row_stride % 8 == 0,
+                    "attention: row strides must be multiples of 8 elements");
+    DESTA_CHECK_ARG(d->batch <= 65535 && d->n_q_heads <= 65535, "attention: grid too large");
+    a.Q = (const bf16_t*)d->Q; a.K = (const bf16_t*)d->K; a.V = (const bf16_t*)d->V; a.O = (bf16_t*)d->O;
+    a.dO = (const bf16_t*)d->dO; a.dQ = (bf16_t*)d->dQ; a.dK = (bf16_t*)d->dK; a.dV = (bf16_t*)d->dV;
+    a.lse = d->lse; a.delta = nullptr;
+    a.q_bs = d->q_batch_stride; a.q_rs = d->q_row_stride; a.k_bs = d->k_batch_stride; a.k_rs = d->k_row_stride;
+    a.v_bs = d->v_batch_stride; a.v_rs = d->v_row_stride; a.o_bs = d->o_batch_stride; a.o_rs = d->o_row_stride;
+    a.do_bs = d->do_batch_stride; a.do_rs = d->do_row_stride; a.dq_bs = d->dq_batch_stride; a.dq_rs = d->dq_row_stride;
+    a.dk_bs = d->dk_batch_stride; a.dk_rs = d->dk_row_stride; a.dv_bs = d->dv_batch_stride; a.dv_rs = d->dv_row_stride;
+    a.B = d->batch; a.Hq = d->n_q_heads; a.Hkv = d->n_kv_heads; a.Sq = d->seq_q; a.Sk = d->seq_k;
+    a.causal = d->causal; a.kv_start = d->kv_start;
+    a.scale = d->scale; a.scale_log2 = d->scale * 1.44269504088896340736f;
+    return DESTA_OK;
+}
+
+}  // namespace
+
+extern "C" int desta_attention_fwd(const desta_attn_desc* d, void* stream) {
+    AttnArgs a;
+    if (int rc = fill_args(d, a)) return rc;
+    DESTA_CHECK_ARG(d->O, "attention_fwd: null output");
+    DESTA_CHECK_ARG(d->o_row_stride % 4 == 0, "attention_fwd: o_row_stride must be a multiple of 4");
+    dim3 grid((a.Sq + 127) / 128, a.Hq, a.B);
+    if (d->head_dim == 128) hipLaunchKernelGGL(attn_fwd_k<128>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(attn_fwd_k<64>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    DESTA_CHECK_LAUNCH("attention_fwd");
+    return DESTA_OK;
+}
+
+extern "C" size_t desta_attention_bwd_workspace_floats(int batch, int n_q_heads, int seq_q) {
+    return (size_t)batch * n_q_heads * seq_q;
+}
+
+extern "C" int desta_attention_bwd(const desta_attn_desc* d, float* workspace, void* stream) {
+    AttnArgs a;
+    if (int rc = fill_args(d, a)) return rc;
+    DESTA_CHECK_ARG(d->O && d->dO && d->lse && workspace && d->dQ, "attention_bwd: null argument");
+    DESTA_CHECK_ARG((d->dK == nullptr) == (d->dV == nullptr), "attention_bwd: dK and dV go together");
+    DESTA_CHECK_ARG(d->dq_row_stride % 4 == 0 && d->do_row_stride % 8 == 0 && d->o_row_stride % 8 == 0,
+                    "attention_bwd: bad strides");
+    a.delta = workspace;
+    hipStream_t st = (hipStream_t)stream;
+    const long rows = (long)a.B * a.Hq * a.Sq;
+    const int G = d->head_dim / 8;
+    dim3 gd((unsigned)((rows * G + 255) / 256));
+    dim3 gq((a.Sq + 127) / 128, a.Hq, a.B);
+    dim3 gk((a.Sk + 127) / 128, a.Hkv, a.B);
+    if (d->head_dim == 128) {
+        hipLaunchKernelGGL(attn_delta_k<128>, gd, dim3(256), 0, st, a, workspace);
+        hipLaunchKernelGGL(attn_bwd_dq_k<128>, gq, dim3(256), 0, st, a);
+        if (d->dK) hipLaunchKernelGGL(attn_bwd_dkdv_k<128>, gk, dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(attn_delta_k<64>, gd, dim3(256), 0, st, a, workspace);
+        hipLaunchKernelGGL(attn_bwd_dq_k<64>, gq, dim3(256), 0, st, a);
+        if (d->dK) hipLaunchKernelGGL(attn_bwd_dkdv_k<64>, gk, dim3(256), 0, st, a);
+    }
+    DESTA_CHECK_LAUNCH("attention_bwd");
+    return DESTA_OK;
+}

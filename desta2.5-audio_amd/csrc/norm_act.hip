@@ -1,0 +1,612 @@
+// Row-wise normalisation / activation / layout kernels of the DeSTA2.5 step (gfx950, all HBM-bound:
+// 16-B per-lane accesses, one wave per row, fp32 statistics, everything else fused into the GEMM
+// epilogues).  Reference call sites (TF: = transformers 5.15):
+//   LayerNorm fwd/bwd ... TF:models/whisper/modeling_whisper.py:392,402 (pre-LN, eps 1e-5),
+//                         TF:models/bert/modeling_bert.py:296,350 (post-LN, eps 1e-12),
+//                         modeling_desta25.py:166 (proj.0)
+//   RMSNorm fwd/bwd ..... TF:models/llama/modeling_llama.py:53-67
+//   RoPE (+ q/k norm) ... TF:models/llama/modeling_llama.py:126-160, TF:models/qwen3/modeling_qwen3.py:237-257
+//   SwiGLU .............. TF:models/llama/modeling_llama.py:163-176
+//   GELU' ............... autograd of F.gelu (erf form)
+#include "common.h"
+#include "desta_hip.h"
+
+namespace {
+
+constexpr int RPB = 4;  // rows per block = waves per block
+
+__device__ __forceinline__ void load8(const void* base, long idx, int is_f32, float* v) {
+    if (is_f32) {
+        const float4 a = *(const float4*)((const float*)base + idx);
+        const float4 b = *(const float4*)((const float*)base + idx + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+        const u16x8 a = *(const u16x8*)((const bf16_t*)base + idx);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = bf2f(a[e]);
+    }
+}
+__device__ __forceinline__ void store8_bf16(bf16_t* base, long idx, const float* v) {
+    u16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+    *(u16x8*)(base + idx) = o;
+}
+__device__ __forceinline__ void store8_f32(float* base, long idx, const float* v) {
+    *(float4*)(base + idx) = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)(base + idx + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+// ------------------------------------------------------------------------------------ LayerNorm
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_fwd_k(const void* __restrict__ x, int x_f32, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, int rows, int cols,
+                                                       bf16_t* __restrict__ y16, float* __restrict__ y32,
+                                                       float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * RPB + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[MAXV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < cols) {
+            load8(x, (long)row * cols + c, x_f32, v[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[i][e];
+        }
+    }
+    const float mean = wave_sum(s) / (float)cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < cols) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
+    if (stats && lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < cols) {
+            float g[8], b[8], o[8];
+            load8(gamma, c, 1, g);
+            load8(beta, c, 1, b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+            if (y16) store8_bf16(y16, (long)row * cols + c, o);
+            if (y32) store8_f32(y32, (long)row * cols + c, o);
+        }
+    }
+}
+
+// dx and per-block partial dgamma/dbeta.  part: [gridDim.x][2][cols]
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_bwd_k(const void* __restrict__ dy, int dy_f32, const void* __restrict__ x,
+                                                       int x_f32, const float* __restrict__ gamma,
+                                                       const float* __restrict__ stats, int rows, int cols,
+                                                       float* __restrict__ dx32, bf16_t* __restrict__ dx16,
+                                                       float* __restrict__ part) {
+    __shared__ float comb[RPB][64 * 8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float dg[MAXV][8], db[MAXV][8];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
+    for (int row = blockIdx.x * RPB + wave; row < rows; row += gridDim.x * RPB) {
+        const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+        float xh[MAXV][8], gy[MAXV][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = (i * 64 + lane) * 8;
+            if (c < cols) {
+                float xv[8], dyv[8], g[8];
+                load8(x, (long)row * cols + c, x_f32, xv);
+                load8(dy, (long)row * cols + c, dy_f32, dyv);
+                load8(gamma, c, 1, g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    xh[i][e] = (xv[e] - mean) * rstd;
+                    gy[i][e] = dyv[e] * g[e];
+                    s1 += gy[i][e];
+                    s2 += gy[i][e] * xh[i][e];
+                    dg[i][e] += dyv[e] * xh[i][e];
+                    db[i][e] += dyv[e];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)cols;
+        s2 = wave_sum(s2) / (float)cols;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = (i * 64 + lane) * 8;
+            if (c < cols) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rstd * (gy[i][e] - s1 - xh[i][e] * s2);
+                if (dx32) store8_f32(dx32, (long)row * cols + c, o);
+                if (dx16) store8_bf16(dx16, (long)row * cols + c, o);
+            }
+        }
+    }
+    if (!part) return;
+    // combine the block's 4 waves (fixed order) and write the partial rows
+    for (int which = 0; which < 2; ++which) {
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            if (i * 512 < cols) {
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < 8; ++e) comb[wave][lane * 8 + e] = which ? db[i][e] : dg[i][e];
+                __syncthreads();
+                for (int j = threadIdx.x; j < 512; j += 256) {
+                    const int c = i * 512 + j;
+                    if (c < cols)
+                        part[((long)blockIdx.x * 2 + which) * cols + c] = (comb[0][j] + comb[1][j]) + (comb[2][j] + comb[3][j]);
+                }
+            }
+        }
+    }
+}
+
+// out[which][c] (+)= sum_b part[b][which][c];  also used for column sums (bias gradients)
+__global__ __launch_bounds__(256) void reduce_partials_k(const float* __restrict__ part, int nblk, int width,
+                                                         float* __restrict__ out0, float* __restrict__ out1, int cols,
+                                                         int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= width) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[(long)b * width + c];
+    float* o = (c < cols) ? out0 + c : out1 + (c - cols);
+    *o = accumulate ? *o + s : s;
+}
+
+// column sums of a bf16 [rows, cols] matrix -> per-block partials [gridDim.y][cols]
+__global__ __launch_bounds__(256) void colsum_partial_k(const bf16_t* __restrict__ x, int rows, int cols, long ld,
+                                                        float* __restrict__ part) {
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c >= cols) return;
+    const int r0 = blockIdx.y, nr = gridDim.y;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = r0; r < rows; r += nr) {
+        const u16x4 v = *(const u16x4*)(x + (long)r * ld + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += bf2f(v[e]);
+    }
+    *(float4*)(part + (long)r0 * cols + c) = make_float4(s[0], s[1], s[2], s[3]);
+}
+
+// ------------------------------------------------------------------------------------ RMSNorm
+template <int MAXV>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_k(const bf16_t* __restrict__ x, const float* __restrict__ w, float eps,
+                                                     int rows, int cols, bf16_t* __restrict__ y, float* __restrict__ rstd_out) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * RPB + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[MAXV][8];
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < cols) {
+            load8(x, (long)row * cols + c, 0, v[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q += v[i][e] * v[i][e];
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
+    if (rstd_out && lane == 0) rstd_out[row] = rstd;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < cols) {
+            float g[8], o[8];
+            load8(w, c, 1, g);
+            // HF: weight * (x * rstd).to(bf16)  -> round the normalised value first
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = g[e] * bf2f(f2bf(v[i][e] * rstd));
+            store8_bf16(y, (long)row * cols + c, o);
+        }
+    }
+}
+
+// dx = [dres +] rstd * (w*dy - xhat * mean(w*dy*xhat))
+template <int MAXV>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                     const float* __restrict__ w, const float* __restrict__ rstd_in,
+                                                     const bf16_t* __restrict__ dres, int rows, int cols,
+                                                     bf16_t* __restrict__ dx) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * RPB + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float rstd = rstd_in[row];
+    float xh[MAXV][8], gy[MAXV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < cols) {
+            float xv[8], dyv[8], g[8];
+            load8(x, (long)row * cols + c, 0, xv);
+            load8(dy, (long)row * cols + c, 0, dyv);
+            load8(w, c, 1, g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                xh[i][e] = xv[e] * rstd;
+                gy[i][e] = dyv[e] * g[e];
+                s += gy[i][e] * xh[i][e];
+            }
+        }
+    }
+    s = wave_sum(s) / (float)cols;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < cols) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = rstd * (gy[i][e] - xh[i][e] * s);
+            if (dres) {
+                float r[8];
+                load8(dres, (long)row * cols + c, 0, r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] += r[e];
+            }
+            store8_bf16(dx, (long)row * cols + c, o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ RoPE (+ per-head q/k RMSNorm)
+// buf: [rows, ld] bf16; heads [0, n_heads) of width HD starting at column 0 are rotated in place.
+// G = HD/16 lanes own one head: lane j holds elements 8j..8j+7 of both halves.
+// NORM: 0 = plain rope; 1 = fwd (rmsnorm with weight then rope); 2 = bwd of (1) given saved pre-norm x.
+template <int HD, int NORM, bool BWD>
+__global__ __launch_bounds__(256) void rope_k(bf16_t* __restrict__ buf, long ld, int rows, int S, int n_heads, int n_q,
+                                              const float* __restrict__ cs, const float* __restrict__ wq,
+                                              const float* __restrict__ wk, float eps, const bf16_t* __restrict__ pre,
+                                              long ld_pre) {
+    constexpr int G = HD / 16, H2 = HD / 2;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long grp = gid / G;
+    const int j = (int)(gid % G);
+    const bool active = grp < (long)rows * n_heads;
+    const int row = active ? (int)(grp / n_heads) : 0, head = active ? (int)(grp % n_heads) : 0;
+    const int pos = row % S;
+    bf16_t* p = buf + (long)row * ld + (long)head * HD;
+    float a[8], b[8], c[8], s[8];
+    load8(p, 8 * j, 0, a);
+    load8(p, H2 + 8 * j, 0, b);
+    load8(cs, ((long)pos * 2) * H2 + 8 * j, 1, c);
+    load8(cs, ((long)pos * 2 + 1) * H2 + 8 * j, 1, s);
+    if (!BWD) {
+        if (NORM == 1) {
+            const float* w = head < n_q ? wq : wk;
+            float q = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q += a[e] * a[e] + b[e] * b[e];
+#pragma unroll
+            for (int o = 1; o < G; o <<= 1) q += __shfl_xor(q, o, 64);
+            const float rstd = rsqrtf(q / (float)HD + eps);
+            float wa[8], wb[8];
+            load8(w, 8 * j, 1, wa);
+            load8(w, H2 + 8 * j, 1, wb);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                a[e] = bf2f(f2bf(wa[e] * bf2f(f2bf(a[e] * rstd))));
+                b[e] = bf2f(f2bf(wb[e] * bf2f(f2bf(b[e] * rstd))));
+            }
+        }
+        float oa[8], ob[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { oa[e] = a[e] * c[e] - b[e] * s[e]; ob[e] = b[e] * c[e] + a[e] * s[e]; }
+        if (active) { store8_bf16(p, 8 * j, oa); store8_bf16(p, H2 + 8 * j, ob); }
+    } else {
+        float ga[8], gb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ga[e] = a[e] * c[e] + b[e] * s[e]; gb[e] = b[e] * c[e] - a[e] * s[e]; }
+        if (NORM == 2) {
+            const float* w = head < n_q ? wq : wk;
+            const bf16_t* pp = pre + (long)row * ld_pre + (long)head * HD;
+            float xa[8], xb[8], wa[8], wb[8];
+            load8(pp, 8 * j, 0, xa);
+            load8(pp, H2 + 8 * j, 0, xb);
+            load8(w, 8 * j, 1, wa);
+            load8(w, H2 + 8 * j, 1, wb);
+            float q = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q += xa[e] * xa[e] + xb[e] * xb[e];
+#pragma unroll
+            for (int o = 1; o < G; o <<= 1) q += __shfl_xor(q, o, 64);
+            const float rstd = rsqrtf(q / (float)HD + eps);
+            float t = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                ga[e] *= wa[e]; gb[e] *= wb[e];
+                xa[e] *= rstd; xb[e] *= rstd;
+                t += ga[e] * xa[e] + gb[e] * xb[e];
+            }
+#pragma unroll
+            for (int o = 1; o < G; o <<= 1) t += __shfl_xor(t, o, 64);
+            t /= (float)HD;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ga[e] = rstd * (ga[e] - xa[e] * t); gb[e] = rstd * (gb[e] - xb[e] * t); }
+        }
+        if (active) { store8_bf16(p, 8 * j, ga); store8_bf16(p, H2 + 8 * j, gb); }
+    }
+}
+
+// ------------------------------------------------------------------------------------ SwiGLU / GELU'
+// gu: [rows, 2*I] (gate | up); act: [rows, I]
+__global__ __launch_bounds__(256) void swiglu_fwd_k(const bf16_t* __restrict__ gu, bf16_t* __restrict__ act, long rows, int I) {
+    const long n8 = rows * (I / 8);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const long r = i / (I / 8);
+        const int c = (int)(i % (I / 8)) * 8;
+        float g[8], u[8], o[8];
+        load8(gu, r * 2 * I + c, 0, g);
+        load8(gu, r * 2 * I + I + c, 0, u);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float sg = g[e] / (1.0f + __expf(-g[e]));
+            o[e] = bf2f(f2bf(sg)) * u[e];                  // HF rounds silu(gate) to bf16 before the product
+        }
+        store8_bf16(act, r * I + c, o);
+    }
+}
+__global__ __launch_bounds__(256) void swiglu_bwd_k(const bf16_t* __restrict__ gu, const bf16_t* __restrict__ dact,
+                                                    bf16_t* __restrict__ dgu, long rows, int I) {
+    const long n8 = rows * (I / 8);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const long r = i / (I / 8);
+        const int c = (int)(i % (I / 8)) * 8;
+        float g[8], u[8], d[8], dg[8], du[8];
+        load8(gu, r * 2 * I + c, 0, g);
+        load8(gu, r * 2 * I + I + c, 0, u);
+        load8(dact, r * I + c, 0, d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float sig = 1.0f / (1.0f + __expf(-g[e]));
+            const float sg = g[e] * sig;
+            du[e] = d[e] * sg;
+            dg[e] = d[e] * u[e] * (sig * (1.0f + g[e] * (1.0f - sig)));
+        }
+        store8_bf16(dgu, r * 2 * I + c, dg);
+        store8_bf16(dgu, r * 2 * I + I + c, du);
+    }
+}
+__global__ __launch_bounds__(256) void gelu_bwd_k(const bf16_t* __restrict__ pre, const bf16_t* __restrict__ dact,
+                                                  bf16_t* __restrict__ dpre, long n8) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        float x[8], d[8], o[8];
+        load8(pre, i * 8, 0, x);
+        load8(dact, i * 8, 0, d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = d[e] * gelu_erf_grad(x[e]);
+        store8_bf16(dpre, i * 8, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------ casts / transposes / adds
+__global__ __launch_bounds__(256) void cast_f32_bf16_k(const float* __restrict__ x, bf16_t* __restrict__ y, long n8) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        float v[8];
+        load8(x, i * 8, 1, v);
+        store8_bf16(y, i * 8, v);
+    }
+}
+__global__ __launch_bounds__(256) void add_f32_k(float* __restrict__ y, const float* __restrict__ x, long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 a = ((float4*)y)[i];
+        const float4 b = ((const float4*)x)[i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        ((float4*)y)[i] = a;
+    }
+}
+// out[c][r] = in[r][c]; out has ld_out >= rows columns, tail [rows, ld_out) zero filled. 64x64 tiles via LDS.
+template <bool IN_F32>
+__global__ __launch_bounds__(256) void transpose_k(const void* __restrict__ in, long ld_in, int rows, int cols,
+                                                   bf16_t* __restrict__ out, long ld_out) {
+    __shared__ bf16_t tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        bf16_t v = 0;
+        if (r < rows && c < cols) v = IN_F32 ? f2bf(((const float*)in)[(long)r * ld_in + c]) : ((const bf16_t*)in)[(long)r * ld_in + c];
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < ld_out) out[(long)c * ld_out + r] = tile[tx][i];
+    }
+}
+
+// mel [B, C, T] f32 -> rows [B, T+2, Cp] bf16 with zero rows at t=0 and t=T+1 and zero channels >= C
+__global__ __launch_bounds__(256) void mel_rows_k(const float* __restrict__ mel, int B, int Cn, int T, int Cp,
+                                                  bf16_t* __restrict__ out) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z, t0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, t = t0 + tx;
+        tile[i][tx] = (c < Cn && t < T) ? mel[((long)b * Cn + c) * T + t] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int t = t0 + i, c = c0 + tx;
+        if (t < T && c < Cp) out[((long)b * (T + 2) + t + 1) * Cp + c] = f2bf(tile[tx][i]);
+    }
+}
+
+int nblocks(long n, int per = 256, int cap = 8192) {
+    long b = (n + per - 1) / per;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+#define LN_DISPATCH(KERNEL, cols, ...)                                                         \
+    do {                                                                                       \
+        if ((cols) <= 512) hipLaunchKernelGGL((KERNEL<1>), __VA_ARGS__);                       \
+        else if ((cols) <= 1024) hipLaunchKernelGGL((KERNEL<2>), __VA_ARGS__);                 \
+        else if ((cols) <= 2048) hipLaunchKernelGGL((KERNEL<4>), __VA_ARGS__);                 \
+        else if ((cols) <= 4096) hipLaunchKernelGGL((KERNEL<8>), __VA_ARGS__);                 \
+        else hipLaunchKernelGGL((KERNEL<16>), __VA_ARGS__);                                    \
+    } while (0)
+
+extern "C" int desta_layernorm_fwd(const void* x, int x_f32, const float* gamma, const float* beta, float eps, int rows,
+                                   int cols, void* y_bf16, float* y_f32, float* stats, void* stream) {
+    DESTA_CHECK_ARG(x && gamma && beta && (y_bf16 || y_f32), "layernorm_fwd: null argument");
+    DESTA_CHECK_ARG(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 8192, "layernorm_fwd: cols=%d must be a multiple of 8, <= 8192", cols);
+    dim3 grid((rows + RPB - 1) / RPB);
+    LN_DISPATCH(layernorm_fwd_k, cols, grid, dim3(256), 0, (hipStream_t)stream, x, x_f32, gamma, beta, eps, rows, cols,
+                (bf16_t*)y_bf16, y_f32, stats);
+    DESTA_CHECK_LAUNCH("layernorm_fwd");
+    return DESTA_OK;
+}
+
+extern "C" size_t desta_layernorm_bwd_workspace_floats(int rows, int cols) {
+    int nb = (rows + RPB - 1) / RPB;
+    if (nb > 128) nb = 128;
+    return (size_t)nb * 2 * cols;
+}
+
+extern "C" int desta_layernorm_bwd(const void* dy, int dy_f32, const void* x, int x_f32, const float* gamma,
+                                   const float* stats, int rows, int cols, float* dx_f32, void* dx_bf16, float* dgamma,
+                                   float* dbeta, int accumulate, float* workspace, void* stream) {
+    DESTA_CHECK_ARG(dy && x && gamma && stats && (dx_f32 || dx_bf16), "layernorm_bwd: null argument");
+    DESTA_CHECK_ARG(rows > 0 && cols % 8 == 0 && cols <= 2048, "layernorm_bwd: cols=%d must be a multiple of 8, <= 2048", cols);
+    DESTA_CHECK_ARG(!dgamma || (dbeta && workspace), "layernorm_bwd: dgamma needs dbeta and workspace");
+    int nb = (rows + RPB - 1) / RPB;
+    if (nb > 128) nb = 128;
+    float* part = dgamma ? workspace : nullptr;
+    if (cols <= 512) hipLaunchKernelGGL((layernorm_bwd_k<1>), dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, dy_f32, x, x_f32, gamma, stats, rows, cols, dx_f32, (bf16_t*)dx_bf16, part);
+    else if (cols <= 1024) hipLaunchKernelGGL((layernorm_bwd_k<2>), dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, dy_f32, x, x_f32, gamma, stats, rows, cols, dx_f32, (bf16_t*)dx_bf16, part);
+    else hipLaunchKernelGGL((layernorm_bwd_k<4>), dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, dy_f32, x, x_f32, gamma, stats, rows, cols, dx_f32, (bf16_t*)dx_bf16, part);
+    if (dgamma)
+        hipLaunchKernelGGL(reduce_partials_k, dim3((2 * cols + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)part, nb, 2 * cols, dgamma, dbeta, cols, accumulate);
+    DESTA_CHECK_LAUNCH("layernorm_bwd");
+    return DESTA_OK;
+}
+
+extern "C" size_t desta_colsum_workspace_floats(int rows, int cols) {
+    int nr = rows < 64 ? rows : 64;
+    return (size_t)nr * cols;
+}
+
+extern "C" int desta_colsum_bf16(const void* x, int rows, int cols, int64_t ld, float* out, int accumulate,
+                                 float* workspace, void* stream) {
+    DESTA_CHECK_ARG(x && out && workspace, "colsum: null argument");
+    DESTA_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0 && ld % 4 == 0, "colsum: cols/ld must be multiples of 4");
+    const int nr = rows < 64 ? rows : 64;
+    hipLaunchKernelGGL(colsum_partial_k, dim3((cols / 4 + 255) / 256, nr), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, rows, cols, (long)ld, workspace);
+    hipLaunchKernelGGL(reduce_partials_k, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, nr, cols, out, out, cols, accumulate);
+    DESTA_CHECK_LAUNCH("colsum");
+    return DESTA_OK;
+}
+
+extern "C" int desta_rmsnorm_fwd(const void* x, const float* weight, float eps, int rows, int cols, void* y,
+                                 float* rstd, void* stream) {
+    DESTA_CHECK_ARG(x && weight && y, "rmsnorm_fwd: null argument");
+    DESTA_CHECK_ARG(rows > 0 && cols % 8 == 0 && cols <= 8192, "rmsnorm_fwd: cols=%d must be a multiple of 8, <= 8192", cols);
+    dim3 grid((rows + RPB - 1) / RPB);
+    LN_DISPATCH(rmsnorm_fwd_k, cols, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, weight, eps, rows, cols,
+                (bf16_t*)y, rstd);
+    DESTA_CHECK_LAUNCH("rmsnorm_fwd");
+    return DESTA_OK;
+}
+
+extern "C" int desta_rmsnorm_bwd(const void* dy, const void* x, const float* weight, const float* rstd,
+                                 const void* dres, int rows, int cols, void* dx, void* stream) {
+    DESTA_CHECK_ARG(dy && x && weight && rstd && dx, "rmsnorm_bwd: null argument");
+    DESTA_CHECK_ARG(rows > 0 && cols % 8 == 0 && cols <= 8192, "rmsnorm_bwd: cols=%d must be a multiple of 8, <= 8192", cols);
+    dim3 grid((rows + RPB - 1) / RPB);
+    LN_DISPATCH(rmsnorm_bwd_k, cols, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, weight,
+                rstd, (const bf16_t*)dres, rows, cols, (bf16_t*)dx);
+    DESTA_CHECK_LAUNCH("rmsnorm_bwd");
+    return DESTA_OK;
+}
+
+extern "C" int desta_rope(void* buf, int64_t ld, int rows, int seq, int n_q_heads, int n_kv_heads, int head_dim,
+                          const float* cos_sin, const float* q_norm_w, const float* k_norm_w, float eps,
+                          const void* pre_norm, int64_t ld_pre, int backward, void* stream) {
+    DESTA_CHECK_ARG(buf && cos_sin, "rope: null argument");
+    DESTA_CHECK_ARG(head_dim == 64 || head_dim == 128, "rope: head_dim %d unsupported (64 or 128)", head_dim);
+    DESTA_CHECK_ARG(ld % 8 == 0 && rows > 0 && seq > 0, "rope: bad shape");
+    const bool norm = q_norm_w != nullptr;
+    DESTA_CHECK_ARG(!norm || k_norm_w, "rope: q_norm without k_norm");
+    DESTA_CHECK_ARG(!(norm && backward) || pre_norm, "rope: backward with q/k norm needs the saved pre-norm q/k");
+    const int nh = n_q_heads + n_kv_heads;
+    const long nthreads = (long)rows * nh * (head_dim / 16);
+    dim3 grid((unsigned)((nthreads + 255) / 256));
+    hipStream_t st = (hipStream_t)stream;
+#define ROPE_ARGS grid, dim3(256), 0, st, (bf16_t*)buf, (long)ld, rows, seq, nh, n_q_heads, cos_sin, q_norm_w, k_norm_w, eps, (const bf16_t*)pre_norm, (long)ld_pre
+    if (head_dim == 128) {
+        if (!backward) { if (norm) hipLaunchKernelGGL((rope_k<128, 1, false>), ROPE_ARGS); else hipLaunchKernelGGL((rope_k<128, 0, false>), ROPE_ARGS); }
+        else { if (norm) hipLaunchKernelGGL((rope_k<128, 2, true>), ROPE_ARGS); else hipLaunchKernelGGL((rope_k<128, 0, true>), ROPE_ARGS); }
+    } else {
+        if (!backward) { if (norm) hipLaunchKernelGGL((rope_k<64, 1, false>), ROPE_ARGS); else hipLaunchKernelGGL((rope_k<64, 0, false>), ROPE_ARGS); }
+        else { if (norm) hipLaunchKernelGGL((rope_k<64, 2, true>), ROPE_ARGS); else hipLaunchKernelGGL((rope_k<64, 0, true>), ROPE_ARGS); }
+    }
+#undef ROPE_ARGS
+    DESTA_CHECK_LAUNCH("rope");
+    return DESTA_OK;
+}
+
+extern "C" int desta_swiglu_fwd(const void* gate_up, void* act, int64_t rows, int inter, void* stream) {
+    DESTA_CHECK_ARG(gate_up && act && rows > 0 && inter % 8 == 0, "swiglu_fwd: bad argument");
+    hipLaunchKernelGGL(swiglu_fwd_k, dim3(nblocks(rows * (inter / 8))), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)gate_up, (bf16_t*)act, (long)rows, inter);
+    DESTA_CHECK_LAUNCH("swiglu_fwd");
+    return DESTA_OK;
+}
+extern "C" int desta_swiglu_bwd(const void* gate_up, const void* dact, void* dgate_up, int64_t rows, int inter, void* stream) {
+    DESTA_CHECK_ARG(gate_up && dact && dgate_up && rows > 0 && inter % 8 == 0, "swiglu_bwd: bad argument");
+    hipLaunchKernelGGL(swiglu_bwd_k, dim3(nblocks(rows * (inter / 8))), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)gate_up, (const bf16_t*)dact, (bf16_t*)dgate_up, (long)rows, inter);
+    DESTA_CHECK_LAUNCH("swiglu_bwd");
+    return DESTA_OK;
+}
+extern "C" int desta_gelu_bwd(const void* preact, const void* dact, void* dpre, int64_t n, void* stream) {
+    DESTA_CHECK_ARG(preact && dact && dpre && n > 0 && n % 8 == 0, "gelu_bwd: n must be a positive multiple of 8");
+    hipLaunchKernelGGL(gelu_bwd_k, dim3(nblocks(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)preact,
+                       (const bf16_t*)dact, (bf16_t*)dpre, (long)(n / 8));
+    DESTA_CHECK_LAUNCH("gelu_bwd");
+    return DESTA_OK;
+}
+extern "C" int desta_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream) {
+    DESTA_CHECK_ARG(x && y && n > 0 && n % 8 == 0, "cast: n must be a positive multiple of 8");
+    hipLaunchKernelGGL(cast_f32_bf16_k, dim3(nblocks(n / 8)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, (long)(n / 8));
+    DESTA_CHECK_LAUNCH("cast_f32_bf16");
+    return DESTA_OK;
+}
+extern "C" int desta_add_f32(float* y, const float* x, int64_t n, void* stream) {
+    DESTA_CHECK_ARG(x && y && n > 0 && n % 4 == 0, "add_f32: n must be a positive multiple of 4");
+    hipLaunchKernelGGL(add_f32_k, dim3(nblocks(n / 4)), dim3(256), 0, (hipStream_t)stream, y, x, (long)(n / 4));
+    DESTA_CHECK_LAUNCH("add_f32");
+    return DESTA_OK;
+}
+extern "C" int desta_transpose_to_bf16(const void* in, int in_f32, int64_t ld_in, int rows, int cols, void* out,
+                                       int64_t ld_out, void* stream) {
+    DESTA_CHECK_ARG(in && out && rows > 0 && cols > 0 && ld_out >= rows, "transpose: bad argument");
+    dim3 grid((cols + 63) / 64, (unsigned)((ld_out + 63) / 64));
+    if (in_f32) hipLaunchKernelGGL((transpose_k<true>), grid, dim3(256), 0, (hipStream_t)stream, in, (long)ld_in, rows, cols, (bf16_t*)out, (long)ld_out);
+    else hipLaunchKernelGGL((transpose_k<false>), grid, dim3(256), 0, (hipStream_t)stream, in, (long)ld_in, rows, cols, (bf16_t*)out, (long)ld_out);
+    DESTA_CHECK_LAUNCH("transpose");
+    return DESTA_OK;
+}
+extern "C" int desta_mel_to_rows(const float* mel, int batch, int n_mels, int frames, int c_pad, void* out, void* stream) {
+    DESTA_CHECK_ARG(mel && out && batch > 0 && n_mels > 0 && frames > 0 && c_pad >= n_mels, "mel_to_rows: bad argument");
+    dim3 grid((frames + 63) / 64, (c_pad + 63) / 64, batch);
+    hipLaunchKernelGGL(mel_rows_k, grid, dim3(256), 0, (hipStream_t)stream, mel, batch, n_mels, frames, c_pad, (bf16_t*)out);
+    DESTA_CHECK_LAUNCH("mel_to_rows");
+    return DESTA_OK;
+}

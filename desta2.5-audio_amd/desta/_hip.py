@@ -138,3 +138,198 @@ def clip_adafactor_step(plan: OptPlan, params, grads, state, workspace, lr, beta
                         max_grad_norm):
     check(_adafactor(C.byref(plan), p(params), p(grads), p(state), p(workspace), lr, beta2t, eps1,
                      clip_threshold, max_grad_norm, stream()), "desta_clip_adafactor_step")
+
+
+# ----------------------------------------------------------------------------- norms / activations / layout
+c_size_t = C.c_size_t
+_ln_fwd = _sig("desta_layernorm_fwd", vp, i32, vp, vp, f32, i32, i32, vp, vp, vp, vp)
+lib.desta_layernorm_bwd_workspace_floats.restype = c_size_t
+lib.desta_layernorm_bwd_workspace_floats.argtypes = [i32, i32]
+_ln_bwd = _sig("desta_layernorm_bwd", vp, i32, vp, i32, vp, vp, i32, i32, vp, vp, vp, vp, i32, vp, vp)
+_rms_fwd = _sig("desta_rmsnorm_fwd", vp, vp, f32, i32, i32, vp, vp, vp)
+_rms_bwd = _sig("desta_rmsnorm_bwd", vp, vp, vp, vp, vp, i32, i32, vp, vp)
+lib.desta_colsum_workspace_floats.restype = c_size_t
+lib.desta_colsum_workspace_floats.argtypes = [i32, i32]
+_colsum = _sig("desta_colsum_bf16", vp, i32, i32, i64, vp, i32, vp, vp)
+_rope = _sig("desta_rope", vp, i64, i32, i32, i32, i32, i32, vp, vp, vp, f32, vp, i64, i32, vp)
+_swiglu_fwd = _sig("desta_swiglu_fwd", vp, vp, i64, i32, vp)
+_swiglu_bwd = _sig("desta_swiglu_bwd", vp, vp, vp, i64, i32, vp)
+_gelu_bwd = _sig("desta_gelu_bwd", vp, vp, vp, i64, vp)
+_cast = _sig("desta_cast_f32_bf16", vp, vp, i64, vp)
+_add = _sig("desta_add_f32", vp, vp, i64, vp)
+_transpose = _sig("desta_transpose_to_bf16", vp, i32, i64, i32, i32, vp, i64, vp)
+_mel_rows = _sig("desta_mel_to_rows", vp, i32, i32, i32, i32, vp, vp)
+
+_scratch = {}
+
+
+def scratch(nfloats: int, device, tag="ws") -> torch.Tensor:
+    """Grow-only fp32 scratch buffer per (device, tag); callers on one stream reuse it serially."""
+    key = (str(device), tag)
+    t = _scratch.get(key)
+    if t is None or t.numel() < nfloats:
+        t = torch.empty(max(nfloats, 1024), dtype=torch.float32, device=device)
+        _scratch[key] = t
+    return t
+
+
+def layernorm_fwd(x, gamma, beta, eps, y16=None, y32=None, stats=None):
+    rows, cols = x.numel() // x.shape[-1], x.shape[-1]
+    check(_ln_fwd(p(x), int(x.dtype == torch.float32), p(gamma), p(beta), eps, rows, cols, p(y16), p(y32), p(stats),
+                  stream()), "desta_layernorm_fwd")
+
+
+def layernorm_bwd(dy, x, gamma, stats, dx32=None, dx16=None, dgamma=None, dbeta=None, accumulate=False):
+    rows, cols = x.numel() // x.shape[-1], x.shape[-1]
+    ws = scratch(lib.desta_layernorm_bwd_workspace_floats(rows, cols), x.device) if dgamma is not None else None
+    check(_ln_bwd(p(dy), int(dy.dtype == torch.float32), p(x), int(x.dtype == torch.float32), p(gamma), p(stats), rows,
+                  cols, p(dx32), p(dx16), p(dgamma), p(dbeta), int(accumulate), p(ws), stream()), "desta_layernorm_bwd")
+
+
+def rmsnorm_fwd(x, weight, eps, y, rstd=None):
+    rows, cols = x.numel() // x.shape[-1], x.shape[-1]
+    check(_rms_fwd(p(x), p(weight), eps, rows, cols, p(y), p(rstd), stream()), "desta_rmsnorm_fwd")
+
+
+def rmsnorm_bwd(dy, x, weight, rstd, dx, dres=None):
+    rows, cols = x.numel() // x.shape[-1], x.shape[-1]
+    check(_rms_bwd(p(dy), p(x), p(weight), p(rstd), p(dres), rows, cols, p(dx), stream()), "desta_rmsnorm_bwd")
+
+
+def colsum(x, rows, cols, ld, out, accumulate=False):
+    ws = scratch(lib.desta_colsum_workspace_floats(rows, cols), x.device)
+    check(_colsum(p(x), rows, cols, ld, p(out), int(accumulate), p(ws), stream()), "desta_colsum_bf16")
+
+
+def rope(buf, ld, rows, seq, n_q, n_kv, hd, cos_sin, q_norm_w=None, k_norm_w=None, eps=1e-6, pre_norm=None,
+         ld_pre=0, backward=False):
+    check(_rope(p(buf), ld, rows, seq, n_q, n_kv, hd, p(cos_sin), p(q_norm_w), p(k_norm_w), eps, p(pre_norm), ld_pre,
+                int(backward), stream()), "desta_rope")
+
+
+def swiglu_fwd(gate_up, act, rows, inter):
+    check(_swiglu_fwd(p(gate_up), p(act), rows, inter, stream()), "desta_swiglu_fwd")
+
+
+def swiglu_bwd(gate_up, dact, dgate_up, rows, inter):
+    check(_swiglu_bwd(p(gate_up), p(dact), p(dgate_up), rows, inter, stream()), "desta_swiglu_bwd")
+
+
+def gelu_bwd(preact, dact, dpre, n):
+    check(_gelu_bwd(p(preact), p(dact), p(dpre), n, stream()), "desta_gelu_bwd")
+
+
+def cast_bf16(x, y, n=None):
+    check(_cast(p(x), p(y), x.numel() if n is None else n, stream()), "desta_cast_f32_bf16")
+
+
+def add_f32(y, x, n=None):
+    check(_add(p(y), p(x), y.numel() if n is None else n, stream()), "desta_add_f32")
+
+
+def transpose_to_bf16(src, rows, cols, out, ld_out, ld_in=None):
+    check(_transpose(p(src), int(src.dtype == torch.float32), cols if ld_in is None else ld_in, rows, cols, p(out),
+                     ld_out, stream()), "desta_transpose_to_bf16")
+
+
+def mel_to_rows(mel, c_pad, out):
+    B, Cn, T = mel.shape
+    check(_mel_rows(p(mel), B, Cn, T, c_pad, p(out), stream()), "desta_mel_to_rows")
+
+
+# ----------------------------------------------------------------------------- embed / CE / tap mix
+_embed = _sig("desta_embed_gather", vp, vp, vp, i32, i32, vp, vp)
+_gather = _sig("desta_gather_rows_bf16", vp, vp, i32, i32, vp, vp)
+lib.desta_ce_workspace_floats.restype = c_size_t
+lib.desta_ce_workspace_floats.argtypes = [i32, i32]
+_ce = _sig("desta_causal_lm_loss", vp, i64, vp, i32, i32, i32, vp, vp, i32, vp)
+_mix_fwd = _sig("desta_tap_mix_fwd", vp, vp, i32, i32, i32, i32, vp, vp)
+_mix_bwd = _sig("desta_tap_mix_bwd", vp, vp, vp, i32, i32, i32, i32, vp, vp, vp)
+
+
+def embed_gather(table, audio_rows, src_row, rows, hidden, out):
+    check(_embed(p(table), p(audio_rows), p(src_row), rows, hidden, p(out), stream()), "desta_embed_gather")
+
+
+def gather_rows(src, idx, rows, hidden, out):
+    check(_gather(p(src), p(idx), rows, hidden, p(out), stream()), "desta_gather_rows_bf16")
+
+
+def causal_lm_loss(logits, ld, labels, batch, seq, vocab, loss, write_grad=True):
+    ws = scratch(lib.desta_ce_workspace_floats(batch, seq), logits.device, "ce")
+    check(_ce(p(logits), ld, p(labels), batch, seq, vocab, p(loss), p(ws), int(write_grad), stream()),
+          "desta_causal_lm_loss")
+
+
+def tap_mix_fwd(x, lw, taps, batch, prompt, d, out):
+    check(_mix_fwd(p(x), p(lw), taps, batch, prompt, d, p(out), stream()), "desta_tap_mix_fwd")
+
+
+def tap_mix_bwd(x, lw, dout, taps, batch, prompt, d, dx, dlw):
+    check(_mix_bwd(p(x), p(lw), p(dout), taps, batch, prompt, d, p(dx), p(dlw), stream()), "desta_tap_mix_bwd")
+
+
+# ----------------------------------------------------------------------------- attention
+class AttnDesc(C.Structure):
+    _fields_ = [("Q", vp), ("K", vp), ("V", vp), ("O", vp), ("dO", vp), ("dQ", vp), ("dK", vp), ("dV", vp),
+                ("lse", vp),
+                ("q_batch_stride", i64), ("q_row_stride", i64), ("k_batch_stride", i64), ("k_row_stride", i64),
+                ("v_batch_stride", i64), ("v_row_stride", i64), ("o_batch_stride", i64), ("o_row_stride", i64),
+                ("do_batch_stride", i64), ("do_row_stride", i64), ("dq_batch_stride", i64), ("dq_row_stride", i64),
+                ("dk_batch_stride", i64), ("dk_row_stride", i64), ("dv_batch_stride", i64), ("dv_row_stride", i64),
+                ("batch", i32), ("n_q_heads", i32), ("n_kv_heads", i32), ("seq_q", i32), ("seq_k", i32),
+                ("head_dim", i32), ("causal", i32), ("kv_start", vp), ("scale", f32)]
+
+
+_attn_fwd = _sig("desta_attention_fwd", C.POINTER(AttnDesc), vp)
+lib.desta_attention_bwd_workspace_floats.restype = c_size_t
+lib.desta_attention_bwd_workspace_floats.argtypes = [i32, i32, i32]
+_attn_bwd = _sig("desta_attention_bwd", C.POINTER(AttnDesc), vp, vp)
+
+
+def _elem_ptr(t, offset_elems):
+    return t.data_ptr() + offset_elems * t.element_size()
+
+
+def attn_desc(q, k, v, o, lse, *, batch, hq, hkv, sq, sk, hd, scale, causal=False, kv_start=None,
+              q_off=0, k_off=0, v_off=0, q_rs=None, k_rs=None, v_rs=None, o_rs=None):
+    """q/k/v are 2-D row-major [batch*seq, row_stride] buffers (possibly the same fused buffer);
+    *_off = first column of the q/k/v slice."""
+    d = AttnDesc()
+    q_rs = q.shape[-1] if q_rs is None else q_rs
+    k_rs = k.shape[-1] if k_rs is None else k_rs
+    v_rs = v.shape[-1] if v_rs is None else v_rs
+    o_rs = o.shape[-1] if o_rs is None else o_rs
+    d.Q, d.K, d.V, d.O = _elem_ptr(q, q_off), _elem_ptr(k, k_off), _elem_ptr(v, v_off), p(o)
+    d.lse = p(lse)
+    d.q_row_stride, d.q_batch_stride = q_rs, sq * q_rs
+    d.k_row_stride, d.k_batch_stride = k_rs, sk * k_rs
+    d.v_row_stride, d.v_batch_stride = v_rs, sk * v_rs
+    d.o_row_stride, d.o_batch_stride = o_rs, sq * o_rs
+    d.batch, d.n_q_heads, d.n_kv_heads, d.seq_q, d.seq_k, d.head_dim = batch, hq, hkv, sq, sk, hd
+    d.causal = int(causal)
+    d.kv_start = p(kv_start)
+    d.scale = scale
+    return d
+
+
+def attention_fwd(d: AttnDesc):
+    check(_attn_fwd(C.byref(d), stream()), "desta_attention_fwd")
+
+
+def attention_bwd(d: AttnDesc, do, dq, dk=None, dv=None, *, do_rs=None, dq_off=0, dk_off=0, dv_off=0, dq_rs=None,
+                  dk_rs=None, dv_rs=None):
+    """Backward of the attention described by `d` (O and lse filled by forward)."""
+    do_rs = do.shape[-1] if do_rs is None else do_rs
+    dq_rs = dq.shape[-1] if dq_rs is None else dq_rs
+    d.dO, d.do_row_stride, d.do_batch_stride = p(do), do_rs, d.seq_q * do_rs
+    d.dQ, d.dq_row_stride, d.dq_batch_stride = _elem_ptr(dq, dq_off), dq_rs, d.seq_q * dq_rs
+    if dk is not None:
+        dk_rs = dk.shape[-1] if dk_rs is None else dk_rs
+        dv_rs = dv.shape[-1] if dv_rs is None else dv_rs
+        d.dK, d.dk_row_stride, d.dk_batch_stride = _elem_ptr(dk, dk_off), dk_rs, d.seq_k * dk_rs
+        d.dV, d.dv_row_stride, d.dv_batch_stride = _elem_ptr(dv, dv_off), dv_rs, d.seq_k * dv_rs
+    else:
+        d.dK = d.dV = 0
+    ws = scratch(lib.desta_attention_bwd_workspace_floats(d.batch, d.n_q_heads, d.seq_q), do.device, "attn")
+    check(_attn_bwd(C.byref(d), p(ws), stream()), "desta_attention_bwd")

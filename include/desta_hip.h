@@ -100,6 +100,109 @@ int desta_logmel_fill_tables(int n_mels, float* host_out);
 int desta_logmel_f32(const float* wave, int batch, int n_samples, int64_t wave_stride, const float* tables,
                      int n_mels, float* out, float* workspace, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Row-wise normalisation.  One wave per row, fp32 statistics, 16-byte accesses; cols % 8 == 0.
+ * LayerNorm: nn.LayerNorm at TF:models/whisper/modeling_whisper.py:392,402 (eps 1e-5),
+ *   TF:models/bert/modeling_bert.py:296,350 (eps 1e-12), modeling_desta25.py:166; x is fp32 or bf16,
+ *   outputs bf16 and/or fp32; stats [rows][2] = (mean, rstd) saved for backward.
+ * layernorm_bwd: dx (fp32 and/or bf16) and dgamma/dbeta (written, or added when accumulate != 0);
+ *   cols <= 2048; workspace from desta_layernorm_bwd_workspace_floats.
+ * RMSNorm: LlamaRMSNorm TF:models/llama/modeling_llama.py:53-67 (bf16 in/out, fp32 weight copy);
+ *   rmsnorm_bwd returns dx = dres + d(norm) (dres may be NULL), frozen weight (no dweight). */
+int desta_layernorm_fwd(const void* x, int x_f32, const float* gamma, const float* beta, float eps, int rows,
+                        int cols, void* y_bf16, float* y_f32, float* stats, void* stream);
+size_t desta_layernorm_bwd_workspace_floats(int rows, int cols);
+int desta_layernorm_bwd(const void* dy, int dy_f32, const void* x, int x_f32, const float* gamma,
+                        const float* stats, int rows, int cols, float* dx_f32, void* dx_bf16, float* dgamma,
+                        float* dbeta, int accumulate, float* workspace, void* stream);
+int desta_rmsnorm_fwd(const void* x, const float* weight, float eps, int rows, int cols, void* y, float* rstd,
+                      void* stream);
+int desta_rmsnorm_bwd(const void* dy, const void* x, const float* weight, const float* rstd, const void* dres,
+                      int rows, int cols, void* dx, void* stream);
+
+/* Column sums of a bf16 [rows, cols] matrix (bias gradients of nn.Linear), fixed-order two-stage. */
+size_t desta_colsum_workspace_floats(int rows, int cols);
+int desta_colsum_bf16(const void* x, int rows, int cols, int64_t ld, float* out, int accumulate,
+                      float* workspace, void* stream);
+
+/* Rotary embedding applied IN PLACE to the first (n_q_heads + n_kv_heads) heads of a fused
+ * [rows, ld] bf16 q|k|v buffer; position = row % seq (position_ids = arange(S) for every row,
+ * TF:models/llama/modeling_llama.py:386-389); cos_sin = fp32 [seq][2][head_dim/2].
+ * With q_norm_w/k_norm_w != NULL the Qwen3 per-head RMSNorm (TF:models/qwen3/modeling_qwen3.py:237-257)
+ * runs first (forward) / is differentiated (backward, needs the saved pre-norm q|k in pre_norm).
+ * backward != 0 applies the transposed rotation to gradients. head_dim 64 or 128. */
+int desta_rope(void* buf, int64_t ld, int rows, int seq, int n_q_heads, int n_kv_heads, int head_dim,
+               const float* cos_sin, const float* q_norm_w, const float* k_norm_w, float eps,
+               const void* pre_norm, int64_t ld_pre, int backward, void* stream);
+
+/* SwiGLU on a fused [rows, 2*inter] gate|up buffer (LlamaMLP, TF:models/llama/modeling_llama.py:163-176),
+ * GELU'(erf) for the Q-Former FFN backward, and small layout helpers. */
+int desta_swiglu_fwd(const void* gate_up, void* act, int64_t rows, int inter, void* stream);
+int desta_swiglu_bwd(const void* gate_up, const void* dact, void* dgate_up, int64_t rows, int inter, void* stream);
+int desta_gelu_bwd(const void* preact, const void* dact, void* dpre, int64_t n, void* stream);
+int desta_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream);
+int desta_add_f32(float* y, const float* x, int64_t n, void* stream);
+/* out[c][r] = in[r][c] as bf16; out row length ld_out >= rows, tail zero-filled (K padding for dW GEMMs) */
+int desta_transpose_to_bf16(const void* in, int in_f32, int64_t ld_in, int rows, int cols, void* out,
+                            int64_t ld_out, void* stream);
+/* mel [B, n_mels, T] fp32 -> channel-last rows [B, T+2, c_pad] bf16 (rows 0 and T+1 stay as the caller
+ * zeroed them): the A operand of the zero-copy im2col conv1 GEMM (modeling_desta25.py:563). */
+int desta_mel_to_rows(const float* mel, int batch, int n_mels, int frames, int c_pad, void* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Embedding gather + audio splice: out[r] = src_row[r] >= 0 ? table[src_row[r]]
+ *                                                           : audio_rows[-(src_row[r]+1)]
+ * `src_row` (int32 [rows], built by the caller from input_ids / start positions / transcription
+ * ids) restates `embed_tokens(input_ids)` + the slice assignment of cat(audio_features,
+ * transcription_embeddings) at modeling_desta25.py:1009-1041.  gather_rows is its backward
+ * (rows of dL/d inputs_embeds at the audio positions -> dL/d audio_features). */
+int desta_embed_gather(const void* table, const void* audio_rows, const int32_t* src_row, int rows, int hidden,
+                       void* out, void* stream);
+int desta_gather_rows_bf16(const void* in, const int32_t* idx, int rows, int hidden, void* out, void* stream);
+
+/* ForCausalLMLoss (TF:loss/loss_utils.py:49-71): labels int64 [batch, seq] UNSHIFTED (the shift by one
+ * and the -100 padding of the last position happen inside), logits bf16 [batch*seq, ld] upcast to fp32;
+ * loss[0] = mean CE over targets != -100.  With write_grad != 0 the logits buffer is overwritten by
+ * dloss/dlogits (bf16).  workspace: desta_ce_workspace_floats(batch, seq). */
+size_t desta_ce_workspace_floats(int batch, int seq);
+int desta_causal_lm_loss(void* logits, int64_t ld, const int64_t* labels, int batch, int seq, int vocab,
+                         float* loss, float* workspace, int write_grad, void* stream);
+
+/* Connector tap mix (modeling_desta25.py:600-604): x fp32 [taps][batch*prompt][d], layer_weights
+ * fp32 [prompt][taps]; out[b,k,:] = sum_j softmax(layer_weights[k,:])_j x[j,b,k,:]; and its backward. */
+int desta_tap_mix_fwd(const float* x, const float* layer_weights, int taps, int batch, int prompt, int d,
+                      float* out, void* stream);
+int desta_tap_mix_bwd(const float* x, const float* layer_weights, const float* dout, int taps, int batch,
+                      int prompt, int d, float* dx, float* dlayer_weights, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Flash-style attention, forward and backward (bf16 operands, fp32 softmax, MFMA 32x32x16).
+ * Element (b, s, h, d) of a tensor X lives at X + b*x_batch_stride + s*x_row_stride + h*head_dim + d,
+ * so q/k/v may be slices of one fused projection buffer.  GQA: kv head = q head / (n_q/n_kv).
+ * Mask: key j is visible to query i iff j < seq_k, j >= kv_start[b] (left padding; NULL = 0) and,
+ * when causal, j <= i + (seq_k - seq_q).  softmax(scale * q.k).  Rows with no visible key give 0.
+ * lse (fp32 [batch][n_q_heads][seq_q], log2 domain) is written by fwd and read by bwd.
+ * Replaces: Whisper self-attention TF:models/whisper/modeling_whisper.py:241-357 (q pre-scaled by
+ * hd^-0.5 == scale), BERT eager self/cross attention TF:models/bert/modeling_bert.py:100-293,
+ * Llama/Qwen3 attention TF:models/llama/modeling_llama.py:179-281 with the mask of
+ * `create_causal_mask` (:391), and their autograd backward.  bwd: dK/dV may both be NULL
+ * (Whisper states carry no gradient, modeling_desta25.py:594). */
+typedef struct desta_attn_desc {
+    const void* Q; const void* K; const void* V; void* O;
+    const void* dO; void* dQ; void* dK; void* dV;
+    float* lse;
+    int64_t q_batch_stride, q_row_stride, k_batch_stride, k_row_stride, v_batch_stride, v_row_stride;
+    int64_t o_batch_stride, o_row_stride, do_batch_stride, do_row_stride;
+    int64_t dq_batch_stride, dq_row_stride, dk_batch_stride, dk_row_stride, dv_batch_stride, dv_row_stride;
+    int batch, n_q_heads, n_kv_heads, seq_q, seq_k, head_dim;
+    int causal;
+    const int32_t* kv_start;
+    float scale;
+} desta_attn_desc;
+int desta_attention_fwd(const desta_attn_desc* d, void* stream);
+size_t desta_attention_bwd_workspace_floats(int batch, int n_q_heads, int seq_q);
+int desta_attention_bwd(const desta_attn_desc* d, float* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

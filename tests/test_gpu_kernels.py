@@ -129,7 +129,11 @@ def _run_adafactor_case(hip, shapes, steps, gscale):
         go = [x.clone() for x in grads]
         n_o = O.clip_grad_norm(go, 1.0)
         O.adafactor_step(p_o, go, st, lr, wd)
-        assert abs(float(opt.grad_norm()) - float(n_o)) <= 2e-6 * max(1.0, float(n_o))
+        # fp32 CPU norms of multi-million-element tensors carry ~1e-4 relative summation error themselves:
+        # pin the kernel's norm against a float64 norm (tight) and the fp32 oracle norm (loose)
+        n64 = math.sqrt(sum(float((x.double() ** 2).sum()) for x in grads))
+        assert abs(float(opt.grad_norm()) - n64) <= 2e-6 * max(1.0, n64)
+        assert abs(float(opt.grad_norm()) - float(n_o)) <= 5e-4 * max(1.0, float(n_o))
         for n, ref in zip(names, p_o):
             torch.testing.assert_close(arena.param(n).cpu(), ref, rtol=2e-6, atol=2e-7)
     return arena, opt

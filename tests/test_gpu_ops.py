@@ -1,0 +1,354 @@
+"""GPU parity: norms, RoPE (+q/k norm), SwiGLU/GELU', layout helpers, embed/splice, CE, tap mix and
+flash attention forward/backward — each against plain torch fp32 (autograd for backward)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import desta_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    assert torch.cuda.is_available()
+    from desta import _hip
+    return _hip
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def rel_err(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+@pytest.mark.parametrize("rows,cols,f32in", [(37, 1280, True), (64, 384, False), (5, 128, True), (12, 2048, False)])
+def test_layernorm_fwd_bwd(hip, rows, cols, f32in):
+    g = torch.Generator().manual_seed(rows + cols)
+    x = torch.randn(rows, cols, generator=g) * 2 + 0.5
+    if not f32in:
+        x = bf(x).float()
+    gam, bet = 1 + 0.1 * torch.randn(cols, generator=g), 0.1 * torch.randn(cols, generator=g)
+    dy = torch.randn(rows, cols, generator=g)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    y = F.layer_norm(xr, (cols,), gr, br, 1e-5)
+    y.backward(dy)
+    xd = (x if f32in else bf(x)).cuda()
+    y16 = torch.empty(rows, cols, dtype=torch.bfloat16, device="cuda")
+    y32 = torch.empty(rows, cols, dtype=torch.float32, device="cuda")
+    st = torch.empty(rows, 2, device="cuda")
+    hip.layernorm_fwd(xd, gam.cuda(), bet.cuda(), 1e-5, y16=y16, y32=y32, stats=st)
+    torch.testing.assert_close(y32.cpu(), y.detach(), rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(y16.float().cpu(), y.detach(), rtol=1e-2, atol=1e-2)
+    dx32 = torch.empty_like(y32)
+    dx16 = torch.empty_like(y16)
+    dg = torch.full((cols,), 7.0, device="cuda")
+    db = torch.full((cols,), 7.0, device="cuda")
+    hip.layernorm_bwd(dy.cuda(), xd, gam.cuda(), st, dx32=dx32, dx16=dx16, dgamma=dg, dbeta=db)
+    torch.testing.assert_close(dx32.cpu(), xr.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dg.cpu(), gr.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(db.cpu(), br.grad, rtol=1e-4, atol=1e-4)
+    hip.layernorm_bwd(dy.cuda(), xd, gam.cuda(), st, dx32=dx32, dgamma=dg, dbeta=db, accumulate=True)
+    torch.testing.assert_close(dg.cpu(), 2 * gr.grad, rtol=1e-4, atol=2e-4)
+    assert rel_err(dx16.float().cpu(), xr.grad) < 1e-2
+
+
+@pytest.mark.parametrize("rows,cols", [(33, 4096), (7, 256), (16, 5120)])
+def test_rmsnorm_fwd_bwd(hip, rows, cols):
+    g = torch.Generator().manual_seed(cols)
+    x = bf(torch.randn(rows, cols, generator=g) * 1.5)
+    w = 1 + 0.1 * torch.randn(cols, generator=g)
+    dy = bf(torch.randn(rows, cols, generator=g))
+    dres = bf(torch.randn(rows, cols, generator=g))
+    xr = x.float().requires_grad_(True)
+    var = xr.pow(2).mean(-1, keepdim=True)
+    y = w * (xr * torch.rsqrt(var + 1e-5))
+    y.backward(dy.float())
+    yd = torch.empty(rows, cols, dtype=torch.bfloat16, device="cuda")
+    rstd = torch.empty(rows, device="cuda")
+    hip.rmsnorm_fwd(x.cuda(), w.cuda(), 1e-5, yd, rstd)
+    assert rel_err(yd.float().cpu(), y.detach()) < 6e-3
+    dx = torch.empty_like(yd)
+    hip.rmsnorm_bwd(dy.cuda(), x.cuda(), w.cuda(), rstd, dx, dres=dres.cuda())
+    assert rel_err(dx.float().cpu(), xr.grad + dres.float()) < 6e-3
+
+
+def test_colsum_transpose_cast_add(hip):
+    g = torch.Generator().manual_seed(2)
+    x = bf(torch.randn(1000, 136, generator=g))
+    out = torch.zeros(136, device="cuda")
+    hip.colsum(x.cuda(), 1000, 136, 136, out)
+    torch.testing.assert_close(out.cpu(), x.float().sum(0), rtol=1e-4, atol=1e-3)
+    hip.colsum(x.cuda(), 1000, 136, 136, out, accumulate=True)
+    torch.testing.assert_close(out.cpu(), 2 * x.float().sum(0), rtol=1e-4, atol=2e-3)
+    # transpose with zero-padded K tail, bf16 and fp32 inputs
+    t = torch.full((136, 1024), 9.0, dtype=torch.bfloat16, device="cuda")
+    hip.transpose_to_bf16(x.cuda(), 1000, 136, t, 1024)
+    assert torch.equal(t[:, :1000].cpu(), x.T.contiguous())
+    assert float(t[:, 1000:].abs().max()) == 0.0
+    xf = torch.randn(70, 200, generator=g)
+    t2 = torch.empty(200, 128, dtype=torch.bfloat16, device="cuda")
+    hip.transpose_to_bf16(xf.cuda(), 70, 200, t2, 128)
+    assert torch.equal(t2[:, :70].cpu(), bf(xf).T.contiguous())
+    y = torch.empty(70 * 200, dtype=torch.bfloat16, device="cuda")
+    hip.cast_bf16(xf.cuda().reshape(-1), y)
+    assert torch.equal(y.cpu(), bf(xf).reshape(-1))
+    a, b = torch.randn(4096, generator=g), torch.randn(4096, generator=g)
+    ad = a.cuda()
+    hip.add_f32(ad, b.cuda())
+    torch.testing.assert_close(ad.cpu(), a + b)
+
+
+def test_mel_to_rows(hip):
+    g = torch.Generator().manual_seed(3)
+    mel = torch.randn(2, 80, 200, generator=g)
+    out = torch.zeros(2, 202, 128, dtype=torch.bfloat16, device="cuda")
+    hip.mel_to_rows(mel.cuda(), 128, out)
+    ref = torch.zeros(2, 202, 128)
+    ref[:, 1:201, :80] = mel.permute(0, 2, 1)
+    assert torch.equal(out.cpu(), bf(ref))
+
+
+@pytest.mark.parametrize("hd,qknorm", [(128, False), (64, False), (128, True), (64, True)])
+def test_rope_fwd_bwd(hip, hd, qknorm):
+    g = torch.Generator().manual_seed(hd)
+    B, S, hq, hkv = 2, 9, 4, 2
+    d = O.tiny_dims(qknorm)
+    d.llm_hd = hd
+    inv = O.rope_inv_freq(d)
+    fr = torch.outer(torch.arange(S).float(), inv)
+    cs = torch.stack([fr.cos(), fr.sin()], dim=1).contiguous()          # [S, 2, hd/2]
+    ld = (hq + 2 * hkv) * hd
+    buf = bf(torch.randn(B * S, ld, generator=g))
+    wq, wk = 1 + 0.2 * torch.randn(hd, generator=g), 1 + 0.2 * torch.randn(hd, generator=g)
+
+    def ref(xb):
+        x = xb.view(B, S, hq + 2 * hkv, hd)
+        qk = x[:, :, :hq + hkv]
+        if qknorm:
+            wcat = torch.cat([wq[None].expand(hq, -1), wk[None].expand(hkv, -1)])[None, None]
+            qk = wcat * (qk * torch.rsqrt(qk.pow(2).mean(-1, keepdim=True) + 1e-6))
+        cos = torch.cat([fr, fr], -1).cos()[None, :, None]
+        sin = torch.cat([fr, fr], -1).sin()[None, :, None]
+        qk = qk * cos + O._rot_half(qk) * sin
+        return torch.cat([qk, x[:, :, hq + hkv:]], dim=2).reshape(B * S, ld)
+
+    xr = buf.float().requires_grad_(True)
+    y = ref(xr)
+    dy = bf(torch.randn(B * S, ld, generator=g))
+    y.backward(dy.float())
+    out = buf.clone().cuda()
+    hip.rope(out, ld, B * S, S, hq, hkv, hd, cs.cuda(), wq.cuda() if qknorm else None, wk.cuda() if qknorm else None, 1e-6)
+    assert rel_err(out.float().cpu(), y.detach()) < 8e-3
+    assert torch.equal(out[:, (hq + hkv) * hd:].cpu(), buf[:, (hq + hkv) * hd:])      # v untouched
+    dbuf = dy.clone().cuda()
+    hip.rope(dbuf, ld, B * S, S, hq, hkv, hd, cs.cuda(), wq.cuda() if qknorm else None, wk.cuda() if qknorm else None,
+             1e-6, pre_norm=buf.cuda() if qknorm else None, ld_pre=ld, backward=True)
+    assert rel_err(dbuf.float().cpu(), xr.grad) < 8e-3
+
+
+def test_swiglu_gelu(hip):
+    g = torch.Generator().manual_seed(4)
+    rows, I = 19, 512
+    gu = bf(torch.randn(rows, 2 * I, generator=g) * 2)
+    dact = bf(torch.randn(rows, I, generator=g))
+    gr = gu.float().requires_grad_(True)
+    act = F.silu(gr[:, :I]) * gr[:, I:]
+    act.backward(dact.float())
+    a = torch.empty(rows, I, dtype=torch.bfloat16, device="cuda")
+    hip.swiglu_fwd(gu.cuda(), a, rows, I)
+    assert rel_err(a.float().cpu(), act.detach()) < 6e-3
+    dgu = torch.empty(rows, 2 * I, dtype=torch.bfloat16, device="cuda")
+    hip.swiglu_bwd(gu.cuda(), dact.cuda(), dgu, rows, I)
+    assert rel_err(dgu.float().cpu(), gr.grad) < 6e-3
+    pre = bf(torch.randn(rows, I, generator=g) * 2)
+    pr = pre.float().requires_grad_(True)
+    F.gelu(pr).backward(dact.float())
+    dpre = torch.empty(rows, I, dtype=torch.bfloat16, device="cuda")
+    hip.gelu_bwd(pre.cuda(), dact.cuda(), dpre, rows * I)
+    assert rel_err(dpre.float().cpu(), pr.grad) < 6e-3
+
+
+def test_embed_gather_and_rows(hip):
+    g = torch.Generator().manual_seed(5)
+    V, h = 50, 256
+    table = bf(torch.randn(V, h, generator=g))
+    audio = bf(torch.randn(6, h, generator=g))
+    src = torch.tensor([3, 49, -1, -2, -6, 0, 7], dtype=torch.int32)
+    out = torch.empty(7, h, dtype=torch.bfloat16, device="cuda")
+    hip.embed_gather(table.cuda(), audio.cuda(), src.cuda(), 7, h, out)
+    ref = torch.stack([table[3], table[49], audio[0], audio[1], audio[5], table[0], table[7]])
+    assert torch.equal(out.cpu(), ref)
+    idx = torch.tensor([6, 0, 2], dtype=torch.int32)
+    o2 = torch.empty(3, h, dtype=torch.bfloat16, device="cuda")
+    hip.gather_rows(out, idx.cuda(), 3, h, o2)
+    assert torch.equal(o2.cpu(), ref[[6, 0, 2]])
+
+
+@pytest.mark.parametrize("V", [512, 1000, 128256])
+def test_causal_lm_loss(hip, V):
+    g = torch.Generator().manual_seed(V)
+    B, S = 2, 7
+    logits = bf(torch.randn(B * S, V, generator=g) * 3)
+    labels = torch.randint(0, V, (B, S), generator=g)
+    labels[0, :3] = -100
+    labels[1, 5] = -100
+    lr = logits.float().view(B, S, V).requires_grad_(True)
+    loss = O.causal_lm_loss(lr, labels)
+    loss.backward()
+    ld = (V + 7) // 8 * 8
+    buf = torch.zeros(B * S, ld, dtype=torch.bfloat16, device="cuda")
+    buf[:, :V] = logits.cuda()
+    out = torch.zeros(1, device="cuda")
+    hip.causal_lm_loss(buf, ld, labels.cuda(), B, S, V, out, write_grad=True)
+    assert abs(float(out) - float(loss)) < 2e-5 * max(1.0, float(loss))
+    got = buf[:, :V].float().cpu().view(B, S, V)
+    assert rel_err(got, lr.grad) < 5e-3
+    assert float(got[0, :2].abs().max()) == 0.0 and float(got[:, -1].abs().max()) == 0.0   # ignored rows
+    # all labels ignored -> loss 0 (n_valid = 0 guarded), grads 0
+    lab2 = torch.full((B, S), -100)
+    buf[:, :V] = logits.cuda()
+    hip.causal_lm_loss(buf, ld, lab2.cuda(), B, S, V, out, write_grad=True)
+    assert float(out) == 0.0 and float(buf.float().abs().max()) == 0.0
+
+
+def test_tap_mix(hip):
+    g = torch.Generator().manual_seed(6)
+    taps, B, K, d = 4, 3, 64, 128
+    x = torch.randn(taps, B * K, d, generator=g)
+    lw = torch.randn(K, taps, generator=g)
+    dout = torch.randn(B * K, d, generator=g)
+    xr, lr = x.clone().requires_grad_(True), lw.clone().requires_grad_(True)
+    xx = xr.view(taps, B, K, d).permute(1, 2, 0, 3)
+    y = (xx * torch.softmax(lr, -1).unsqueeze(-1)).sum(2).reshape(B * K, d)
+    y.backward(dout)
+    out = torch.empty(B * K, d, device="cuda")
+    hip.tap_mix_fwd(x.cuda(), lw.cuda(), taps, B, K, d, out)
+    torch.testing.assert_close(out.cpu(), y.detach(), rtol=1e-5, atol=1e-5)
+    dx = torch.empty(taps, B * K, d, device="cuda")
+    dlw = torch.empty(K, taps, device="cuda")
+    hip.tap_mix_bwd(x.cuda(), lw.cuda(), dout.cuda(), taps, B, K, d, dx, dlw)
+    torch.testing.assert_close(dx.cpu(), xr.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dlw.cpu(), lr.grad, rtol=1e-4, atol=1e-4)
+
+
+def _attn_ref(q, k, v, scale, causal, kv_start):
+    """q [B,Sq,Hq,D], k/v [B,Sk,Hkv,D] fp32 -> out [B,Sq,Hq,D]; fully masked rows -> 0."""
+    B, Sq, Hq, D = q.shape
+    Sk, Hkv = k.shape[1], k.shape[2]
+    rep = Hq // Hkv
+    kk = k.repeat_interleave(rep, dim=2).permute(0, 2, 1, 3)
+    vv = v.repeat_interleave(rep, dim=2).permute(0, 2, 1, 3)
+    s = (q.permute(0, 2, 1, 3) @ kk.transpose(-1, -2)) * scale
+    ok = torch.ones(B, 1, Sq, Sk, dtype=torch.bool)
+    if causal:
+        ok = ok & (torch.arange(Sk)[None, :] <= torch.arange(Sq)[:, None] + (Sk - Sq))[None, None]
+    if kv_start is not None:
+        ok = ok & (torch.arange(Sk)[None, None, None, :] >= kv_start[:, None, None, None])
+    s = s.masked_fill(~ok, float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    p = torch.nan_to_num(p, nan=0.0)
+    return (p @ vv).permute(0, 2, 1, 3)
+
+
+ATTN_CASES = [
+    # B, Hq, Hkv, Sq, Sk, D, causal, pad
+    (2, 4, 4, 64, 64, 64, False, None),          # Q-Former self-attention
+    (2, 2, 2, 64, 200, 64, False, None),         # Q-Former cross-attention (ragged Sk)
+    (1, 3, 3, 333, 333, 64, False, None),        # Whisper-like, ragged
+    (2, 4, 2, 160, 160, 128, True, [0, 37]),     # Llama GQA causal + left padding
+    (2, 4, 1, 70, 70, 64, True, [5, 0]),         # tiny-LLM head dim 64
+    (1, 8, 2, 300, 300, 128, True, None),
+]
+
+
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_attention_fwd_bwd(hip, case):
+    B, Hq, Hkv, Sq, Sk, D, causal, pad = case
+    g = torch.Generator().manual_seed(Sq * 3 + Sk + D)
+    # fused projection buffers: q | k | v in one row (self-attention) or separate q / kv buffers
+    fused = Sq == Sk
+    wq, wkv = Hq * D, Hkv * D
+    if fused:
+        qkv = bf(torch.randn(B * Sq, wq + 2 * wkv, generator=g))
+        qb, kb_, vb = qkv, qkv, qkv
+        q_off, k_off, v_off = 0, wq, wq + wkv
+    else:
+        qb = bf(torch.randn(B * Sq, wq, generator=g))
+        kvb = bf(torch.randn(B * Sk, 2 * wkv, generator=g))
+        kb_, vb = kvb, kvb
+        q_off, k_off, v_off = 0, 0, wkv
+    q = qb[:, q_off:q_off + wq].float().reshape(B, Sq, Hq, D).clone().requires_grad_(True)
+    k = kb_[:, k_off:k_off + wkv].float().reshape(B, Sk, Hkv, D).clone().requires_grad_(True)
+    v = vb[:, v_off:v_off + wkv].float().reshape(B, Sk, Hkv, D).clone().requires_grad_(True)
+    scale = D ** -0.5
+    kvs = torch.tensor(pad, dtype=torch.int32) if pad is not None else None
+    ref = _attn_ref(q, k, v, scale, causal, kvs)
+    do = bf(torch.randn(B * Sq, wq, generator=g))
+    ref.backward(do.float().view(B, Sq, Hq, D))
+
+    qd, kd, vd = qb.cuda(), (qb.cuda() if fused else kvb.cuda()), None
+    if fused:
+        kd = vd = qd
+    else:
+        vd = kd
+    o = torch.zeros(B * Sq, wq, dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros(B, Hq, Sq, device="cuda")
+    d = hip.attn_desc(qd, kd, vd, o, lse, batch=B, hq=Hq, hkv=Hkv, sq=Sq, sk=Sk, hd=D, scale=scale, causal=causal,
+                      kv_start=kvs.cuda() if kvs is not None else None, q_off=q_off, k_off=k_off, v_off=v_off)
+    hip.attention_fwd(d)
+    got = o.float().cpu().view(B, Sq, Hq, D)
+    assert rel_err(got, ref.detach()) < 8e-3, rel_err(got, ref.detach())
+    if pad is not None:
+        for b, pl in enumerate(pad):
+            assert float(got[b, :pl].abs().max()) == 0.0 if pl else True
+
+    if fused:
+        dqkv = torch.zeros(B * Sq, wq + 2 * wkv, dtype=torch.bfloat16, device="cuda")
+        hip.attention_bwd(d, do.cuda(), dqkv, dqkv, dqkv, dq_off=0, dk_off=wq, dv_off=wq + wkv)
+        gq, gk, gv = dqkv[:, :wq], dqkv[:, wq:wq + wkv], dqkv[:, wq + wkv:]
+    else:
+        dq = torch.zeros(B * Sq, wq, dtype=torch.bfloat16, device="cuda")
+        dkv = torch.zeros(B * Sk, 2 * wkv, dtype=torch.bfloat16, device="cuda")
+        hip.attention_bwd(d, do.cuda(), dq, dkv, dkv, dk_off=0, dv_off=wkv)
+        gq, gk, gv = dq, dkv[:, :wkv], dkv[:, wkv:]
+    assert rel_err(gq.float().cpu().view(B, Sq, Hq, D), q.grad) < 1.5e-2
+    assert rel_err(gk.float().cpu().view(B, Sk, Hkv, D), k.grad) < 1.5e-2
+    assert rel_err(gv.float().cpu().view(B, Sk, Hkv, D), v.grad) < 1.5e-2
+    # dQ-only variant (Whisper states carry no gradient)
+    dq2 = torch.zeros(B * Sq, wq, dtype=torch.bfloat16, device="cuda")
+    hip.attention_bwd(d, do.cuda(), dq2)
+    assert torch.equal(dq2.cpu(), gq.cpu().contiguous())
+
+
+def test_attention_forced_rescale(hip):
+    """Spike one key late in the sequence so the running max jumps at a chosen tile (online-softmax
+    rescale branch), plus an exact-integer check of the P·V operand order (V = one-hot rows)."""
+    B, H, S, D = 1, 1, 256, 64
+    g = torch.Generator().manual_seed(0)
+    q = bf(torch.randn(B * S, D, generator=g))
+    k = bf(torch.randn(B * S, D, generator=g))
+    k[200] = (q[5].float() * 6).to(torch.bfloat16)          # huge score for query 5 at key 200 (4th tile)
+    v = bf(torch.randn(B * S, D, generator=g))
+    ref = _attn_ref(q.float().view(1, S, 1, D), k.float().view(1, S, 1, D), v.float().view(1, S, 1, D), D ** -0.5, False, None)
+    o = torch.zeros(S, D, dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros(1, 1, S, device="cuda")
+    d = hip.attn_desc(q.cuda(), k.cuda(), v.cuda(), o, lse, batch=1, hq=1, hkv=1, sq=S, sk=S, hd=D, scale=D ** -0.5)
+    hip.attention_fwd(d)
+    assert rel_err(o.float().cpu().view(1, S, 1, D), ref) < 8e-3
+    # uniform attention (q = 0) over asymmetric integer V: out = column means, exact in bf16-friendly ints
+    S2 = 64
+    v2 = torch.zeros(S2, D)
+    v2[torch.arange(S2), torch.arange(S2) % D] = 64.0
+    v2[:, 0] += torch.arange(S2).float()
+    q0 = torch.zeros(S2, D, dtype=torch.bfloat16)
+    o2 = torch.zeros(S2, D, dtype=torch.bfloat16, device="cuda")
+    lse2 = torch.zeros(1, 1, S2, device="cuda")
+    d2 = hip.attn_desc(q0.cuda(), q0.cuda(), bf(v2).cuda(), o2, lse2, batch=1, hq=1, hkv=1, sq=S2, sk=S2, hd=D, scale=1.0)
+    hip.attention_fwd(d2)
+    torch.testing.assert_close(o2.float().cpu(), v2.mean(0, keepdim=True).expand(S2, D), rtol=1e-2, atol=1e-2)
