@@ -156,7 +156,55 @@ __global__ __launch_bounds__(256) void mix_bwd_k(const float* __restrict__ x, co
         for (int j = 0; j < taps; ++j) dlw[k * taps + j] = sm[j] * (ds[j] - dot);
 }
 
+// x32/x16[(j*B + b)][:] = prompts[j][:]   (rows of n = K*d floats; layer_prompts[j].expand(B,-1,-1))
+__global__ __launch_bounds__(256) void prompt_expand_k(const float* __restrict__ prompts, int taps, int Bn, long n,
+                                                       float* __restrict__ x32, bf16_t* __restrict__ x16) {
+    const long n4 = n / 4, total = (long)taps * Bn * n4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long jb = i / n4, c = (i % n4) * 4;
+        const int j = (int)(jb / Bn);
+        const float4 v = *(const float4*)(prompts + (long)j * n + c);
+        *(float4*)(x32 + jb * n + c) = v;
+        u16x4 o;
+        o[0] = f2bf(v.x); o[1] = f2bf(v.y); o[2] = f2bf(v.z); o[3] = f2bf(v.w);
+        *(u16x4*)(x16 + jb * n + c) = o;
+    }
+}
+// dprompts[j][:] = sum_b dx[(j*B + b)][:]   (fixed order)
+__global__ __launch_bounds__(256) void prompt_grad_k(const float* __restrict__ dx, int taps, int Bn, long n,
+                                                     float* __restrict__ dprompts) {
+    const long n4 = n / 4, total = (long)taps * n4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int j = (int)(i / n4);
+        const long c = (i % n4) * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int b = 0; b < Bn; ++b) {
+            const float4 v = *(const float4*)(dx + ((long)j * Bn + b) * n + c);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        *(float4*)(dprompts + (long)j * n + c) = acc;
+    }
+}
+
 }  // namespace
+
+extern "C" int desta_prompt_expand(const float* prompts, int taps, int batch, int64_t n, float* x_f32, void* x_bf16, void* stream) {
+    DESTA_CHECK_ARG(prompts && x_f32 && x_bf16 && taps > 0 && batch > 0 && n > 0 && n % 4 == 0, "prompt_expand: bad argument");
+    long blocks = ((long)taps * batch * (n / 4) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(prompt_expand_k, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, prompts, taps, batch, (long)n, x_f32, (bf16_t*)x_bf16);
+    DESTA_CHECK_LAUNCH("prompt_expand");
+    return DESTA_OK;
+}
+
+extern "C" int desta_prompt_grad(const float* dx, int taps, int batch, int64_t n, float* dprompts, void* stream) {
+    DESTA_CHECK_ARG(dx && dprompts && taps > 0 && batch > 0 && n > 0 && n % 4 == 0, "prompt_grad: bad argument");
+    long blocks = ((long)taps * (n / 4) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(prompt_grad_k, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dx, taps, batch, (long)n, dprompts);
+    DESTA_CHECK_LAUNCH("prompt_grad");
+    return DESTA_OK;
+}
 
 extern "C" int desta_embed_gather(const void* table, const void* audio_rows, const int32_t* src_row, int rows, int hidden,
                                   void* out, void* stream) {

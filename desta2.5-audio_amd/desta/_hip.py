@@ -333,3 +333,15 @@ def attention_bwd(d: AttnDesc, do, dq, dk=None, dv=None, *, do_rs=None, dq_off=0
         d.dK = d.dV = 0
     ws = scratch(lib.desta_attention_bwd_workspace_floats(d.batch, d.n_q_heads, d.seq_q), do.device, "attn")
     check(_attn_bwd(C.byref(d), p(ws), stream()), "desta_attention_bwd")
+
+
+_prompt_expand = _sig("desta_prompt_expand", vp, i32, i32, i64, vp, vp, vp)
+_prompt_grad = _sig("desta_prompt_grad", vp, i32, i32, i64, vp, vp)
+
+
+def prompt_expand(prompts, taps, batch, n, x32, x16):
+    check(_prompt_expand(p(prompts), taps, batch, n, p(x32), p(x16), stream()), "desta_prompt_expand")
+
+
+def prompt_grad(dx, taps, batch, n, dprompts):
+    check(_prompt_grad(p(dx), taps, batch, n, p(dprompts), stream()), "desta_prompt_grad")

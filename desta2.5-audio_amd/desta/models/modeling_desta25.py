@@ -1,0 +1,841 @@
+"""MI355X-native DeSTA2.5-Audio model: host side of the hot path.
+
+Mirrors the reference's model surface (desta/models/modeling_desta25.py): `DeSTA25Config` (:633-694),
+`DeSTA25AudioModel.forward / state_dict / load_state_dict / from_pretrained` (:698-1050, :1284-1354,
+:1723-1747), `WhisperPerception.forward_whisper` (:544-608) and `QformerConnector` (:126-205) — same
+names, argument meaning, error behaviour and checkpoint keys — but every FLOP runs in hand-written HIP
+kernels behind the C ABI (`desta._hip`).  There is no autograd graph and no tracing compiler: forward
+saves the activations the hand-written backward needs into pre-allocated HBM buffers, `backward()`
+walks the layers in reverse calling the backward kernels, gradients land in the flat fp32 arena that
+the fused Adafactor and the RCCL all-reduce consume.
+
+Precision policy (== HF autocast(bf16) of the reference, hazard H11): GEMM operands bf16 with fp32
+accumulation; LayerNorm / RMSNorm / softmax / loss statistics fp32; Whisper and LLM residual streams
+bf16; Q-Former residual stream and all trainable parameters / gradients / optimizer state fp32.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from collections import OrderedDict
+from dataclasses import dataclass, field, asdict
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from .. import _hip as H
+from ..optim import ParamArena
+
+BF16, F32 = torch.bfloat16, torch.float32
+ENC = "perception.whisper.model.encoder."
+CON = "perception.connector."
+LLM = "llm_model."
+
+TAP_LAYERS = {  # modeling_desta25.py:134-145 (keyed on the hub name; we key on the name suffix / depth)
+    "whisper-tiny": [0, 1, 2, 3], "whisper-small": [2, 5, 8, 11], "whisper-medium": [5, 11, 17, 23],
+    "whisper-large-v3": [7, 15, 23, 31], "whisper-large-v3-turbo": [7, 15, 23, 31],
+}
+_TAPS_BY_DEPTH = {4: [0, 1, 2, 3], 12: [2, 5, 8, 11], 24: [5, 11, 17, 23], 32: [7, 15, 23, 31]}
+
+
+def _r64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+@dataclass
+class EncoderConfig:
+    num_mel_bins: int = 128
+    d_model: int = 1280
+    encoder_layers: int = 32
+    encoder_attention_heads: int = 20
+    encoder_ffn_dim: int = 5120
+    max_source_positions: int = 1500
+
+
+@dataclass
+class LLMConfig:
+    model_type: str = "llama"
+    hidden_size: int = 4096
+    num_hidden_layers: int = 32
+    num_attention_heads: int = 32
+    num_key_value_heads: int = 8
+    head_dim: int = 128
+    intermediate_size: int = 14336
+    vocab_size: int = 128256
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 500000.0
+    rope_scaling: Optional[dict] = None          # {"rope_type":"llama3","factor":8,"low_freq_factor":1,...} or None
+    tie_word_embeddings: bool = False
+
+    @property
+    def qk_norm(self) -> bool:
+        return self.model_type == "qwen3"
+
+
+def _read_hf_config(path_or_id: str) -> dict:
+    cfg = os.path.join(path_or_id, "config.json")
+    if not os.path.isfile(cfg):
+        raise FileNotFoundError(
+            f"'{path_or_id}' is not a local model directory with a config.json (no hub access here); "
+            "pass a local path or explicit llm_config / encoder_config")
+    with open(cfg) as f:
+        return json.load(f)
+
+
+class DeSTA25Config:
+    """Same fields as the reference's `DeSTA25Config` (modeling_desta25.py:636-694).  `llm_model_id` /
+    `encoder_model_id` are local HF model directories (or names, when `llm_config` / `encoder_config`
+    are given explicitly — offline there is no hub to resolve names against)."""
+    model_type = "desta25"
+
+    def __init__(self, llm_model_id="DeSTA-ntu/Llama-3.1-8B-Instruct", encoder_model_id="openai/whisper-large-v3",
+                 connector_mode="qformer_1", qformer_num_hidden_layers=2, prompt_size=64, use_lora=False,
+                 audio_locator="<|AUDIO|>", placeholder_token="<|reserved_special_token_87|>",
+                 llm_config: Optional[dict] = None, encoder_config: Optional[dict] = None,
+                 qformer_intermediate_size: int = 3072, target_layer_ids: Optional[List[int]] = None,
+                 orca_enabled=False, **kwargs):
+        if connector_mode != "qformer_1" or orca_enabled:
+            raise NotImplementedError(
+                f"connector_mode '{connector_mode}' not implemented. Supported modes: 'qformer_1' "
+                "(ORCA hybrid is out of scope of the MI355X hot path, SURVEY.md §8f)")
+        if use_lora:
+            raise NotImplementedError("use_lora=True is not on the MI355X hot path (no shipped config enables it)")
+        self.llm_model_id, self.encoder_model_id = llm_model_id, encoder_model_id
+        self.connector_mode, self.qformer_num_hidden_layers, self.prompt_size = connector_mode, qformer_num_hidden_layers, prompt_size
+        self.use_lora, self.audio_locator, self.placeholder_token = use_lora, audio_locator, placeholder_token
+        self.orca_enabled = False
+        self.qformer_intermediate_size = qformer_intermediate_size   # BertConfig() default (never overridden, :156-162)
+        lc = dict(llm_config) if llm_config is not None else _read_hf_config(llm_model_id)
+        ec = dict(encoder_config) if encoder_config is not None else _read_hf_config(encoder_model_id)
+        self.llm_config = self._llm_from_dict(lc)
+        self.encoder_config = EncoderConfig(**{k: ec[k] for k in asdict(EncoderConfig()) if k in ec})
+        if target_layer_ids is not None:
+            self.target_layer_ids = list(target_layer_ids)
+        else:
+            key = os.path.basename(os.path.normpath(encoder_model_id))
+            if key in TAP_LAYERS:
+                self.target_layer_ids = list(TAP_LAYERS[key])
+            elif self.encoder_config.encoder_layers in _TAPS_BY_DEPTH:
+                self.target_layer_ids = list(_TAPS_BY_DEPTH[self.encoder_config.encoder_layers])
+            else:
+                raise NotImplementedError(f"model_id {encoder_model_id} not implemented")
+        self.info = "Ｄｅｓｔａ２。５ Ａｕｄｉｏ"
+        self.extra = dict(kwargs)
+
+    @staticmethod
+    def _llm_from_dict(c: dict) -> LLMConfig:
+        heads = c.get("num_attention_heads", 32)
+        rp = c.get("rope_parameters") or {}
+        scaling = c.get("rope_scaling") or ({k: v for k, v in rp.items() if k != "rope_theta"} if rp.get("rope_type", "default") != "default" else None)
+        if scaling is not None and scaling.get("rope_type", scaling.get("type", "default")) in ("default", None):
+            scaling = None
+        return LLMConfig(
+            model_type=c.get("model_type", "llama"), hidden_size=c["hidden_size"], num_hidden_layers=c["num_hidden_layers"],
+            num_attention_heads=heads, num_key_value_heads=c.get("num_key_value_heads", heads),
+            head_dim=c.get("head_dim") or c["hidden_size"] // heads, intermediate_size=c["intermediate_size"],
+            vocab_size=c["vocab_size"], rms_norm_eps=c.get("rms_norm_eps", 1e-5),
+            rope_theta=float(c.get("rope_theta", rp.get("rope_theta", 10000.0))), rope_scaling=scaling,
+            tie_word_embeddings=bool(c.get("tie_word_embeddings", False)))
+
+    def to_dict(self) -> dict:
+        return {"model_type": self.model_type, "llm_model_id": self.llm_model_id, "encoder_model_id": self.encoder_model_id,
+                "connector_mode": self.connector_mode, "qformer_num_hidden_layers": self.qformer_num_hidden_layers,
+                "prompt_size": self.prompt_size, "use_lora": self.use_lora, "audio_locator": self.audio_locator,
+                "placeholder_token": self.placeholder_token, "orca_enabled": False,
+                "qformer_intermediate_size": self.qformer_intermediate_size, "target_layer_ids": self.target_layer_ids,
+                "llm_config": asdict(self.llm_config), "encoder_config": asdict(self.encoder_config), "info": self.info}
+
+    def save_pretrained(self, path: str) -> None:
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, "config.json"), "w") as f:
+            json.dump(self.to_dict(), f, indent=2)
+
+    @classmethod
+    def from_pretrained(cls, path: str, **kwargs) -> "DeSTA25Config":
+        d = _read_hf_config(path)
+        d.pop("model_type", None)
+        d.pop("info", None)
+        d.update(kwargs)
+        return cls(**d)
+
+
+def connector_param_shapes(cfg: DeSTA25Config) -> "OrderedDict[str, Tuple[int, ...]]":
+    """Trainable tensors with the reference's state-dict names, in ARENA order:
+    query/key/value weights (and biases) of every attention block are adjacent so that the fused
+    QKV / KV projection GEMMs read them as one [3d, d] / [2d, d] operand."""
+    d, K, nt = cfg.encoder_config.d_model, cfg.prompt_size, len(cfg.target_layer_ids)
+    inter, h = cfg.qformer_intermediate_size, cfg.llm_config.hidden_size
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    for j in range(nt):
+        s[f"{CON}layer_prompts.{j}"] = (1, K, d)
+    s[f"{CON}layer_weights"] = (K, nt)
+    for i in range(cfg.qformer_num_hidden_layers):
+        p = f"{CON}qformer.layer.{i}."
+        for blk in ("attention", "crossattention"):
+            for lin in ("query", "key", "value"):
+                s[f"{p}{blk}.self.{lin}.weight"] = (d, d)
+            for lin in ("query", "key", "value"):
+                s[f"{p}{blk}.self.{lin}.bias"] = (d,)
+            s[f"{p}{blk}.output.dense.weight"] = (d, d)
+            s[f"{p}{blk}.output.dense.bias"] = (d,)
+            s[f"{p}{blk}.output.LayerNorm.weight"] = (d,)
+            s[f"{p}{blk}.output.LayerNorm.bias"] = (d,)
+        s[p + "intermediate.dense.weight"] = (inter, d)
+        s[p + "intermediate.dense.bias"] = (inter,)
+        s[p + "output.dense.weight"] = (d, inter)
+        s[p + "output.dense.bias"] = (d,)
+        s[p + "output.LayerNorm.weight"] = (d,)
+        s[p + "output.LayerNorm.bias"] = (d,)
+    s[CON + "proj.0.weight"] = (d,)
+    s[CON + "proj.0.bias"] = (d,)
+    s[CON + "proj.1.weight"] = (h, d)
+    s[CON + "proj.1.bias"] = (h,)
+    return s
+
+
+def rope_inv_freq(c: LLMConfig) -> torch.Tensor:
+    """Default / llama3-scaled inverse frequencies (TF:modeling_rope_utils.py, `_compute_llama3_parameters`)."""
+    dim = c.head_dim
+    inv = 1.0 / (c.rope_theta ** (torch.arange(0, dim, 2, dtype=torch.float64) / dim))
+    sc = c.rope_scaling
+    if sc is not None and sc.get("rope_type", sc.get("type")) == "llama3":
+        factor, lo, hi = sc["factor"], sc["low_freq_factor"], sc["high_freq_factor"]
+        old = sc["original_max_position_embeddings"]
+        wl = 2 * math.pi / inv
+        inv_l = torch.where(wl > old / lo, inv / factor, inv)
+        smooth = (old / wl - lo) / (hi - lo)
+        sm = (1 - smooth) * inv_l / factor + smooth * inv_l
+        med = ~(wl < old / hi) & ~(wl > old / lo)
+        inv = torch.where(med, sm, inv_l)
+    elif sc is not None:
+        raise NotImplementedError(f"rope scaling {sc} not implemented")
+    return inv.float()
+
+
+class _Out:
+    """`CausalLMOutputWithPast`-shaped result (`.loss` 0-d fp32 tensor, `.logits` [B,S,V])."""
+
+    def __init__(self, loss, logits):
+        self.loss, self.logits = loss, logits
+
+    def __getitem__(self, k):
+        return getattr(self, k)
+
+
+# =========================================================================================== Whisper encoder
+class WhisperEncoderHIP:
+    """Frozen Whisper encoder, forward only (modeling_desta25.py:551-585; no final layer_norm, H2)."""
+
+    def __init__(self, cfg: DeSTA25Config, w: Dict[str, torch.Tensor], device):
+        e = cfg.encoder_config
+        self.cfg, self.e, self.dev = cfg, e, device
+        self.d, self.L, self.heads, self.ffn, self.T = e.d_model, e.encoder_layers, e.encoder_attention_heads, e.encoder_ffn_dim, e.max_source_positions
+        assert self.d // self.heads == 64, "Whisper head_dim is 64 for every released size"
+        self.Cp = _r64(e.num_mel_bins)
+        dev = device
+
+        def g(name):
+            return w[ENC + name].to(dev)
+        c1 = g("conv1.weight").float()                                  # [d, C, 3]
+        w1 = torch.zeros(self.d, 3, self.Cp, dtype=F32, device=dev)
+        w1[:, :, : e.num_mel_bins] = c1.permute(0, 2, 1)
+        self.conv1_w = w1.reshape(self.d, 3 * self.Cp).to(BF16).contiguous()
+        self.conv1_b = g("conv1.bias").float().contiguous()
+        self.conv2_w = g("conv2.weight").float().permute(0, 2, 1).reshape(self.d, 3 * self.d).to(BF16).contiguous()
+        self.conv2_b = g("conv2.bias").float().contiguous()
+        self.pos = g("embed_positions.weight")[: self.T].to(BF16).contiguous()
+        self.layers = []
+        for i in range(self.L):
+            p = f"layers.{i}."
+            qw, kw, vw = g(p + "self_attn.q_proj.weight"), g(p + "self_attn.k_proj.weight"), g(p + "self_attn.v_proj.weight")
+            qb, vb = g(p + "self_attn.q_proj.bias").float(), g(p + "self_attn.v_proj.bias").float()
+            self.layers.append(dict(
+                ln1_g=g(p + "self_attn_layer_norm.weight").float().contiguous(), ln1_b=g(p + "self_attn_layer_norm.bias").float().contiguous(),
+                wqkv=torch.cat([qw, kw, vw], 0).to(BF16).contiguous(),
+                bqkv=torch.cat([qb, torch.zeros_like(qb), vb]).contiguous(),           # k_proj has no bias (H6)
+                wo=g(p + "self_attn.out_proj.weight").to(BF16).contiguous(), bo=g(p + "self_attn.out_proj.bias").float().contiguous(),
+                ln2_g=g(p + "final_layer_norm.weight").float().contiguous(), ln2_b=g(p + "final_layer_norm.bias").float().contiguous(),
+                w1=g(p + "fc1.weight").to(BF16).contiguous(), b1=g(p + "fc1.bias").float().contiguous(),
+                w2=g(p + "fc2.weight").to(BF16).contiguous(), b2=g(p + "fc2.bias").float().contiguous()))
+        self.B = 0
+
+    def _alloc(self, B: int, enc_all: torch.Tensor):
+        d, T, dev = self.d, self.T, self.dev
+        self.B = B
+        self.melrows = torch.zeros(B, 2 * T + 2, self.Cp, dtype=BF16, device=dev)
+        self.h1 = torch.zeros(B, 2 * T + 1, d, dtype=BF16, device=dev)          # row 0 of each clip stays 0 (conv2 left pad)
+        self.x = torch.empty(B * T, d, dtype=BF16, device=dev)
+        self.hb = torch.empty(B * T, d, dtype=BF16, device=dev)
+        self.qkv = torch.empty(B * T, 3 * d, dtype=BF16, device=dev)
+        self.att = torch.empty(B * T, d, dtype=BF16, device=dev)
+        self.ff = torch.empty(B * T, self.ffn, dtype=BF16, device=dev)
+
+    def forward(self, mel: torch.Tensor, enc_all: torch.Tensor) -> None:
+        """mel [B, n_mels, 2T] fp32 -> enc_all [taps, B*T, d] bf16 (tapped hidden states)."""
+        e, d, T = self.e, self.d, self.T
+        B = mel.shape[0]
+        if mel.shape[-1] != 2 * T:
+            raise ValueError(f"Whisper expects the mel input features to be of length {2 * T}, but found "
+                             f"{mel.shape[-1]}. Make sure to pad the input mel features to {2 * T}.")
+        if B != self.B:
+            self._alloc(B, enc_all)
+        M = B * T
+        H.mel_to_rows(mel, self.Cp, self.melrows)
+        # conv1 (k3,s1,p1) + GELU as a zero-copy im2col GEMM over the padded channel-last rows
+        H.gemm(self.melrows, self.conv1_w, self.h1[:, 1:], 2 * T, d, 3 * self.Cp, lda=self.Cp, ldc=d, bias=self.conv1_b,
+               act=1, batch=B, stride_a=(2 * T + 2) * self.Cp, stride_c=(2 * T + 1) * d)
+        # conv2 (k3,s2,p1) + GELU + positions
+        H.gemm(self.h1, self.conv2_w, self.x, T, d, 3 * d, lda=2 * d, ldc=d, bias=self.conv2_b, act=1,
+               residual=self.pos, ldr=d, stride_r=0, batch=B, stride_a=(2 * T + 1) * d, stride_c=T * d)
+        cur = self.x
+        taps = self.cfg.target_layer_ids
+        scale = 64 ** -0.5
+        for i, ly in enumerate(self.layers):
+            H.layernorm_fwd(cur, ly["ln1_g"], ly["ln1_b"], 1e-5, y16=self.hb)
+            H.gemm(self.hb, ly["wqkv"], self.qkv, M, 3 * d, d, bias=ly["bqkv"])
+            ad = H.attn_desc(self.qkv, self.qkv, self.qkv, self.att, None, batch=B, hq=self.heads, hkv=self.heads, sq=T, sk=T,
+                             hd=64, scale=scale, q_off=0, k_off=d, v_off=2 * d)
+            H.attention_fwd(ad)
+            H.gemm(self.att, ly["wo"], self.x, M, d, d, bias=ly["bo"], residual=cur)
+            H.layernorm_fwd(self.x, ly["ln2_g"], ly["ln2_b"], 1e-5, y16=self.hb)
+            H.gemm(self.hb, ly["w1"], self.ff, M, self.ffn, d, bias=ly["b1"], act=1)
+            out = enc_all[taps.index(i)] if i in taps else self.x
+            H.gemm(self.ff, ly["w2"], out, M, d, self.ffn, bias=ly["b2"], residual=self.x)
+            cur = out
+
+
+# =========================================================================================== Q-Former connector
+class QformerConnectorHIP:
+    """Trainable connector (modeling_desta25.py:126-205, 587-606): the 4 taps are run as ONE batch of
+    taps*B prompt sequences (same weights for every tap), hoisted after the encoder loop
+    (mathematically identical), forward + hand-written backward."""
+
+    def __init__(self, cfg: DeSTA25Config, arena: ParamArena, device):
+        self.cfg, self.arena, self.dev = cfg, arena, device
+        self.d, self.K, self.nt = cfg.encoder_config.d_model, cfg.prompt_size, len(cfg.target_layer_ids)
+        self.heads, self.T = cfg.encoder_config.encoder_attention_heads, cfg.encoder_config.max_source_positions
+        self.inter, self.Lq, self.h = cfg.qformer_intermediate_size, cfg.qformer_num_hidden_layers, cfg.llm_config.hidden_size
+        assert self.d // self.heads == 64 and self.d % 64 == 0 and self.inter % 64 == 0 and self.h % 64 == 0
+        assert (self.K * self.d) % 64 == 0, "layer_prompts must tile the arena without padding"
+        self.w16 = torch.empty(arena.numel, dtype=BF16, device=device)          # bf16 image of the arena (autocast copy)
+        self.B = 0
+        # transposed bf16 weights for the dX GEMMs: name -> [in, out]
+        self.wT: Dict[str, torch.Tensor] = {}
+
+    # -- views
+    def P(self, name):
+        return self.arena.param(name)
+
+    def G(self, name):
+        return self.arena.grad(name)
+
+    def W16(self, name, rows=None):
+        """bf16 copy of parameter `name`; rows != None widens the view over adjacent tensors (fused QKV)."""
+        o = self.arena.offsets[name]
+        shape = self.arena.shapes[name]
+        r = shape[0] if rows is None else rows
+        return self.w16[o:o + r * shape[1]].view(r, shape[1])
+
+    def P32(self, name, n=None):
+        o = self.arena.offsets[name]
+        n = int(math.prod(self.arena.shapes[name])) if n is None else n
+        return self.arena.params[o:o + n]
+
+    def G32(self, name, n=None):
+        o = self.arena.offsets[name]
+        n = int(math.prod(self.arena.shapes[name])) if n is None else n
+        return self.arena.grads[o:o + n]
+
+    def refresh_weights(self):
+        """Per step: bf16 image of all parameters + transposed copies for the dX GEMMs."""
+        H.cast_bf16(self.arena.params, self.w16, self.arena.numel)
+        d, inter = self.d, self.inter
+        for i in range(self.Lq):
+            p = f"{CON}qformer.layer.{i}."
+            for key, name, rows, cols in (
+                    ("s.qkv", p + "attention.self.query.weight", 3 * d, d), ("s.o", p + "attention.output.dense.weight", d, d),
+                    ("c.q", p + "crossattention.self.query.weight", d, d), ("c.o", p + "crossattention.output.dense.weight", d, d),
+                    ("i", p + "intermediate.dense.weight", inter, d), ("o", p + "output.dense.weight", d, inter)):
+                k = f"{i}.{key}"
+                if k not in self.wT:
+                    self.wT[k] = torch.empty(cols, rows, dtype=BF16, device=self.dev)
+                H.transpose_to_bf16(self.W16(name, rows), rows, cols, self.wT[k], rows)
+        if "proj" not in self.wT:
+            self.wT["proj"] = torch.empty(d, self.h, dtype=BF16, device=self.dev)
+        H.transpose_to_bf16(self.W16(CON + "proj.1.weight"), self.h, d, self.wT["proj"], self.h)
+
+    def _alloc(self, B: int):
+        d, K, nt, T, dev, inter = self.d, self.K, self.nt, self.T, self.dev, self.inter
+        self.B = B
+        R, E = nt * B * K, nt * B * T
+        self.R, self.E = R, E
+        self.Rp, self.Ep, self.BKp = _r64(R), _r64(E), _r64(B * K)
+
+        def b16(*s):
+            return torch.empty(*s, dtype=BF16, device=dev)
+
+        def f32(*s):
+            return torch.empty(*s, dtype=F32, device=dev)
+        self.x0_32, self.x0_16 = f32(R, d), b16(R, d)
+        self.sv = []
+        for _ in range(self.Lq):
+            self.sv.append(dict(
+                qkv=b16(R, 3 * d), a_s=b16(R, d), lse_s=f32(nt * B, self.heads, K), pre1=f32(R, d), st1=f32(R, 2), x1_32=f32(R, d), x1_16=b16(R, d),
+                qc=b16(R, d), kv=b16(E, 2 * d), a_c=b16(R, d), lse_c=f32(nt * B, self.heads, K), pre2=f32(R, d), st2=f32(R, 2), x2_32=f32(R, d), x2_16=b16(R, d),
+                hpre=b16(R, inter), hact=b16(R, inter), pre3=f32(R, d), st3=f32(R, 2), x3_32=f32(R, d), x3_16=b16(R, d)))
+        self.mixed, self.st_p, self.pb = f32(B * K, d), f32(B * K, 2), b16(B * K, d)
+        self.af = b16(B * K, self.h)
+        # backward scratch
+        self.g32a, self.g32b = f32(R, d), f32(R, d)
+        self.dpre16, self.da, self.dq = b16(R, d), b16(R, d), b16(R, d)
+        self.dqkv, self.dh = b16(R, 3 * d), b16(R, inter)
+        self.dkv = b16(E, 2 * d)
+        self.tA = b16(max(3 * d, inter, self.h) * max(self.Rp, self.BKp))     # transposed dY  [N, Rp]
+        self.tB = b16(max(d, inter) * max(self.Rp, self.BKp))                  # transposed X   [K, Rp]
+        self.tE = b16(d, self.Ep)                                              # enc^T, shared by all layers
+        self.tKV = b16(2 * d, self.Ep)
+        self.dmixed = f32(B * K, d)
+        self.dpb = b16(B * K, d)
+
+    # -- forward
+    def forward(self, enc_all: torch.Tensor, B: int) -> torch.Tensor:
+        """enc_all [taps, B*T, d] bf16 -> audio features [B*K, h] bf16."""
+        if B != self.B:
+            self._alloc(B)
+        d, K, nt, T, R, E = self.d, self.K, self.nt, self.T, self.R, self.E
+        self.enc = enc_all.view(E, d)
+        H.prompt_expand(self.P32(f"{CON}layer_prompts.0", nt * K * d), nt, B, K * d, self.x0_32, self.x0_16)
+        x32, x16 = self.x0_32, self.x0_16
+        scale = 64 ** -0.5
+        for i in range(self.Lq):
+            p, s = f"{CON}qformer.layer.{i}.", self.sv[i]
+            # self-attention over the K queries (bidirectional, H5)
+            H.gemm(x16, self.W16(p + "attention.self.query.weight", 3 * d), s["qkv"], R, 3 * d, d, bias=self.P32(p + "attention.self.query.bias", 3 * d))
+            ad = H.attn_desc(s["qkv"], s["qkv"], s["qkv"], s["a_s"], s["lse_s"], batch=nt * B, hq=self.heads, hkv=self.heads, sq=K, sk=K,
+                             hd=64, scale=scale, q_off=0, k_off=d, v_off=2 * d)
+            H.attention_fwd(ad)
+            s["ad_s"] = ad
+            H.gemm(s["a_s"], self.W16(p + "attention.output.dense.weight"), s["pre1"], R, d, d, bias=self.P32(p + "attention.output.dense.bias"), residual=x32)
+            H.layernorm_fwd(s["pre1"], self.P32(p + "attention.output.LayerNorm.weight"), self.P32(p + "attention.output.LayerNorm.bias"), 1e-12,
+                            y16=s["x1_16"], y32=s["x1_32"], stats=s["st1"])
+            # cross-attention: K queries x T encoder states (unmasked)
+            H.gemm(s["x1_16"], self.W16(p + "crossattention.self.query.weight"), s["qc"], R, d, d, bias=self.P32(p + "crossattention.self.query.bias"))
+            H.gemm(self.enc, self.W16(p + "crossattention.self.key.weight", 2 * d), s["kv"], E, 2 * d, d, bias=self.P32(p + "crossattention.self.key.bias", 2 * d))
+            ad = H.attn_desc(s["qc"], s["kv"], s["kv"], s["a_c"], s["lse_c"], batch=nt * B, hq=self.heads, hkv=self.heads, sq=K, sk=T,
+                             hd=64, scale=scale, q_off=0, k_off=0, v_off=d)
+            H.attention_fwd(ad)
+            s["ad_c"] = ad
+            H.gemm(s["a_c"], self.W16(p + "crossattention.output.dense.weight"), s["pre2"], R, d, d, bias=self.P32(p + "crossattention.output.dense.bias"), residual=s["x1_32"])
+            H.layernorm_fwd(s["pre2"], self.P32(p + "crossattention.output.LayerNorm.weight"), self.P32(p + "crossattention.output.LayerNorm.bias"), 1e-12,
+                            y16=s["x2_16"], y32=s["x2_32"], stats=s["st2"])
+            # FFN
+            H.gemm(s["x2_16"], self.W16(p + "intermediate.dense.weight"), s["hact"], R, self.inter, d, bias=self.P32(p + "intermediate.dense.bias"), act=1, preact=s["hpre"])
+            H.gemm(s["hact"], self.W16(p + "output.dense.weight"), s["pre3"], R, d, self.inter, bias=self.P32(p + "output.dense.bias"), residual=s["x2_32"])
+            H.layernorm_fwd(s["pre3"], self.P32(p + "output.LayerNorm.weight"), self.P32(p + "output.LayerNorm.bias"), 1e-12,
+                            y16=s["x3_16"], y32=s["x3_32"], stats=s["st3"])
+            s["x_in32"], s["x_in16"] = x32, x16
+            x32, x16 = s["x3_32"], s["x3_16"]
+        self.qf_out = x32
+        H.tap_mix_fwd(x32, self.P32(CON + "layer_weights"), nt, B, K, d, self.mixed)
+        H.layernorm_fwd(self.mixed, self.P32(CON + "proj.0.weight"), self.P32(CON + "proj.0.bias"), 1e-5, y16=self.pb, stats=self.st_p)
+        H.gemm(self.pb, self.W16(CON + "proj.1.weight"), self.af, B * K, self.h, d, bias=self.P32(CON + "proj.1.bias"))
+        return self.af
+
+    # -- backward helpers
+    def _dW(self, dY, X, M, N, Kin, wname, bname, Mp, x_is_T=None):
+        """grad(wname)[N,Kin] = dY[M,N]^T @ X[M,Kin];  grad(bname)[N] = colsum(dY).  bf16 operands."""
+        tA = self.tA[: N * Mp].view(N, Mp)
+        H.transpose_to_bf16(dY, M, N, tA, Mp, ld_in=dY.shape[-1])
+        if x_is_T is None:
+            tB = self.tB[: Kin * Mp].view(Kin, Mp)
+            H.transpose_to_bf16(X, M, Kin, tB, Mp, ld_in=X.shape[-1])
+        else:
+            tB = x_is_T
+        H.gemm(tA, tB, self.G(wname) if N == self.arena.shapes[wname][0] else self._gwide(wname, N), N, Kin, Mp)
+        if bname is not None:
+            H.colsum(dY, M, N, dY.shape[-1], self.G32(bname, N))
+
+    def _gwide(self, name, rows):
+        o = self.arena.offsets[name]
+        cols = self.arena.shapes[name][1]
+        return self.arena.grads[o:o + rows * cols].view(rows, cols)
+
+    def backward(self, d_af: torch.Tensor) -> None:
+        """d_af [B*K, h] bf16 = dL/d audio_features  ->  gradients of every connector tensor (arena.grads)."""
+        d, K, nt, T, R, E, B, inter, h = self.d, self.K, self.nt, self.T, self.R, self.E, self.B, self.inter, self.h
+        BK = B * K
+        # projector
+        self._dW(d_af, self.pb, BK, h, d, CON + "proj.1.weight", CON + "proj.1.bias", self.BKp)
+        H.gemm(d_af, self.wT["proj"], self.dpb, BK, d, h)
+        H.layernorm_bwd(self.dpb, self.mixed, self.P32(CON + "proj.0.weight"), self.st_p, dx32=self.dmixed,
+                        dgamma=self.G32(CON + "proj.0.weight"), dbeta=self.G32(CON + "proj.0.bias"))
+        dx = self.g32a                                                        # grad wrt current layer output (fp32 [R,d])
+        H.tap_mix_bwd(self.qf_out, self.P32(CON + "layer_weights"), self.dmixed, nt, B, K, d, dx, self.G32(CON + "layer_weights"))
+        other = self.g32b
+        H.transpose_to_bf16(self.enc, E, d, self.tE, self.Ep)
+        for i in reversed(range(self.Lq)):
+            p, s = f"{CON}qformer.layer.{i}.", self.sv[i]
+            # --- FFN block: x3 = LN(pre3), pre3 = hact@Wo^T + b + x2
+            dpre, dpre16, dh, da, dq, dqkv = other, self.dpre16, self.dh, self.da, self.dq, self.dqkv
+            H.layernorm_bwd(dx, s["pre3"], self.P32(p + "output.LayerNorm.weight"), s["st3"], dx32=dpre, dx16=dpre16,
+                            dgamma=self.G32(p + "output.LayerNorm.weight"), dbeta=self.G32(p + "output.LayerNorm.bias"))
+            self._dW(dpre16, s["hact"], R, d, inter, p + "output.dense.weight", p + "output.dense.bias", self.Rp)
+            H.gemm(dpre16, self.wT[f"{i}.o"], dh, R, inter, d)
+            H.gelu_bwd(s["hpre"], dh, dh, R * inter)
+            self._dW(dh, s["x2_16"], R, inter, d, p + "intermediate.dense.weight", p + "intermediate.dense.bias", self.Rp)
+            H.gemm(dh, self.wT[f"{i}.i"], dx, R, d, inter, residual=dpre)                      # dx := d x2_32
+            # --- cross-attention block: x2 = LN(pre2), pre2 = a_c@Wo^T + b + x1
+            H.layernorm_bwd(dx, s["pre2"], self.P32(p + "crossattention.output.LayerNorm.weight"), s["st2"], dx32=dpre, dx16=dpre16,
+                            dgamma=self.G32(p + "crossattention.output.LayerNorm.weight"), dbeta=self.G32(p + "crossattention.output.LayerNorm.bias"))
+            self._dW(dpre16, s["a_c"], R, d, d, p + "crossattention.output.dense.weight", p + "crossattention.output.dense.bias", self.Rp)
+            H.gemm(dpre16, self.wT[f"{i}.c.o"], da, R, d, d)
+            H.attention_bwd(s["ad_c"], da, dq, self.dkv, self.dkv, dk_off=0, dv_off=d)
+            self._dW(dq, s["x1_16"], R, d, d, p + "crossattention.self.query.weight", p + "crossattention.self.query.bias", self.Rp)
+            # key/value projections of the encoder states (no dX into the frozen Whisper states)
+            H.transpose_to_bf16(self.dkv, E, 2 * d, self.tKV, self.Ep)
+            H.gemm(self.tKV, self.tE, self._gwide(p + "crossattention.self.key.weight", 2 * d), 2 * d, d, self.Ep)
+            H.colsum(self.dkv, E, 2 * d, 2 * d, self.G32(p + "crossattention.self.key.bias", 2 * d))
+            H.gemm(dq, self.wT[f"{i}.c.q"], dx, R, d, d, residual=dpre)                         # dx := d x1_32
+            # --- self-attention block: x1 = LN(pre1), pre1 = a_s@Wo^T + b + x_in
+            H.layernorm_bwd(dx, s["pre1"], self.P32(p + "attention.output.LayerNorm.weight"), s["st1"], dx32=dpre, dx16=dpre16,
+                            dgamma=self.G32(p + "attention.output.LayerNorm.weight"), dbeta=self.G32(p + "attention.output.LayerNorm.bias"))
+            self._dW(dpre16, s["a_s"], R, d, d, p + "attention.output.dense.weight", p + "attention.output.dense.bias", self.Rp)
+            H.gemm(dpre16, self.wT[f"{i}.s.o"], da, R, d, d)
+            H.attention_bwd(s["ad_s"], da, dqkv, dqkv, dqkv, dq_off=0, dk_off=d, dv_off=2 * d)
+            self._dW(dqkv, s["x_in16"], R, 3 * d, d, p + "attention.self.query.weight", p + "attention.self.query.bias", self.Rp)
+            H.gemm(dqkv, self.wT[f"{i}.s.qkv"], dx, R, d, 3 * d, residual=dpre)                # dx := d x_in32
+        H.prompt_grad(dx, nt, B, K * d, self.G32(f"{CON}layer_prompts.0", nt * K * d))
+
+
+# =========================================================================================== causal LM
+class CausalLMHIP:
+    """Frozen Llama-3.1 / Qwen3 decoder: forward + dX-only backward."""
+
+    def __init__(self, cfg: DeSTA25Config, w: Dict[str, torch.Tensor], device):
+        c = cfg.llm_config
+        self.c, self.dev = c, device
+        self.h, self.L, self.hq, self.hkv, self.hd, self.I, self.V = c.hidden_size, c.num_hidden_layers, c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.intermediate_size, c.vocab_size
+        assert self.hd in (64, 128), "head_dim 64 or 128"
+        assert self.h % 64 == 0 and self.I % 64 == 0 and (self.hq * self.hd) % 64 == 0
+        self.qkvw = (self.hq + 2 * self.hkv) * self.hd
+        self.Vp = _r64(self.V)
+        dev = device
+
+        def g(name):
+            return w[LLM + name].to(dev)
+
+        def T(x):                                   # [out,in] bf16 -> [in, out(+pad)] bf16 via the HIP transpose
+            o, i = x.shape
+            t = torch.empty(i, _r64(o), dtype=BF16, device=dev)
+            H.transpose_to_bf16(x, o, i, t, _r64(o))
+            return t
+        self.embed = g("model.embed_tokens.weight").to(BF16).contiguous()
+        self.layers = []
+        for i in range(self.L):
+            p = f"model.layers.{i}."
+            wqkv = torch.cat([g(p + "self_attn.q_proj.weight"), g(p + "self_attn.k_proj.weight"), g(p + "self_attn.v_proj.weight")], 0).to(BF16).contiguous()
+            wo = g(p + "self_attn.o_proj.weight").to(BF16).contiguous()
+            wgu = torch.cat([g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight")], 0).to(BF16).contiguous()
+            wd = g(p + "mlp.down_proj.weight").to(BF16).contiguous()
+            ly = dict(n1=g(p + "input_layernorm.weight").float().contiguous(), n2=g(p + "post_attention_layernorm.weight").float().contiguous(),
+                      wqkv=wqkv, wqkvT=T(wqkv), wo=wo, woT=T(wo), wgu=wgu, wguT=T(wgu), wd=wd, wdT=T(wd))
+            if c.qk_norm:
+                ly["qn"] = g(p + "self_attn.q_norm.weight").float().contiguous()
+                ly["kn"] = g(p + "self_attn.k_norm.weight").float().contiguous()
+            self.layers.append(ly)
+        self.norm = g("model.norm.weight").float().contiguous()
+        self.head = self.embed if c.tie_word_embeddings else g("lm_head.weight").to(BF16).contiguous()
+        self.headT = T(self.head)                                             # [h, Vp], zero padded
+        self.inv_freq = rope_inv_freq(c).to(dev)
+        self.B = self.S = 0
+
+    def _alloc(self, B: int, S: int):
+        h, dev, M = self.h, self.dev, B * S
+        self.B, self.S, self.M = B, S, M
+
+        def b16(*s):
+            return torch.empty(*s, dtype=BF16, device=dev)
+        fr = torch.outer(torch.arange(S, device=dev, dtype=F32), self.inv_freq)
+        self.cos_sin = torch.stack([fr.cos(), fr.sin()], dim=1).contiguous()                 # [S, 2, hd/2]
+        self.xs = [b16(M, h) for _ in range(self.L + 1)]
+        self.sv = []
+        for _ in range(self.L):
+            s = dict(r1=torch.empty(M, dtype=F32, device=dev), qkv=b16(M, self.qkvw), att=b16(M, self.hq * self.hd),
+                     lse=torch.empty(B, self.hq, S, dtype=F32, device=dev), xm=b16(M, h), r2=torch.empty(M, dtype=F32, device=dev), gu=b16(M, 2 * self.I))
+            if self.c.qk_norm:
+                s["pre"] = b16(M, self.qkvw)
+            self.sv.append(s)
+        self.rf = torch.empty(M, dtype=F32, device=dev)
+        self.hb = b16(M, h)
+        self.act = b16(M, self.I)
+        self.logits = torch.zeros(M, self.Vp, dtype=BF16, device=dev)                        # pad columns stay 0
+        self.loss = torch.zeros(1, dtype=F32, device=dev)
+        # backward scratch
+        self.dxa, self.dxb = b16(M, h), b16(M, h)
+        self.dgu = b16(M, 2 * self.I)
+        self.dqkv = b16(M, self.qkvw)
+        self.datt = b16(M, self.hq * self.hd)
+
+    def forward(self, x0_filler, B: int, S: int, kv_start: Optional[torch.Tensor], labels: Optional[torch.Tensor], need_grad: bool):
+        """`x0_filler(buf)` writes inputs_embeds [B*S, h] bf16 into buf.  Returns (loss tensor|None, logits view)."""
+        if (B, S) != (self.B, self.S):
+            self._alloc(B, S)
+        c, h, M = self.c, self.h, self.M
+        x0_filler(self.xs[0])
+        self.kv_start = kv_start
+        scale = self.hd ** -0.5
+        for i, (ly, s) in enumerate(zip(self.layers, self.sv)):
+            x = self.xs[i]
+            H.rmsnorm_fwd(x, ly["n1"], c.rms_norm_eps, self.hb, s["r1"])
+            H.gemm(self.hb, ly["wqkv"], s["qkv"], M, self.qkvw, h, preact=s.get("pre"))
+            H.rope(s["qkv"], self.qkvw, M, S, self.hq, self.hkv, self.hd, self.cos_sin, ly.get("qn"), ly.get("kn"), c.rms_norm_eps)
+            ad = H.attn_desc(s["qkv"], s["qkv"], s["qkv"], s["att"], s["lse"], batch=B, hq=self.hq, hkv=self.hkv, sq=S, sk=S, hd=self.hd,
+                             scale=scale, causal=True, kv_start=kv_start, q_off=0, k_off=self.hq * self.hd, v_off=(self.hq + self.hkv) * self.hd)
+            H.attention_fwd(ad)
+            s["ad"] = ad
+            H.gemm(s["att"], ly["wo"], s["xm"], M, h, self.hq * self.hd, residual=x)
+            H.rmsnorm_fwd(s["xm"], ly["n2"], c.rms_norm_eps, self.hb, s["r2"])
+            H.gemm(self.hb, ly["wgu"], s["gu"], M, 2 * self.I, h)
+            H.swiglu_fwd(s["gu"], self.act, M, self.I)
+            H.gemm(self.act, ly["wd"], self.xs[i + 1], M, h, self.I, residual=s["xm"])
+        H.rmsnorm_fwd(self.xs[self.L], self.norm, c.rms_norm_eps, self.hb, self.rf)
+        H.gemm(self.hb, self.head, self.logits, M, self.V, h, ldc=self.Vp)
+        return self.logits
+
+    def loss_and_grad(self, labels: torch.Tensor, write_grad: bool) -> torch.Tensor:
+        """ForCausalLMLoss on the logits of the last forward; with write_grad the logits buffer becomes dlogits."""
+        H.causal_lm_loss(self.logits, self.Vp, labels, self.B, self.S, self.V, self.loss, write_grad=write_grad)
+        return self.loss
+
+    def backward(self) -> torch.Tensor:
+        """dlogits (in self.logits) -> dL/d inputs_embeds [B*S, h] bf16."""
+        c, h, M, S = self.c, self.h, self.M, self.S
+        dhb = self.hb
+        H.gemm(self.logits, self.headT, dhb, M, h, self.Vp, ldb=self.Vp)
+        dx, other = self.dxa, self.dxb
+        H.rmsnorm_bwd(dhb, self.xs[self.L], self.norm, self.rf, dx)
+        for i in reversed(range(self.L)):
+            ly, s = self.layers[i], self.sv[i]
+            H.gemm(dx, ly["wdT"], self.act, M, self.I, h)                                     # d act
+            H.swiglu_bwd(s["gu"], self.act, self.dgu, M, self.I)
+            H.gemm(self.dgu, ly["wguT"], dhb, M, h, 2 * self.I)
+            H.rmsnorm_bwd(dhb, s["xm"], ly["n2"], s["r2"], other, dres=dx)                   # other := d x_mid
+            H.gemm(other, ly["woT"], self.datt, M, self.hq * self.hd, h)
+            H.attention_bwd(s["ad"], self.datt, self.dqkv, self.dqkv, self.dqkv, dq_off=0, dk_off=self.hq * self.hd, dv_off=(self.hq + self.hkv) * self.hd)
+            H.rope(self.dqkv, self.qkvw, M, S, self.hq, self.hkv, self.hd, self.cos_sin, ly.get("qn"), ly.get("kn"), c.rms_norm_eps,
+                   pre_norm=s.get("pre"), ld_pre=self.qkvw, backward=True)
+            H.gemm(self.dqkv, ly["wqkvT"], dhb, M, h, self.qkvw)
+            H.rmsnorm_bwd(dhb, self.xs[i], ly["n1"], s["r1"], dx, dres=other)                # dx := d x_in
+        return dx
+
+
+# =========================================================================================== the model
+class DeSTA25AudioModel:
+    """Drop-in for the reference's `DeSTA25AudioModel` on the qformer_1 path (hot path only)."""
+    config_class = DeSTA25Config
+
+    def __init__(self, config: DeSTA25Config, weights: Optional[Dict[str, torch.Tensor]] = None, device="cuda:0", **kwargs):
+        if not torch.cuda.is_available():
+            raise RuntimeError("DeSTA25AudioModel (MI355X hot path) needs a HIP device; there is no CPU fallback")
+        self.config = config
+        self.device = torch.device(device)
+        self.audio_locator, self.placeholder_token = config.audio_locator, config.placeholder_token
+        if weights is None:
+            weights = self._load_base_weights(config)
+        shapes = connector_param_shapes(config)
+        self.arena = ParamArena(list(shapes.items()), self.device)
+        self.trainable_parameter_names = list(shapes.keys())
+        with torch.cuda.device(self.device):
+            self.encoder = WhisperEncoderHIP(config, weights, self.device)
+            self.llm = CausalLMHIP(config, weights, self.device)
+            self.connector = QformerConnectorHIP(config, self.arena, self.device)
+        self._init_connector(weights)
+        e = config.encoder_config
+        self.enc_all = None
+        self.training = True
+        self._weights_dirty = True
+        self._fwd = None
+        self._enc_prefetched = None
+
+    # -- weights -------------------------------------------------------------------------------
+    @staticmethod
+    def _load_base_weights(config) -> Dict[str, torch.Tensor]:
+        """Base LLM + Whisper weights from LOCAL HF directories (safetensors only; nothing is executed)."""
+        from safetensors import safe_open
+        out: Dict[str, torch.Tensor] = {}
+        for path, prefix, keep in ((config.llm_model_id, LLM, None), (config.encoder_model_id, "perception.whisper.", "model.encoder.")):
+            files = sorted(f for f in os.listdir(path) if f.endswith(".safetensors")) if os.path.isdir(path) else []
+            if not files:
+                raise FileNotFoundError(f"no *.safetensors under '{path}' (local HF model directory required; no hub access)")
+            for fn in files:
+                with safe_open(os.path.join(path, fn), framework="pt") as f:
+                    for k in f.keys():
+                        if keep is None or k.startswith(keep):
+                            out[prefix + k] = f.get_tensor(k)
+        return out
+
+    def _init_connector(self, weights):
+        """Load connector tensors from `weights` when present, else the reference's init (H4):
+        torch-default nn.Linear / LayerNorm init, randn prompts, zero mix weights."""
+        g = torch.Generator().manual_seed(0)
+        for name, shape in self.arena.shapes.items():
+            if name in weights:
+                self.arena.param(name).copy_(weights[name].to(self.device, F32).reshape(shape))
+                continue
+            if "layer_prompts" in name:
+                v = torch.randn(*shape, generator=g)
+            elif name.endswith("layer_weights"):
+                v = torch.zeros(*shape)
+            elif "LayerNorm" in name or ".proj.0." in name:
+                v = torch.ones(*shape) if name.endswith("weight") else torch.zeros(*shape)
+            elif name.endswith(".weight"):
+                v = (torch.rand(*shape, generator=g) * 2 - 1) / math.sqrt(shape[1])
+            else:
+                fan_in = self.arena.shapes[name[:-4] + "weight"][1]
+                v = (torch.rand(*shape, generator=g) * 2 - 1) / math.sqrt(fan_in)
+            self.arena.param(name).copy_(v.to(self.device))
+
+    def named_parameters(self):
+        for n in self.trainable_parameter_names:
+            yield n, self.arena.param(n)
+
+    def state_dict(self):
+        """Only the trainable parameters, like the reference (modeling_desta25.py:1284-1292)."""
+        return OrderedDict((n, self.arena.param(n).detach().clone()) for n in sorted(self.trainable_parameter_names))
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        sd = {k.replace("ocar_cross_attns", "orca_cross_attns"): v for k, v in state_dict.items()}
+        missing = [n for n in self.trainable_parameter_names if n not in sd]
+        unexpected = [k for k in sd if k not in self.arena.shapes]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict: missing {missing[:5]} unexpected {unexpected[:5]}")
+        for n in self.trainable_parameter_names:
+            if n in sd:
+                self.arena.param(n).copy_(sd[n].to(self.device, F32).reshape(self.arena.shapes[n]))
+        self._weights_dirty = True
+        return missing, unexpected
+
+    def save_pretrained(self, path: str, state_dict=None, **kwargs):
+        from safetensors.torch import save_file
+        os.makedirs(path, exist_ok=True)
+        self.config.save_pretrained(path)
+        sd = state_dict if state_dict is not None else self.state_dict()
+        save_file({k: v.detach().cpu().contiguous() for k, v in sd.items()}, os.path.join(path, "model.safetensors"))
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, *args, **kwargs):
+        """Config + base models from local dirs, then trainable-only model.safetensors (strict=False)."""
+        from safetensors.torch import load_file
+        config = cls.config_class.from_pretrained(pretrained_model_name_or_path)
+        model = cls(config, **{k: v for k, v in kwargs.items() if k in ("weights", "device")})
+        if not os.path.isdir(pretrained_model_name_or_path):
+            raise FileNotFoundError(f"'{pretrained_model_name_or_path}' is not a local directory (no hub access)")
+        model.load_state_dict(load_file(os.path.join(pretrained_model_name_or_path, "model.safetensors")), strict=False)
+        return model
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def mark_weights_updated(self):
+        self._weights_dirty = True
+
+    # -- forward / backward ----------------------------------------------------------------------
+    def _src_rows(self, input_ids, batch_transcription_ids, batch_start_positions, audio_lengths):
+        """int32 map [B*S]: >=0 token row of the embedding table, <0 -(audio_row+1)."""
+        B, S = input_ids.shape
+        K = self.config.prompt_size
+        src = input_ids.to(torch.int32).clone()
+        for a, (row, start) in enumerate(batch_start_positions):
+            row, start = int(row), int(start)
+            tr = batch_transcription_ids[a].reshape(-1)
+            n = K + tr.numel()
+            assert start + n <= S, "audio span exceeds the sequence"
+            src[row, start:start + K] = -(torch.arange(a * K, (a + 1) * K, device=src.device, dtype=torch.int32) + 1)
+            if tr.numel():
+                src[row, start + K:start + n] = tr.to(src.device, torch.int32)
+        return src.reshape(-1).contiguous()
+
+    def forward(self, input_ids, attention_mask, batch_features, batch_transcription_ids, batch_start_positions,
+                labels=None, **kwargs):
+        cfg, dev = self.config, self.device
+        B, S = input_ids.shape
+        K = cfg.prompt_size
+        input_ids = input_ids.to(dev)
+        attention_mask = attention_mask.to(dev)
+        N_audio = len(batch_start_positions)
+        with torch.cuda.device(dev):
+            if self._weights_dirty:
+                self.connector.refresh_weights()
+                self._weights_dirty = False
+            af = None
+            if N_audio > 0:
+                assert len(batch_start_positions) == len(batch_transcription_ids) == batch_features.shape[0], \
+                    "batch_start_positions, batch_transcription_ids, audio_features, speech_feature_lengths must have the same length."
+                mel = batch_features.to(dev, F32).contiguous()
+                e = cfg.encoder_config
+                nt = len(cfg.target_layer_ids)
+                if self.enc_all is None or self.enc_all.shape[1] != N_audio * e.max_source_positions:
+                    self.enc_all = torch.empty(nt, N_audio * e.max_source_positions, e.d_model, dtype=BF16, device=dev)
+                if self._enc_prefetched != (batch_features.data_ptr(), tuple(batch_features.shape)):
+                    self.encoder.forward(mel, self.enc_all)
+                self._enc_prefetched = None
+                af = self.connector.forward(self.enc_all, N_audio)
+                src = self._src_rows(input_ids, [t.to(dev) for t in batch_transcription_ids], batch_start_positions, None)
+            else:
+                src = input_ids.to(torch.int32).reshape(-1).contiguous()
+            kv_start = (attention_mask == 0).sum(dim=1).to(torch.int32).contiguous()
+            h = cfg.llm_config.hidden_size
+
+            def fill(buf):
+                H.embed_gather(self.llm.embed, af, src, B * S, h, buf)
+            logits = self.llm.forward(fill, B, S, kv_start, labels, self.training)
+            V = cfg.llm_config.vocab_size
+            out_logits = logits.view(B, S, self.llm.Vp)[:, :, :V]
+            loss = None
+            if labels is not None:
+                labels = labels.to(dev).contiguous()
+                need_grad = self.training and N_audio > 0
+                if need_grad:
+                    # dlogits overwrite the logits buffer: hand the caller a copy only if asked to keep them
+                    if kwargs.get("keep_logits", False):
+                        out_logits = out_logits.clone()
+                    else:
+                        out_logits = None
+                loss = self.llm.loss_and_grad(labels, write_grad=need_grad).view(())
+            # audio rows of inputs_embeds, for the backward gather
+            self._fwd = dict(B=B, S=S, N_audio=N_audio, starts=[(int(r), int(s)) for r, s in batch_start_positions],
+                             has_grad=labels is not None and self.training and N_audio > 0)
+        return _Out(loss, out_logits)
+
+    __call__ = forward
+
+    def prefetch_encoder(self, batch_features: torch.Tensor) -> None:
+        """Run the FROZEN Whisper encoder for the next batch now (it does not depend on the connector
+        weights, so it may overlap the previous step's all-reduce + optimizer on another stream)."""
+        cfg, dev = self.config, self.device
+        e, nt, N = cfg.encoder_config, len(cfg.target_layer_ids), batch_features.shape[0]
+        with torch.cuda.device(dev):
+            mel = batch_features.to(dev, F32).contiguous()
+            if self.enc_all is None or self.enc_all.shape[1] != N * e.max_source_positions:
+                self.enc_all = torch.empty(nt, N * e.max_source_positions, e.d_model, dtype=BF16, device=dev)
+            self.encoder.forward(mel, self.enc_all)
+        self._enc_prefetched = (batch_features.data_ptr(), tuple(batch_features.shape))
+
+    def backward(self) -> None:
+        """Gradients of the last forward's loss w.r.t. every connector tensor -> arena.grads (overwritten)."""
+        f = self._fwd
+        if not f or not f["has_grad"]:
+            raise RuntimeError("backward() needs a training-mode forward with labels and at least one audio")
+        K, S = self.config.prompt_size, f["S"]
+        with torch.cuda.device(self.device):
+            dx0 = self.llm.backward()
+            idx = torch.cat([torch.arange(r * S + s, r * S + s + K, dtype=torch.int32) for r, s in f["starts"]]).to(self.device)
+            d_af = torch.empty(f["N_audio"] * K, self.config.llm_config.hidden_size, dtype=BF16, device=self.device)
+            H.gather_rows(dx0, idx, f["N_audio"] * K, self.config.llm_config.hidden_size, d_af)
+            self.connector.backward(d_af)
+        self._fwd = None

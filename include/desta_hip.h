@@ -203,6 +203,12 @@ int desta_attention_fwd(const desta_attn_desc* d, void* stream);
 size_t desta_attention_bwd_workspace_floats(int batch, int n_q_heads, int seq_q);
 int desta_attention_bwd(const desta_attn_desc* d, float* workspace, void* stream);
 
+/* layer_prompts[j].expand(B,-1,-1) for all taps at once (modeling_desta25.py:589): prompts fp32
+ * [taps][n], n = prompt_size*d -> rows [(taps*batch)][n] in fp32 and bf16; prompt_grad sums the
+ * gradient back over the batch. */
+int desta_prompt_expand(const float* prompts, int taps, int batch, int64_t n, float* x_f32, void* x_bf16, void* stream);
+int desta_prompt_grad(const float* dx, int taps, int batch, int64_t n, float* dprompts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -464,9 +464,14 @@ def decay_mask(names: List[str]) -> List[bool]:
     return out
 
 
-def clip_grad_norm(grads: List[Tensor], max_norm: float = 1.0) -> Tensor:
-    """``torch.nn.utils.clip_grad_norm_`` semantics (in place); returns the total norm."""
-    total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g.float(), 2) for g in grads]), 2)
+def clip_grad_norm(grads: List[Tensor], max_norm: float = 1.0, f64: bool = False) -> Tensor:
+    """``torch.nn.utils.clip_grad_norm_`` semantics (in place); returns the total norm.
+    ``f64=True`` accumulates the norm in float64 (the fp32 CPU norm of multi-million-element tensors
+    carries ~1e-4 relative summation error of its own, which would otherwise dominate a comparison)."""
+    if f64:
+        total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).float()
+    else:
+        total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g.float(), 2) for g in grads]), 2)
     coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
     for g in grads:
         g.mul_(coef)

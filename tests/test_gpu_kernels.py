@@ -120,6 +120,8 @@ def _run_adafactor_case(hip, shapes, steps, gscale):
     opt = FusedAdafactor(arena, weight_decay=0.01)
     wd = [0.01 if m else 0.0 for m in O.decay_mask(names)]
     st = O.adafactor_init(p_o)
+    p_32 = [x.clone() for x in p_o]                 # second oracle copy driven by the plain fp32 norm
+    st_32 = O.adafactor_init(p_32)
     for step in range(steps):
         grads = [torch.randn(*s, generator=g) * gscale[step % len(gscale)] for s in shapes]
         for n, gr in zip(names, grads):
