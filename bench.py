@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""bench.py — train steps/s of the MI355X-native DeSTA2.5-Audio hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the whole hot path over one per-GPU batch (B=8 synthetic 30 s clips + 640
+tokens): log-mel -> Whisper-large-v3 encoder -> Q-Former 6L -> projector -> splice -> Llama-3.1-8B ->
+CE -> backward (dX through the LLM, dW+dX through the connector) -> mean all-reduce of the flat
+gradient arena over RCCL (N>1) -> global-norm clip -> Adafactor -> LR schedule.  Inputs (waveforms,
+token ids) are resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "desta2.5-audio_amd"))
+
+import torch
+import torch.distributed as dist
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md §Chip-level parameters
+
+
+def cpu_baseline(cfg, B, S_ctx, S_tgt, threads):
+    """CPU 'port' baseline: the oracle (oracle/desta_oracle.py, plain fp32 PyTorch restatement of the
+    reference step) timed on this box's host cores on a BOUNDED sample of the same workload — one layer
+    of each stack at true width at B=1 — and scaled by layer counts and batch to one full step."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import desta_oracle as O
+    torch.set_num_threads(threads)
+    c, e = cfg.llm_config, cfg.encoder_config
+    sc = c.rope_scaling
+    d = O.Dims(n_mels=e.num_mel_bins, enc_d=e.d_model, enc_layers=1, enc_heads=e.encoder_attention_heads, enc_ffn=e.encoder_ffn_dim,
+               enc_T=e.max_source_positions, taps=(0,), qf_layers=1, qf_inter=cfg.qformer_intermediate_size, prompt_size=cfg.prompt_size,
+               llm_h=c.hidden_size, llm_layers=1, llm_hq=c.num_attention_heads, llm_hkv=c.num_key_value_heads, llm_hd=c.head_dim,
+               llm_inter=c.intermediate_size, vocab=c.vocab_size, rms_eps=c.rms_norm_eps, rope_theta=c.rope_theta,
+               rope_llama3=(sc["factor"], sc["low_freq_factor"], sc["high_freq_factor"], sc["original_max_position_embeddings"]) if sc else None,
+               qk_norm=c.qk_norm)
+    w = O.init_weights(d, seed=0)
+    batch = O.synthetic_batch(d, B=1, S_ctx=S_ctx, S_tgt=S_tgt, seed=1)
+    names = O.trainable_names(d)
+
+    def timed(fn, reps=1):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return (time.perf_counter() - t0) / reps
+    wave = (0.1 * torch.randn(1, 480000)).clamp(-1, 1)
+    t_mel = timed(lambda: O.logmel(wave, d.n_mels))
+    with torch.no_grad():
+        mel = batch["batch_features"]
+        t_stem = timed(lambda: O.whisper_stem(w, d, mel))
+        x = O.whisper_stem(w, d, mel)
+        t_enc = timed(lambda: O.whisper_layer(w, d, 0, x))
+    for n in names:
+        w[n].requires_grad_(True)
+
+    def qf():
+        y = O.qformer_layer(w, d, 0, w[O.CON + "layer_prompts.0"].expand(1, -1, -1), x)
+        y.sum().backward()
+    t_qf = timed(qf)
+    af = torch.randn(1, d.prompt_size, d.llm_h, requires_grad=True)
+
+    def llm(layers):
+        dd = O.Dims(**{**d.__dict__, "llm_layers": layers})
+        xe = O.embed_splice(w, dd, batch["input_ids"], af, batch["batch_transcription_ids"], batch["batch_start_positions"])
+        loss = O.causal_lm_loss(O.llm_forward(w, dd, xe, batch["attention_mask"]), batch["labels"])
+        loss.backward()
+    t_l1 = timed(lambda: llm(1))
+    t_l0 = timed(lambda: llm(0))
+    t_layer, t_head = max(t_l1 - t_l0, 1e-6), t_l0
+    nt = len(cfg.target_layer_ids)
+    full = B * (t_mel + t_stem + e.encoder_layers * t_enc + nt * cfg.qformer_num_hidden_layers * t_qf
+                + c.num_hidden_layers * t_layer + t_head)
+    sample = (f"oracle fp32 on {threads} threads, B=1: log-mel {t_mel:.2f}s, conv stem {t_stem:.2f}s, 1 Whisper layer fwd {t_enc:.2f}s, "
+              f"1 Q-Former layer fwd+bwd on one tap {t_qf:.2f}s, 1 LLM layer fwd+bwd {t_layer:.2f}s, final norm+lm_head+CE fwd+bwd {t_head:.2f}s; "
+              f"scaled to B={B}, {e.encoder_layers}+{nt}x{cfg.qformer_num_hidden_layers}+{c.num_hidden_layers} layers (optimizer/clip time excluded: <1% of the step)")
+    return {"value": 1.0 / full, "unit": "steps/s", "cores": threads, "kind": "port", "sample": sample}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="desta25_llama31-8B_Qformer6L")
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--ctx", type=int, default=64)
+    ap.add_argument("--tgt", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    if a.gpus != world and rank == 0 and world > 1:
+        print(f"[bench] --gpus {a.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+
+    from desta import _hip as H
+    from desta.models.modeling_desta25 import DeSTA25AudioModel, DeSTA25Config
+    from desta.synthetic import FULL_CONFIGS, RandomWeights, synthetic_inputs, synthetic_waveform
+    from desta.trainer.desta_trainer import DeSTA25Trainer, TrainingArguments
+
+    cfg = DeSTA25Config(**FULL_CONFIGS[a.config])
+    t0 = time.time()
+    model = DeSTA25AudioModel(cfg, weights=RandomWeights(cfg, dev, seed=0), device=dev)
+    args = TrainingArguments(learning_rate=1e-4, weight_decay=0.01, warmup_steps=5000, max_steps=10 ** 6, logging_steps=10 ** 9,
+                             overlap_comm=not a.no_overlap)
+    trainer = DeSTA25Trainer(model, args=args)
+    B, S = a.batch, a.ctx + cfg.prompt_size + a.tgt
+    n_mels = cfg.encoder_config.num_mel_bins
+    # two alternating synthetic batches per rank, resident in HBM (seed 1234 + rank)
+    waves = [synthetic_waveform(B, dev, seed=1234 + rank + 97 * i) for i in range(2)]
+    toks = [synthetic_inputs(cfg, B, a.ctx, a.tgt, dev, seed=1234 + rank + 97 * i) for i in range(2)]
+    torch.cuda.synchronize()
+    if rank == 0:
+        print(f"[bench] model built in {time.time() - t0:.1f}s, trainable params {model.arena.true_numel() / 1e6:.2f} M, "
+              f"HBM in use {torch.cuda.memory_allocated() / 2**30:.1f} GiB", file=sys.stderr)
+
+    def batch(i):
+        b = dict(toks[i % 2])
+        b["batch_features"] = H.logmel(waves[i % 2], n_mels)              # A1 runs inside the step
+        return b
+
+    def run(nsteps, start):
+        cur = batch(start)
+        loss = None
+        for i in range(start, start + nsteps):
+            nxt = batch(i + 1)
+            loss = trainer.training_step(cur, nxt)
+            cur = nxt
+        trainer.wait_update()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(a.warmup, 0)
+    fence()
+    H.gemm_profile_start()
+    t0 = time.perf_counter()
+    loss = run(a.steps, a.warmup)
+    fence()
+    elapsed = time.perf_counter() - t0
+    n_launch, flops, gemm_ms = H.gemm_profile_stop()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    final_loss = float(loss)
+
+    if rank == 0:
+        achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        out = {
+            "metric": "train steps/sec (node) Whisper-v3+Llama3.1-8B Q-Former6L at 1/2/4/8 MI355X",
+            "value": world * a.steps / elapsed, "unit": "steps/s (per-GPU batches of 8 clips, summed over GPUs)",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{a.config}: whisper-large-v3 + Llama-3.1-8B, Q-Former 6L, per-GPU batch {B} x 30 s clips, "
+                                   f"S={S} ({a.ctx} ctx + {cfg.prompt_size} audio + {a.tgt} target tokens), random-init weights at true shapes",
+                       "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}"},
+            "final_loss": final_loss,
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                         "launches_per_step": n_launch / a.steps, "avg_launch_us": 1e3 * gemm_ms / max(n_launch, 1),
+                         "flop_per_launch": flops / max(n_launch, 1), "gemm_ms_per_step": gemm_ms / a.steps},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            try:
+                threads = min(len(os.sched_getaffinity(0)), 64)
+                out["cpu_baseline"] = cpu_baseline(cfg, B, a.ctx, a.tgt, threads)
+            except Exception as ex:                                   # noqa: BLE001
+                out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": 0, "kind": "port", "sample": f"failed: {ex}"}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

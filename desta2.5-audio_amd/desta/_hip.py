@@ -84,8 +84,33 @@ def gemm(A, B, out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, residua
     d.ldp = N if ldp is None else ldp
     d.stride_p = stride_p
     d.alpha = alpha
+    if _gemm_prof is not None:
+        # HIP events on the launch stream around this one kernel (bench.py roofline leg)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_gemm(C.byref(d), stream()), "desta_gemm_bf16_nt")
+        e1.record()
+        _gemm_prof.append((e0, e1, 2.0 * M * N * K * batch))
+        return out
     check(_gemm(C.byref(d), stream()), "desta_gemm_bf16_nt")
     return out
+
+
+_gemm_prof = None
+
+
+def gemm_profile_start():
+    global _gemm_prof
+    _gemm_prof = []
+
+
+def gemm_profile_stop():
+    """-> (n_launches, total_flops, total_ms) of the GEMM launches since gemm_profile_start()."""
+    global _gemm_prof
+    rec, _gemm_prof = _gemm_prof, None
+    torch.cuda.synchronize()
+    ms = sum(a.elapsed_time(b) for a, b, _ in rec)
+    return len(rec), sum(f for _, _, f in rec), ms
 
 
 # ----------------------------------------------------------------------------- log-mel

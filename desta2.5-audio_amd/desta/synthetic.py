@@ -1,0 +1,126 @@
+"""Seeded synthetic weights / batches at TRUE shapes, generated directly in HBM.
+
+There are no checkpoints or datasets offline: benchmarks and full-size property tests use
+random-init weights of the named architecture and synthetic 30 s clips + token batches in the collate
+layout (simple_dataset.py:248-264)."""
+from __future__ import annotations
+
+import math
+import re
+from typing import Dict
+
+import torch
+
+from .models.modeling_desta25 import CON, ENC, LLM, DeSTA25Config, connector_param_shapes
+
+
+class RandomWeights:
+    """Lazy `{name: tensor}` mapping: every tensor is generated on `device` when first asked for and not
+    kept, so building an 8 B-parameter model never holds a second copy (frozen weights in bf16)."""
+
+    def __init__(self, cfg: DeSTA25Config, device, seed: int = 0, with_connector: bool = False):
+        self.cfg, self.device, self.seed = cfg, torch.device(device), seed
+        self._connector = connector_param_shapes(cfg) if with_connector else {}
+        self._gen = torch.Generator(device=self.device)
+
+    def __contains__(self, name: str) -> bool:
+        return name in self._connector
+
+    def _shape(self, name: str):
+        e, c = self.cfg.encoder_config, self.cfg.llm_config
+        d, f = e.d_model, e.encoder_ffn_dim
+        if name.startswith(ENC):
+            n = name[len(ENC):]
+            if n == "conv1.weight": return (d, e.num_mel_bins, 3)
+            if n == "conv2.weight": return (d, d, 3)
+            if n in ("conv1.bias", "conv2.bias"): return (d,)
+            if n == "embed_positions.weight": return (e.max_source_positions, d)
+            if "fc1.weight" in n: return (f, d)
+            if "fc1.bias" in n: return (f,)
+            if "fc2.weight" in n: return (d, f)
+            if n.endswith("proj.weight"): return (d, d)
+            return (d,)
+        if name.startswith(LLM):
+            n = name[len(LLM):]
+            h, I, hd = c.hidden_size, c.intermediate_size, c.head_dim
+            if n in ("model.embed_tokens.weight", "lm_head.weight"): return (c.vocab_size, h)
+            if "q_proj" in n: return (c.num_attention_heads * hd, h)
+            if "k_proj" in n or "v_proj" in n: return (c.num_key_value_heads * hd, h)
+            if "o_proj" in n: return (h, c.num_attention_heads * hd)
+            if "gate_proj" in n or "up_proj" in n: return (I, h)
+            if "down_proj" in n: return (h, I)
+            if "q_norm" in n or "k_norm" in n: return (hd,)
+            return (h,)
+        return self._connector[name]
+
+    def __getitem__(self, name: str) -> torch.Tensor:
+        shape = self._shape(name)
+        g = self._gen
+        g.manual_seed((self.seed * 1000003 + (hash_name(name) % 1000003)) & 0x7FFFFFFF)
+        is_norm = ("layer_norm" in name or "layernorm" in name or name.endswith("norm.weight") or "LayerNorm" in name or ".proj.0." in name)
+        if is_norm:
+            if name.endswith("bias"):
+                return 0.02 * torch.randn(shape, generator=g, device=self.device)
+            return 1.0 + 0.02 * torch.randn(shape, generator=g, device=self.device)
+        if name.endswith("bias"):
+            return 0.02 * torch.randn(shape, generator=g, device=self.device)
+        if "embed_positions" in name or "embed_tokens" in name:
+            return (0.02 * torch.randn(shape, generator=g, device=self.device, dtype=torch.float32)).to(torch.bfloat16)
+        if "layer_prompts" in name:
+            return torch.randn(shape, generator=g, device=self.device)
+        if "layer_weights" in name:
+            return torch.zeros(shape, device=self.device)
+        fan_in = int(math.prod(shape[1:]))
+        w = torch.empty(shape, device=self.device, dtype=torch.bfloat16 if not name.startswith(CON) else torch.float32)
+        w.uniform_(-1.0, 1.0, generator=g)
+        return w * (1.0 / math.sqrt(fan_in))
+
+
+def hash_name(name: str) -> int:
+    h = 2166136261
+    for ch in name.encode():
+        h = ((h ^ ch) * 16777619) & 0xFFFFFFFF
+    return h
+
+
+def synthetic_inputs(cfg: DeSTA25Config, B: int, S_ctx: int, S_tgt: int, device, seed: int = 1234) -> Dict:
+    """Token side of a collated batch on `device`: context ‖ prompt_size placeholders ‖ targets, no
+    padding, labels -100 on the first S_ctx + prompt_size positions."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    K, V = cfg.prompt_size, cfg.llm_config.vocab_size
+    S = S_ctx + K + S_tgt
+    ids = torch.randint(3, V, (B, S), generator=g, device=device)
+    labels = torch.full((B, S), -100, dtype=torch.long, device=device)
+    labels[:, S_ctx + K:] = ids[:, S_ctx + K:]
+    return {"input_ids": ids, "attention_mask": torch.ones(B, S, dtype=torch.long, device=device), "labels": labels,
+            "batch_start_positions": [(b, S_ctx) for b in range(B)],
+            "batch_transcription_ids": [torch.zeros(1, 0, dtype=torch.long, device=device) for _ in range(B)]}
+
+
+def synthetic_waveform(B: int, device, seed: int = 1234, n: int = 480000) -> torch.Tensor:
+    g = torch.Generator(device=device).manual_seed(seed)
+    return (0.1 * torch.randn(B, n, generator=g, device=device)).clamp_(-1.0, 1.0)
+
+
+FULL_CONFIGS = {
+    # BASELINE.json configs[1]/[2]: Whisper-large-v3 + Llama-3.1-8B, Q-Former 6L (Appendix B dims)
+    "desta25_llama31-8B_Qformer6L": dict(
+        llm_model_id="DeSTA-ntu/Llama-3.1-8B-Instruct", encoder_model_id="openai/whisper-large-v3",
+        qformer_num_hidden_layers=6, prompt_size=64,
+        llm_config=dict(model_type="llama", hidden_size=4096, num_hidden_layers=32, num_attention_heads=32,
+                        num_key_value_heads=8, head_dim=128, intermediate_size=14336, vocab_size=128256,
+                        rms_norm_eps=1e-5, rope_theta=500000.0,
+                        rope_scaling={"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0,
+                                      "high_freq_factor": 4.0, "original_max_position_embeddings": 8192}),
+        encoder_config=dict(num_mel_bins=128, d_model=1280, encoder_layers=32, encoder_attention_heads=20,
+                            encoder_ffn_dim=5120, max_source_positions=1500)),
+    # configs[4]: Qwen3-8B backbone
+    "desta25_qwen3-8B_Qformer6L": dict(
+        llm_model_id="Qwen/Qwen3-8B", encoder_model_id="openai/whisper-large-v3",
+        qformer_num_hidden_layers=6, prompt_size=64, placeholder_token="<|video_pad|>",
+        llm_config=dict(model_type="qwen3", hidden_size=4096, num_hidden_layers=36, num_attention_heads=32,
+                        num_key_value_heads=8, head_dim=128, intermediate_size=12288, vocab_size=151936,
+                        rms_norm_eps=1e-6, rope_theta=1000000.0),
+        encoder_config=dict(num_mel_bins=128, d_model=1280, encoder_layers=32, encoder_attention_heads=20,
+                            encoder_ffn_dim=5120, max_source_positions=1500)),
+}

@@ -36,8 +36,16 @@ def test_forward_backward_vs_reference_golden(golden_dir, name):
     assert e_logits < 3e-2, e_logits
     model.backward()
     errs = {}
+    # relative L2 error per tensor; tensors whose true gradient is (numerically) zero — the key biases:
+    # softmax is invariant to a per-query constant — are measured against the typical gradient norm
+    gn = sorted(float(g["grad::" + n].double().norm()) for n in model.trainable_parameter_names)
+    floor = gn[len(gn) // 2] * 1e-2
     for n in model.trainable_parameter_names:
-        errs[n] = rel_err(model.arena.grad(n), g["grad::" + n])
+        ref = g["grad::" + n].double()
+        got = model.arena.grad(n).double().cpu()
+        errs[n] = float((got - ref).norm() / max(float(ref.norm()), floor))
+    for n in sorted(errs, key=errs.get)[-6:]:
+        print(f"   grad err {errs[n]:.4f}  {n}")
     worst = max(errs, key=errs.get)
     print("loss", loss, float(g["loss"]), "logits", e_logits, "af", e_af, "worst grad", worst, errs[worst])
     assert errs[worst] < 8e-2, (worst, errs[worst])
