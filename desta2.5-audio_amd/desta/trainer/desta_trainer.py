@@ -43,6 +43,18 @@ class TrainingArguments:
     overlap_comm: bool = True
 
 
+def allreduce_mean_(flat: torch.Tensor) -> None:
+    """Mean over data-parallel ranks of ONE flat buffer (what DDP's bucketed reducer does for the
+    reference, accelerate `accelerator.py:1892`): RCCL AVG over xGMI on GPUs, SUM + scale on gloo."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    if dist.get_backend() == "nccl":
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.mul_(1.0 / dist.get_world_size())
+
+
 class DeSTA25Trainer:
     def __init__(self, model: DeSTA25AudioModel, cfg: Any = None, args: Optional[TrainingArguments] = None,
                  train_dataset=None, eval_dataset=None, data_collator=None, processing_class=None, **kwargs):
@@ -99,13 +111,7 @@ class DeSTA25Trainer:
     # -- one optimizer step ----------------------------------------------------------------------
     def _reduce_and_update(self, lr: float) -> None:
         arena = self.model.arena
-        if self.world > 1:
-            backend = dist.get_backend()
-            if backend == "nccl":
-                dist.all_reduce(arena.grads, op=dist.ReduceOp.AVG)          # RCCL over xGMI, one flat buffer
-            else:
-                dist.all_reduce(arena.grads, op=dist.ReduceOp.SUM)
-                arena.grads.mul_(1.0 / self.world)
+        allreduce_mean_(arena.grads)                                          # one flat buffer, no buckets
         self.optimizer.step(lr)
         self.model.connector.refresh_weights()
 

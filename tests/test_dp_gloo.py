@@ -1,0 +1,76 @@
+"""N>1 path on CPU: world_size-2 `gloo` processes exercise the data-parallel exchange of the flat
+gradient arena (mean over ranks of per-rank token-mean gradients, hazard H8) and check it against a
+single process that sees both micro-batches.  The HIP optimizer itself is covered by the -m gpu tests;
+here the arena lives on CPU and the oracle supplies the per-rank gradients."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "desta2.5-audio_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import desta_oracle as O
+    from helpers import cfg_from_dims
+    from desta.models.modeling_desta25 import connector_param_shapes
+    from desta.optim import ParamArena
+    from desta.trainer.desta_trainer import allreduce_mean_
+    torch.set_num_threads(2)
+    d = O.tiny_dims(False)
+    w = O.init_weights(d, seed=7)
+    arena = ParamArena(list(connector_param_shapes(cfg_from_dims(d)).items()), "cpu")
+    batch = O.synthetic_batch(d, B=1, S_ctx=4, S_tgt=8 + 4 * rank, seed=50 + rank)     # ragged target lengths per rank
+    names = O.trainable_names(d)
+    for n in names:
+        w[n].requires_grad_(True)
+    loss, _ = O.model_forward(w, d, batch)
+    loss.backward()
+    for n in names:
+        arena.grad(n).copy_(w[n].grad)
+    allreduce_mean_(arena.grads)
+    q.put((rank, float(loss), arena.grads.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_mean_matches_single_process():
+    world, port = 2, 29500 + os.getpid() % 2000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert torch.equal(res[0][2], res[1][2]), "ranks disagree after the all-reduce"
+    # single process: mean over ranks of the per-rank gradients
+    for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "desta2.5-audio_amd")):
+        sys.path.insert(0, p)
+    import desta_oracle as O
+    from helpers import cfg_from_dims
+    from desta.models.modeling_desta25 import connector_param_shapes
+    from desta.optim import ParamArena
+    d = O.tiny_dims(False)
+    ref = ParamArena(list(connector_param_shapes(cfg_from_dims(d)).items()), "cpu")
+    for rank in range(world):
+        w = O.init_weights(d, seed=7)
+        names = O.trainable_names(d)
+        for n in names:
+            w[n].requires_grad_(True)
+        batch = O.synthetic_batch(d, B=1, S_ctx=4, S_tgt=8 + 4 * rank, seed=50 + rank)
+        loss, _ = O.model_forward(w, d, batch)
+        assert abs(float(loss) - res[rank][1]) < 1e-6
+        loss.backward()
+        for n in names:
+            ref.grad(n).add_(w[n].grad / world)
+    torch.testing.assert_close(res[0][2], ref.grads, rtol=1e-6, atol=1e-8)
