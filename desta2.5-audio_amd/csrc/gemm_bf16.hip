@@ -16,6 +16,7 @@
 // row and stores them as one 8-B (bf16) / 16-B (f32) access.
 #include "common.h"
 #include "desta_hip.h"
+#include <math.h>
 
 namespace {
 
@@ -34,11 +35,52 @@ struct GemmArgs {
     bf16_t* preact; long ldp; long sP;                  // optional copy of (acc+bias) before act
     float alpha;                                        // scales the accumulator before bias
     int tilesM, tilesN;
+    int full_tiles, split;                              // 256-kernel: tiles [0,full) whole-K; the rest in `split` K-slices
+    float* ws;                                          // fp32 partial slabs [(tile-full)*split + slice][256][256]
 };
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// epilogue for 4 consecutive N outputs of row m: alpha, bias, pre-activation copy, GELU, residual, store
+__device__ __forceinline__ void epilogue4(const GemmArgs& p, int z, int m, int n0, const f32x4& a) {
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = a[e] * p.alpha;
+    if (p.bias) {
+        const float4 b = *(const float4*)(p.bias + n0);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if (p.preact) {
+        u16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+        *(u16x4*)(p.preact + (long)z * p.sP + (long)m * p.ldp + n0) = o;
+    }
+    if (p.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+    }
+    if (p.res) {
+        if (p.res_f32) {
+            const float4 r = *(const float4*)((const float*)p.res + (long)z * p.sR + (long)m * p.ldr + n0);
+            v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+        } else {
+            const u16x4 r = *(const u16x4*)((const bf16_t*)p.res + (long)z * p.sR + (long)m * p.ldr + n0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += bf2f(r[e]);
+        }
+    }
+    if (p.out_f32) {
+        *(float4*)((float*)p.C + (long)z * p.sC + (long)m * p.ldc + n0) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        u16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+        *(u16x4*)((bf16_t*)p.C + (long)z * p.sC + (long)m * p.ldc + n0) = o;
+    }
 }
 
 __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs p) {
@@ -129,7 +171,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs p) {
     }
 
     // epilogue: lane holds C[m][n0..n0+3], m = ..+fr, n0 = ..+fq*4
-    const long zc = (long)z * p.sC;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = brow + wr * 64 + i * 16 + fr;
@@ -138,46 +179,244 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs p) {
         for (int j = 0; j < 4; ++j) {
             const int n0 = bcol + wc * 64 + j * 16 + fq * 4;
             if (n0 >= p.N) continue;
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * p.alpha;
-            if (p.bias) {
-                const float4 b = *(const float4*)(p.bias + n0);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-            }
-            if (p.preact) {
-                u16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-                *(u16x4*)(p.preact + (long)z * p.sP + (long)m * p.ldp + n0) = o;
-            }
-            if (p.act == 1) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-            }
-            if (p.res) {
-                if (p.res_f32) {
-                    const float4 r = *(const float4*)((const float*)p.res + (long)z * p.sR + (long)m * p.ldr + n0);
-                    v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-                } else {
-                    const u16x4 r = *(const u16x4*)((const bf16_t*)p.res + (long)z * p.sR + (long)m * p.ldr + n0);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += bf2f(r[e]);
-                }
-            }
-            if (p.out_f32) {
-                *(float4*)((float*)p.C + zc + (long)m * p.ldc + n0) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                u16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-                *(u16x4*)((bf16_t*)p.C + zc + (long)m * p.ldc + n0) = o;
-            }
+            epilogue4(p, z, m, n0, acc[i][j]);
         }
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// 256x256x64 tile, 8 waves (2M x 4N, 128x64 per wave), 4 phases per K-tile, one 16-KiB half-tile staged
+// per phase by LDS-DMA, five half-tiles (80 KiB) in flight behind a COUNTED s_waitcnt vmcnt(10) and raw
+// s_barriers (never vmcnt(0) in the loop).  LDS = 2 buffers x {A0, A1, B0, B1} x 16 KiB = 128 KiB.
+//   A-half s = rows {wm*128 + s*64 + r}, B-half s = cols {wn*64 + s*32 + c}: a half is what ONE phase
+//   reads, so its slot is dead (re-stageable) one phase later:
+//     P1 reads A0,B0 -> Q00 | P2 reads B1 -> Q01 | P3 reads A1 -> Q11 | P4 (B0 kept in VGPRs) -> Q10
+//   stream order of half-tiles S = (A0,B0,B1,A1)(t), t = 0,1,2..; global phase g issues S[g+7] and, before
+//   its closing barrier, waits until all but the 5 youngest half-tiles (2 LDS-DMA each per wave) landed:
+//   exactly what phase g+1 reads.  Past the last K-tile the stream re-loads the last tile into dead
+//   slots so the count stays constant.
+constexpr int HT = 128 * BK * 2;                         // half-tile bytes (128 rows x 128 B)
+
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * 4 * HT];            // [buf][A0,A1,B0,B1]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    // work item -> (tile, K-slice): the first `full_tiles` items are whole tiles; the remainder of the
+    // tile grid (the tail round that would leave CUs idle) is cut into `split` K-slices per tile
+    int L, slice = 0;
+    if ((int)blockIdx.x < p.full_tiles) {
+        L = xcd_remap(blockIdx.x, p.full_tiles);
+    } else {
+        const int j = blockIdx.x - p.full_tiles;
+        L = p.full_tiles + j / p.split;
+        slice = j % p.split;
+    }
+    constexpr int GROUP_M = 4;
+    const int gspan = GROUP_M * p.tilesN;
+    const int first_m = (L / gspan) * GROUP_M;
+    const int gsz = min(p.tilesM - first_m, GROUP_M);
+    const int tm = first_m + (L % gspan) % gsz;
+    const int tn = (L % gspan) / gsz;
+    const int brow = tm * 256, bcol = tn * 256;
+    const int z = blockIdx.y;
+    const bf16_t* A = p.A + (long)z * p.sA;
+    const bf16_t* B = p.B + (long)z * p.sB;
+
+    // staging sources: this thread's two 16-B chunks of each of the four half-tile kinds
+    const bf16_t* src[4][2];                              // [A0, A1, B0, B1][i]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = i * 512 + tid;
+        const int r = idx >> 3, pc = idx & 7;
+        const int c = pc ^ (r & 7);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int arow = (r >> 6) * 128 + s2 * 64 + (r & 63);
+            const int bcolr = (r >> 5) * 64 + s2 * 32 + (r & 31);
+            src[s2][i] = A + (long)min(brow + arow, p.M - 1) * p.lda + c * 8;
+            src[2 + s2][i] = B + (long)min(bcol + bcolr, p.N - 1) * p.ldb + c * 8;
+        }
+    }
+    const int nk_all = p.K / BK;
+    const bool partial = (int)blockIdx.x >= p.full_tiles && p.split > 1;
+    const int kt0 = partial ? (int)((long)nk_all * slice / p.split) : 0;
+    const int kt1 = partial ? (int)((long)nk_all * (slice + 1) / p.split) : nk_all;
+    const int nk = kt1 - kt0;
+    // issue half-tile number j of the stream
+    auto stage = [&](int j) {
+        const int t = j >> 2, q = j & 3;                  // q: 0 A0, 1 B0, 2 B1, 3 A1
+        const int kind = (q == 0) ? 0 : (q == 1) ? 2 : (q == 2) ? 3 : 1;
+        const long koff = (long)(kt0 + min(t, nk - 1)) * BK;
+        char* dst = lds + ((t & 1) * 4 + kind) * HT;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            glds16(src[kind][i] + koff, dst + (i * 512 + wave * 64) * 16);
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    int offA[4], offB[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = wm * 64 + i * 16 + fr;
+        offA[i] = r * 128 + ((fq ^ (r & 7)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = wn * 32 + i * 16 + fr;
+        offB[i] = r * 128 + ((fq ^ (r & 7)) << 4);
+    }
+
+#pragma unroll
+    for (int j = 0; j < 7; ++j) stage(j);
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    bf16x8 a[4][2], b0[2][2], b1[2][2];
+    for (int t = 0; t < nk; ++t) {
+        const char* base = lds + (t & 1) * 4 * HT;
+        const char* A0 = base, *A1 = base + HT, *B0 = base + 2 * HT, *B1 = base + 3 * HT;
+        const int g = 4 * t;
+        // ---------------- P1: A0, B0 -> Q00
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) b0[i][kk] = *(const bf16x8*)(B0 + (offB[i] ^ (kk << 6)));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) a[i][kk] = *(const bf16x8*)(A0 + (offA[i] ^ (kk << 6)));
+        stage(g + 7);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j][kk], a[i][kk], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ---------------- P2: B1 -> Q01
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) b1[i][kk] = *(const bf16x8*)(B1 + (offB[i] ^ (kk << 6)));
+        stage(g + 8);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j][kk], a[i][kk], acc[i][2 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ---------------- P3: A1 -> Q11
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) a[i][kk] = *(const bf16x8*)(A1 + (offA[i] ^ (kk << 6)));
+        stage(g + 9);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j][kk], a[i][kk], acc[4 + i][2 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---------------- P4: (B0 in registers) -> Q10
+        stage(g + 10);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j][kk], a[i][kk], acc[4 + i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the dummy tail loads before LDS is released
+
+    if (partial) {
+        // raw fp32 accumulators -> this item's slab; the fix-up kernel sums the slices in order
+        float* slab = p.ws + ((long)z * (p.tilesM * p.tilesN - p.full_tiles) * p.split +
+                              (long)(blockIdx.x - p.full_tiles)) * (256 * 256);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *(f32x4*)(slab + (wm * 128 + i * 16 + fr) * 256 + wn * 64 + j * 16 + fq * 4) = acc[i][j];
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = brow + wm * 128 + i * 16 + fr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n0 = bcol + wn * 64 + j * 16 + fq * 4;
+            if (n0 >= p.N) continue;
+            epilogue4(p, z, m, n0, acc[i][j]);
+        }
+    }
+}
+
+// sum the K-slice slabs of the split tiles (fixed order) and run the normal epilogue
+__global__ __launch_bounds__(256) void gemm_splitk_fixup_kernel(GemmArgs p) {
+    const int rem = p.tilesM * p.tilesN - p.full_tiles;
+    const int ti = blockIdx.x / 64, part = blockIdx.x % 64;          // 64 blocks per tile: 4 rows x 256 cols each
+    const int z = blockIdx.y;
+    const int L = p.full_tiles + ti;
+    constexpr int GROUP_M = 4;
+    const int gspan = GROUP_M * p.tilesN;
+    const int first_m = (L / gspan) * GROUP_M;
+    const int gsz = min(p.tilesM - first_m, GROUP_M);
+    const int tm = first_m + (L % gspan) % gsz;
+    const int tn = (L % gspan) / gsz;
+    const int ml = part * 4 + (threadIdx.x >> 6), nl = (threadIdx.x & 63) * 4;
+    const float* slab = p.ws + ((long)z * rem + ti) * p.split * (256 * 256) + ml * 256 + nl;
+    f32x4 acc = *(const f32x4*)slab;
+    for (int s2 = 1; s2 < p.split; ++s2) {
+        const f32x4 v = *(const f32x4*)(slab + (long)s2 * (256 * 256));
+        acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+    }
+    const int m = tm * 256 + ml, n0 = tn * 256 + nl;
+    if (m < p.M && n0 < p.N) epilogue4(p, z, m, n0, acc);
+}
+
 }  // namespace
+
+static int g_force_variant = 0;   // 0 auto, 1 = 128x128, 2 = 256x256 (tuning / tests)
+extern "C" int desta_gemm_force_variant(int v) { g_force_variant = v; return DESTA_OK; }
 
 extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
     DESTA_CHECK_ARG(d && d->A && d->B && d->C, "gemm: null operand");
@@ -200,9 +439,46 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
     a.act = d->act; a.out_f32 = d->out_f32;
     a.preact = (bf16_t*)d->preact; a.ldp = d->ldp; a.sP = d->stride_p;
     a.alpha = d->alpha;
-    a.tilesM = (d->M + BM - 1) / BM; a.tilesN = (d->N + BN - 1) / BN;
-    dim3 grid(a.tilesM * a.tilesN, d->batch);
-    hipLaunchKernelGGL(gemm_bf16_nt_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    // Tile choice.  The 256x256 8-phase kernel runs ONE block per CU, so the tile grid executes in rounds
+    // of 256; a partial last round leaves CUs idle (M=5120 x N=4096: 320 tiles = 1.25 rounds).  Those tail
+    // tiles are cut into `split` K-slices (<= 256 items, each 1/split long: "1 + 1/split" rounds instead
+    // of 2), partial sums go to the caller's workspace and a fix-up launch reduces them in fixed order.
+    // The 128x128 kernel (2 blocks/CU) covers small shapes and calls without a workspace.
+    constexpr int NCU = 256;
+    const int tM = (d->M + 255) / 256, tN = (d->N + 255) / 256, nk = d->K / BK;
+    const long T = (long)tM * tN;
+    int split = 1, full = (int)T;
+    if (d->batch == 1 && d->workspace && nk >= 8) {
+        const int rem = (int)(T % NCU);
+        if (rem > 0 && rem <= NCU / 2) {
+            int sp = NCU / rem;
+            if (sp > 8) sp = 8;
+            if (sp > nk / 16) sp = nk / 16;              // >= 16 K-tiles per slice, or the 7-half-tile prologue dominates
+            if (sp >= 2 && (size_t)rem * sp * 256 * 256 * sizeof(float) <= d->workspace_bytes) { split = sp; full = (int)(T - rem); }
+        }
+    }
+    bool big = false;
+    if (d->M >= 128 && d->N >= 128 && d->K >= 512) {
+        const double rounds = (double)full * d->batch / NCU + (split > 1 ? 1.0 / split : 0.0);
+        const double ideal = (double)T * d->batch / NCU;
+        const double eff = ideal / (split > 1 ? rounds : ceil(rounds));      // fraction of CU-time doing work
+        big = eff >= 0.78;
+    }
+    if (g_force_variant == 1) big = false;
+    if (g_force_variant == 2) big = true;
+    if (big) {
+        a.tilesM = tM; a.tilesN = tN;
+        a.full_tiles = full; a.split = split; a.ws = (float*)d->workspace;
+        const int items = full + (int)(T - full) * split;
+        hipLaunchKernelGGL(gemm_bf16_nt_256_kernel, dim3(items, d->batch), dim3(512), 0, (hipStream_t)stream, a);
+        if (split > 1)
+            hipLaunchKernelGGL(gemm_splitk_fixup_kernel, dim3((unsigned)(T - full) * 64, d->batch), dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        a.tilesM = (d->M + BM - 1) / BM; a.tilesN = (d->N + BN - 1) / BN;
+        a.full_tiles = a.tilesM * a.tilesN; a.split = 1; a.ws = nullptr;
+        dim3 grid(a.tilesM * a.tilesN, d->batch);
+        hipLaunchKernelGGL(gemm_bf16_nt_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    }
     DESTA_CHECK_LAUNCH("gemm_bf16_nt");
     return DESTA_OK;
 }

@@ -31,7 +31,8 @@ class GemmDesc(C.Structure):
                 ("stride_a", i64), ("stride_b", i64), ("stride_c", i64),
                 ("bias", vp), ("residual", vp), ("ldr", i64), ("stride_r", i64), ("residual_f32", i32),
                 ("act", i32), ("out_f32", i32),
-                ("preact", vp), ("ldp", i64), ("stride_p", i64), ("alpha", f32)]
+                ("preact", vp), ("ldp", i64), ("stride_p", i64), ("alpha", f32),
+                ("workspace", vp), ("workspace_bytes", C.c_size_t)]
 
 
 lib.desta_abi_version.restype = i32
@@ -84,6 +85,10 @@ def gemm(A, B, out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, residua
     d.ldp = N if ldp is None else ldp
     d.stride_p = stride_p
     d.alpha = alpha
+    ws = _gemm_ws.get(A.device)
+    if ws is None:
+        ws = _gemm_ws[A.device] = torch.empty(GEMM_WS_BYTES // 4, dtype=torch.float32, device=A.device)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), GEMM_WS_BYTES
     if _gemm_prof is not None:
         # HIP events on the launch stream around this one kernel (bench.py roofline leg)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -97,6 +102,8 @@ def gemm(A, B, out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, residua
 
 
 _gemm_prof = None
+_gemm_ws = {}                      # per-device split-K scratch (GEMMs of one stream run serially)
+GEMM_WS_BYTES = 64 << 20
 
 
 def gemm_profile_start():
@@ -370,3 +377,9 @@ def prompt_expand(prompts, taps, batch, n, x32, x16):
 
 def prompt_grad(dx, taps, batch, n, dprompts):
     check(_prompt_grad(p(dx), taps, batch, n, p(dprompts), stream()), "desta_prompt_grad")
+
+
+def gemm_force_variant(v: int) -> None:
+    """Tuning / tests: 0 = automatic tile choice, 1 = 128x128 kernel, 2 = 256x256 8-phase kernel."""
+    lib.desta_gemm_force_variant.argtypes = [i32]
+    lib.desta_gemm_force_variant(v)

@@ -56,8 +56,12 @@ typedef struct desta_gemm_desc {
     void* preact;                      /* optional bf16 [M,N] */
     int64_t ldp, stride_p;
     float alpha;
+    void* workspace;                   /* optional fp32 scratch for the split-K tail (NULL = never split);   */
+    size_t workspace_bytes;            /* 64 MiB covers every shape (<= 256 slabs of 256x256 fp32)            */
 } desta_gemm_desc;
 int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream);
+/* tuning / tests only: 0 = automatic tile choice, 1 = force 128x128, 2 = force the 256x256 8-phase kernel */
+int desta_gemm_force_variant(int variant);
 
 /* ------------------------------------------------------------------------------------------
  * Global-norm clip + Adafactor over a flat fp32 arena.

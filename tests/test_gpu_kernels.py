@@ -35,6 +35,46 @@ def test_gemm_plain(hip, M, N, K):
     torch.testing.assert_close(outb.float(), ref, rtol=1e-2, atol=1e-2 * math.sqrt(K))
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 512), (512, 768, 1024), (300, 520, 576), (1500, 1280, 1280), (257, 260, 640),
+                                   (2560, 1280, 4096), (5120, 4096, 512)])
+def test_gemm_256_tile_variant(hip, M, N, K):
+    """The 256x256 8-phase kernel (forced), incl. ragged M/N edges and K tails shorter than the prefetch depth."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = _bf(torch.randn(M, K, generator=g)).cuda()
+    B = _bf(torch.randn(N, K, generator=g)).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    res = _bf(torch.randn(M, N, generator=g)).cuda()
+    ref = A.float() @ B.float().T
+    try:
+        hip.gemm_force_variant(2)
+        out = torch.empty(M, N, dtype=torch.float32, device="cuda")
+        hip.gemm(A, B, out, M, N, K)
+        torch.testing.assert_close(out, ref, rtol=1e-4, atol=2e-3)
+        outb = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        hip.gemm(A, B, outb, M, N, K, bias=bias, residual=res, act=1)
+        hip.gemm_force_variant(1)
+        outb1 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        hip.gemm(A, B, outb1, M, N, K, bias=bias, residual=res, act=1)
+        # same fp32 accumulation order unless the tail tiles were K-split: allow one bf16 ulp
+        torch.testing.assert_close(outb.float(), outb1.float(), rtol=8e-3, atol=8e-3)
+    finally:
+        hip.gemm_force_variant(0)
+
+
+def test_gemm_256_identity_and_k64(hip):
+    K = 64                                        # a single K-tile: the whole loop is prologue + dummy tail loads
+    A = _bf(torch.eye(256)[:, :K]).cuda()
+    B = _bf(torch.arange(512 * K).reshape(512, K).float() % 251 - 100).cuda()
+    out = torch.empty(256, 512, dtype=torch.float32, device="cuda")
+    try:
+        hip.gemm_force_variant(2)
+        hip.gemm(A, B, out, 256, 512, K)
+    finally:
+        hip.gemm_force_variant(0)
+    ref = A.float() @ B.float().T
+    torch.testing.assert_close(out, ref, rtol=0, atol=0)
+
+
 def test_gemm_asymmetric_identity(hip):
     """A = I with an asymmetric B catches a swapped C-write or fragment map."""
     K = 128
