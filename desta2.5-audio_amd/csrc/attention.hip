@@ -159,37 +159,45 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
             for (int ds = 0; ds < D / 16; ++ds)
                 st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(kimg, kb * 32, ds, lane), qf[ds], st[kb], 0, 0, 0);
         }
+        // masks only on boundary tiles (wave-uniform): ragged Sk, left padding, causal diagonal
+        const bool need_mask = (kt * 64 + 63 >= p.Sk) || (kt * 64 < kv_lo) || (p.causal && kt * 64 + 63 > q0 + coff);
+        if (need_mask) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * 64 + kb * 32 + acc_row(r, lane);
+                    const bool ok = key < p.Sk && key >= kv_lo && (!p.causal || key <= q_abs);
+                    st[kb][r] = ok ? st[kb][r] : -INFINITY;
+                }
+        }
         float tmax = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * 64 + kb * 32 + acc_row(r, lane);
-                const bool ok = key < p.Sk && key >= kv_lo && (!p.causal || key <= q_abs);
-                const float s = ok ? st[kb][r] * p.scale_log2 : -INFINITY;
-                st[kb][r] = s;
-                tmax = fmaxf(tmax, s);
-            }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, st[kb][r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * p.scale_log2;         // scale > 0: max commutes
         const float mnew = fmaxf(m, tmax);
         const float muse = (mnew == -INFINITY) ? 0.f : mnew;
-        const float alpha = exp2f(m - muse);
+        const float alpha = __builtin_amdgcn_exp2f(m - muse);
         float rs = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = exp2f(st[kb][r] - muse);
+                const float pv = __builtin_amdgcn_exp2f(fmaf(st[kb][r], p.scale_log2, -muse));
                 st[kb][r] = pv;
                 rs += pv;
             }
         rs += __shfl_xor(rs, 32, 64);
         l = l * alpha + rs;
+        if (__any(mnew != m)) {                            // rescale only when some row's max moved
+#pragma unroll
+            for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        }
         m = mnew;
-#pragma unroll
-        for (int i = 0; i < D / 32; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -303,11 +311,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(AttnArgs p) {
                 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(kimg, kb * 32, ds, lane), qf[ds], st, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(vimg, kb * 32, ds, lane), gf[ds], dp, 0, 0, 0);
             }
+            const bool need_mask = (kt * 64 + kb * 32 + 31 >= p.Sk) || (kt * 64 + kb * 32 < kv_lo) ||
+                                   (p.causal && kt * 64 + kb * 32 + 31 > q0 + coff);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = kt * 64 + kb * 32 + acc_row(r, lane);
-                const bool ok = key < p.Sk && key >= kv_lo && (!p.causal || key <= q_abs);
-                const float pv = ok ? exp2f(st[r] * p.scale_log2 - lse) : 0.f;
+                float pv = __builtin_amdgcn_exp2f(fmaf(st[r], p.scale_log2, -lse));
+                if (need_mask) {
+                    const int key = kt * 64 + kb * 32 + acc_row(r, lane);
+                    const bool ok = key < p.Sk && key >= kv_lo && (!p.causal || key <= q_abs);
+                    pv = ok ? pv : 0.f;
+                }
                 st[r] = pv * (dp[r] - dlt) * p.scale;      // dS^T
             }
 #pragma unroll
@@ -401,11 +414,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_k(AttnArgs p) {
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(gimg, 0, ds, lane), vf[ds], dp, 0, 0, 0);
             }
             // st[r]: S[q = qt*32 + acc_row(r)][key = kcol]
+            // masks only on boundary tiles (wave-uniform): ragged Sq/Sk, left padding, causal diagonal
+            const bool need_mask = (qt * 32 + 31 >= p.Sq) || (k0 + 31 >= p.Sk) || (k0 < kv_lo) ||
+                                   (p.causal && k0 + 31 > qt * 32 + coff);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ql = acc_row(r, lane), q = qt * 32 + ql;
-                const bool ok = key_ok && q < p.Sq && (!p.causal || kcol <= q + coff);
-                const float pv = ok ? exp2f(st[r] * p.scale_log2 - lse_s[ql]) : 0.f;
+                const int ql = acc_row(r, lane);
+                float pv = __builtin_amdgcn_exp2f(fmaf(st[r], p.scale_log2, -lse_s[ql]));
+                if (need_mask) {
+                    const int q = qt * 32 + ql;
+                    const bool ok = key_ok && q < p.Sq && (!p.causal || kcol <= q + coff);
+                    pv = ok ? pv : 0.f;
+                }
                 st[r] = pv;                                                  // P
                 dp[r] = pv * (dp[r] - dlt_s[ql]) * p.scale;                  // dS
             }
