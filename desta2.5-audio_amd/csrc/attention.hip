@@ -42,26 +42,38 @@ __device__ __forceinline__ int img_off(int row, int ch) {
     return row * (D * 2) + ((ch ^ sw) << 4);
 }
 
-// global -> registers for a ROWS x D bf16 tile (16-B chunks), rows clamped to [0, max_row]
+// Register stage of a ROWS x D bf16 tile: N = ROWS*D/8/256 16-B chunks per thread held in ONE first-class
+// vector value (ext_vector_type) — an array here ends up in scratch once two stages are alive
+// (hipcc keeps allocas that are conditionally re-loaded inside the unrolled-by-two loop in memory).
+template <int N> struct stage_vec;
+template <> struct stage_vec<1> { typedef __attribute__((ext_vector_type(4))) unsigned type; };
+template <> struct stage_vec<2> { typedef __attribute__((ext_vector_type(8))) unsigned type; };
+template <> struct stage_vec<4> { typedef __attribute__((ext_vector_type(16))) unsigned type; };
+template <int D, int ROWS> using stage_t = typename stage_vec<ROWS * (D / 8) / 256>::type;
+
+// global -> registers (16-B chunks), rows clamped to [0, max_row]
 template <int D, int ROWS>
-__device__ __forceinline__ void tile_load(const bf16_t* base, long rs, int row0, int max_row, uint4* regs) {
+__device__ __forceinline__ stage_t<D, ROWS> tile_load(const bf16_t* base, long rs, int row0, int max_row) {
     constexpr int CH = D / 8, N = ROWS * CH / 256;
+    stage_t<D, ROWS> out;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const int id = i * 256 + threadIdx.x;
         const int r = id / CH, c = id % CH;
         const int gr = min(row0 + r, max_row);
-        regs[i] = *(const uint4*)(base + (long)gr * rs + c * 8);
+        const uint4 v = *(const uint4*)(base + (long)gr * rs + c * 8);
+        out[4 * i + 0] = v.x; out[4 * i + 1] = v.y; out[4 * i + 2] = v.z; out[4 * i + 3] = v.w;
     }
+    return out;
 }
 template <int D, int ROWS>
-__device__ __forceinline__ void tile_store(char* img, const uint4* regs) {
+__device__ __forceinline__ void tile_store(char* img, const stage_t<D, ROWS>& regs) {
     constexpr int CH = D / 8, N = ROWS * CH / 256;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const int id = i * 256 + threadIdx.x;
         const int r = id / CH, c = id % CH;
-        *(uint4*)(img + img_off<D>(r, c)) = regs[i];
+        *(uint4*)(img + img_off<D>(r, c)) = make_uint4(regs[4 * i + 0], regs[4 * i + 1], regs[4 * i + 2], regs[4 * i + 3]);
     }
 }
 
@@ -117,7 +129,7 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
     for (int ds = 0; ds < D / 16; ++ds) qf[ds] = *(const bf16x8*)(qptr + 16 * ds + 8 * h2);
 
     const int coff = p.Sk - p.Sq;
-    const int kv_lo = p.kv_start ? p.kv_start[b] : 0;
+    const int kv_lo = p.kv_start ? max(0, min(p.kv_start[b], p.Sk)) : 0;
     int kv_hi = p.Sk;
     if (p.causal) kv_hi = min(p.Sk, min(qb0 + 127, p.Sq - 1) + coff + 1);
     const int t_lo = kv_lo / 64, t_hi = (kv_hi + 63) / 64;
@@ -134,22 +146,20 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
         for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
     float m = -INFINITY, l = 0.f;
 
-    constexpr int NCH = 64 * (D / 8) / 256;
-    uint4 kr[NCH], vr[NCH];
+    // K/V tiles are register-staged TWO tiles ahead (two register sets, loop unrolled by two through the
+    // `step` lambda): under load an L2/HBM round trip outlasts one tile of MFMA work.
+    constexpr int PF = 2;                                  // prefetch distance in tiles (1 or 2)
+    stage_t<D, 64> kr0 = {}, vr0 = {}, kr1 = {}, vr1 = {};
     if (t_lo < t_hi) {
-        tile_load<D, 64>(kbase, p.k_rs, t_lo * 64, p.Sk - 1, kr);
-        tile_load<D, 64>(vbase, p.v_rs, t_lo * 64, p.Sk - 1, vr);
+        kr0 = tile_load<D, 64>(kbase, p.k_rs, t_lo * 64, p.Sk - 1);
+        vr0 = tile_load<D, 64>(vbase, p.v_rs, t_lo * 64, p.Sk - 1);
     }
-    for (int kt = t_lo; kt < t_hi; ++kt) {
-        __syncthreads();                                   // previous tile's LDS reads are done
-        tile_store<D, 64>(kimg, kr);
-        tile_store<D, 64>(vimg, vr);
-        __syncthreads();
-        if (kt + 1 < t_hi) {
-            tile_load<D, 64>(kbase, p.k_rs, (kt + 1) * 64, p.Sk - 1, kr);
-            tile_load<D, 64>(vbase, p.v_rs, (kt + 1) * 64, p.Sk - 1, vr);
-        }
-        if (kt * 64 > wave_kmax) continue;                 // wave-uniform: nothing visible in this tile
+    if (PF == 2 && t_lo + 1 < t_hi) {
+        kr1 = tile_load<D, 64>(kbase, p.k_rs, (t_lo + 1) * 64, p.Sk - 1);
+        vr1 = tile_load<D, 64>(vbase, p.v_rs, (t_lo + 1) * 64, p.Sk - 1);
+    }
+    auto compute = [&](const int kt) __attribute__((always_inline)) {
+        if (kt * 64 > wave_kmax) return;                   // wave-uniform: nothing visible in this tile
         f32x16 st[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -207,7 +217,30 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
                 for (int i = 0; i < D / 32; ++i)
                     oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(vimg, kb * 32 + 16 * s, i * 32, lane), pb, oacc[i], 0, 0, 0);
             }
+    };
+#define DESTA_KV_STAGE(KT, KR, VR)                                                   \
+    __syncthreads(); /* previous tile's LDS reads are done */                        \
+    asm volatile("; stage " #KR ::: "memory"); /* distinct text: keeps the two halves from being tail-merged */ \
+    tile_store<D, 64>(kimg, KR);                                                     \
+    tile_store<D, 64>(vimg, VR);                                                     \
+    __syncthreads();                                                                 \
+    if ((KT) + PF < t_hi) {                                                          \
+        KR = tile_load<D, 64>(kbase, p.k_rs, ((KT) + PF) * 64, p.Sk - 1);            \
+        VR = tile_load<D, 64>(vbase, p.v_rs, ((KT) + PF) * 64, p.Sk - 1);            \
     }
+    for (int kt = t_lo; kt < t_hi; kt += 2) {
+        DESTA_KV_STAGE(kt, kr0, vr0)
+        compute(kt);
+        if (kt + 1 < t_hi) {
+            if constexpr (PF == 2) {
+                DESTA_KV_STAGE(kt + 1, kr1, vr1)
+            } else {
+                DESTA_KV_STAGE(kt + 1, kr0, vr0)
+            }
+            compute(kt + 1);
+        }
+    }
+#undef DESTA_KV_STAGE
 
     if (qcol < p.Sq) {
         const float inv = l > 0.f ? 1.0f / l : 0.f;
@@ -269,7 +302,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(AttnArgs p) {
     const float lse = p.lse[stat], dlt = p.delta[stat];
 
     const int coff = p.Sk - p.Sq;
-    const int kv_lo = p.kv_start ? p.kv_start[b] : 0;
+    const int kv_lo = p.kv_start ? max(0, min(p.kv_start[b], p.Sk)) : 0;
     int kv_hi = p.Sk;
     if (p.causal) kv_hi = min(p.Sk, min(qb0 + 127, p.Sq - 1) + coff + 1);
     const int t_lo = kv_lo / 64, t_hi = (kv_hi + 63) / 64;
@@ -285,22 +318,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
 
-    constexpr int NCH = 64 * (D / 8) / 256;
-    uint4 kr[NCH], vr[NCH];
+    // K/V tiles are register-staged TWO tiles ahead (two register sets, loop unrolled by two through the
+    // `step` lambda): under load an L2/HBM round trip outlasts one tile of MFMA work.
+    constexpr int PF = 2;                                  // prefetch distance in tiles (1 or 2)
+    stage_t<D, 64> kr0 = {}, vr0 = {}, kr1 = {}, vr1 = {};
     if (t_lo < t_hi) {
-        tile_load<D, 64>(kbase, p.k_rs, t_lo * 64, p.Sk - 1, kr);
-        tile_load<D, 64>(vbase, p.v_rs, t_lo * 64, p.Sk - 1, vr);
+        kr0 = tile_load<D, 64>(kbase, p.k_rs, t_lo * 64, p.Sk - 1);
+        vr0 = tile_load<D, 64>(vbase, p.v_rs, t_lo * 64, p.Sk - 1);
     }
-    for (int kt = t_lo; kt < t_hi; ++kt) {
-        __syncthreads();
-        tile_store<D, 64>(kimg, kr);
-        tile_store<D, 64>(vimg, vr);
-        __syncthreads();
-        if (kt + 1 < t_hi) {
-            tile_load<D, 64>(kbase, p.k_rs, (kt + 1) * 64, p.Sk - 1, kr);
-            tile_load<D, 64>(vbase, p.v_rs, (kt + 1) * 64, p.Sk - 1, vr);
-        }
-        if (kt * 64 > wave_kmax) continue;
+    if (PF == 2 && t_lo + 1 < t_hi) {
+        kr1 = tile_load<D, 64>(kbase, p.k_rs, (t_lo + 1) * 64, p.Sk - 1);
+        vr1 = tile_load<D, 64>(vbase, p.v_rs, (t_lo + 1) * 64, p.Sk - 1);
+    }
+    auto compute = [&](const int kt) __attribute__((always_inline)) {
+        if (kt * 64 > wave_kmax) return;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             f32x16 st, dp;
@@ -331,7 +362,30 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(AttnArgs p) {
                     dq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(kimg, kb * 32 + 16 * s, i * 32, lane), dsf, dq[i], 0, 0, 0);
             }
         }
+    };
+#define DESTA_KV_STAGE(KT, KR, VR)                                                   \
+    __syncthreads(); /* previous tile's LDS reads are done */                        \
+    asm volatile("; stage " #KR ::: "memory"); /* distinct text: keeps the two halves from being tail-merged */ \
+    tile_store<D, 64>(kimg, KR);                                                     \
+    tile_store<D, 64>(vimg, VR);                                                     \
+    __syncthreads();                                                                 \
+    if ((KT) + PF < t_hi) {                                                          \
+        KR = tile_load<D, 64>(kbase, p.k_rs, ((KT) + PF) * 64, p.Sk - 1);            \
+        VR = tile_load<D, 64>(vbase, p.v_rs, ((KT) + PF) * 64, p.Sk - 1);            \
     }
+    for (int kt = t_lo; kt < t_hi; kt += 2) {
+        DESTA_KV_STAGE(kt, kr0, vr0)
+        compute(kt);
+        if (kt + 1 < t_hi) {
+            if constexpr (PF == 2) {
+                DESTA_KV_STAGE(kt + 1, kr1, vr1)
+            } else {
+                DESTA_KV_STAGE(kt + 1, kr0, vr0)
+            }
+            compute(kt + 1);
+        }
+    }
+#undef DESTA_KV_STAGE
     if (qcol < p.Sq) {
         bf16_t* optr = p.dQ + (long)b * p.dq_bs + (long)qcol * p.dq_rs + (long)h * D;
 #pragma unroll
@@ -359,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_k(AttnArgs p) {
     const int kb0 = blockIdx.x * 128, k0 = kb0 + wave * 32;
     const int hk = blockIdx.y, b = blockIdx.z, group = p.Hq / p.Hkv;
     const int kcol = k0 + (lane & 31), kc = min(kcol, p.Sk - 1);
-    const int kv_lo = p.kv_start ? p.kv_start[b] : 0;
+    const int kv_lo = p.kv_start ? max(0, min(p.kv_start[b], p.Sk)) : 0;
     const int coff = p.Sk - p.Sq;
 
     const bf16_t* kptr = p.K + (long)b * p.k_bs + (long)kc * p.k_rs + (long)hk * D;
@@ -381,30 +435,36 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_k(AttnArgs p) {
     // first query row that can see any key of this block
     const int q_first = p.causal ? max(0, kb0 - coff) : 0;
     const int qt_lo = q_first / 32, qt_hi = (p.Sq + 31) / 32;
-    constexpr int NCH = 32 * (D / 8) / 256;
-    uint4 qr[NCH > 0 ? NCH : 1], gr[NCH > 0 ? NCH : 1];
-
-    for (int hh = 0; hh < group; ++hh) {
-        const int h = hk * group + hh;
-        const bf16_t* qbase = p.Q + (long)b * p.q_bs + (long)h * D;
-        const bf16_t* gbase = p.dO + (long)b * p.do_bs + (long)h * D;
-        const long stat0 = ((long)b * p.Hq + h) * p.Sq;
-        for (int qt = qt_lo; qt < qt_hi; ++qt) {
-            __syncthreads();
-            if (NCH > 0) {
-                tile_load<D, 32>(qbase, p.q_rs, qt * 32, p.Sq - 1, qr);
-                tile_load<D, 32>(gbase, p.do_rs, qt * 32, p.Sq - 1, gr);
-                tile_store<D, 32>(qimg, qr);
-                tile_store<D, 32>(gimg, gr);
-            }
-            if (threadIdx.x < 32) {
-                const int q = min(qt * 32 + (int)threadIdx.x, p.Sq - 1);
-                lse_s[threadIdx.x] = p.lse[stat0 + q];
-                dlt_s[threadIdx.x] = p.delta[stat0 + q];
-            }
-            __syncthreads();
+    // (query head of the GQA group, 32-row query slice) flattened into one iteration space; the Q / dO
+    // tiles and their lse / delta rows are register-staged TWO iterations ahead.
+    const int nq = qt_hi - qt_lo, n_it = group * nq;
+    stage_t<D, 32> qr0 = {}, gr0 = {}, qr1 = {}, gr1 = {};
+    float ls0 = 0.f, dl0 = 0.f, ls1 = 0.f, dl1 = 0.f;
+#define DESTA_Q_FETCH(IT, QR, GR, LS, DL)                                                                       \
+    {                                                                                                          \
+        const int h_ = hk * group + (IT) / nq, qt_ = qt_lo + (IT) % nq;                                        \
+        QR = tile_load<D, 32>(p.Q + (long)b * p.q_bs + (long)h_ * D, p.q_rs, qt_ * 32, p.Sq - 1);             \
+        GR = tile_load<D, 32>(p.dO + (long)b * p.do_bs + (long)h_ * D, p.do_rs, qt_ * 32, p.Sq - 1);          \
+        if (threadIdx.x < 32) {                                                                                \
+            const long st_ = ((long)b * p.Hq + h_) * p.Sq + min(qt_ * 32 + (int)threadIdx.x, p.Sq - 1);       \
+            LS = p.lse[st_];                                                                                   \
+            DL = p.delta[st_];                                                                                 \
+        }                                                                                                      \
+    }
+#define DESTA_Q_STAGE(IT, QR, GR, LS, DL)                                                                       \
+    __syncthreads();                                                                                           \
+    asm volatile("; stage " #QR ::: "memory");                                                                 \
+    tile_store<D, 32>(qimg, QR);                                                                               \
+    tile_store<D, 32>(gimg, GR);                                                                               \
+    if (threadIdx.x < 32) { lse_s[threadIdx.x] = LS; dlt_s[threadIdx.x] = DL; }                                \
+    __syncthreads();                                                                                           \
+    if ((IT) + 2 < n_it) DESTA_Q_FETCH((IT) + 2, QR, GR, LS, DL)
+    if (n_it > 0) DESTA_Q_FETCH(0, qr0, gr0, ls0, dl0)
+    if (n_it > 1) DESTA_Q_FETCH(1, qr1, gr1, ls1, dl1)
+    auto compute = [&](const int it) __attribute__((always_inline)) {
+        const int qt = qt_lo + it % nq;
             // wave-uniform skip: under the causal mask this wave's keys are all in the future of this q tile
-            if (p.causal && k0 > qt * 32 + 31 + coff) continue;
+            if (p.causal && k0 > qt * 32 + 31 + coff) return;
             f32x16 st, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
@@ -438,8 +498,17 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_k(AttnArgs p) {
                     dk[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf, frag_tr<D>(qimg, 16 * s, i * 32, lane), dk[i], 0, 0, 0);
                 }
             }
+    };
+    for (int it = 0; it < n_it; it += 2) {
+        DESTA_Q_STAGE(it, qr0, gr0, ls0, dl0)
+        compute(it);
+        if (it + 1 < n_it) {
+            DESTA_Q_STAGE(it + 1, qr1, gr1, ls1, dl1)
+            compute(it + 1);
         }
     }
+#undef DESTA_Q_STAGE
+#undef DESTA_Q_FETCH
     // dk[i][r]: dK[key = k0 + acc_row(r)][d = i*32 + (lane&31)]
     bf16_t* dkp = p.dK + (long)b * p.dk_bs + (long)hk * D;
     bf16_t* dvp = p.dV + (long)b * p.dv_bs + (long)hk * D;

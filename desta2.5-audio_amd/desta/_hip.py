@@ -342,6 +342,7 @@ def attn_desc(q, k, v, o, lse, *, batch, hq, hkv, sq, sk, hd, scale, causal=Fals
     d.causal = int(causal)
     d.kv_start = p(kv_start)
     d.scale = scale
+    d._keep = (q, k, v, o, lse, kv_start)       # the descriptor holds RAW pointers: keep the tensors alive with it
     return d
 
 
@@ -364,6 +365,7 @@ def attention_bwd(d: AttnDesc, do, dq, dk=None, dv=None, *, do_rs=None, dq_off=0
     else:
         d.dK = d.dV = 0
     ws = scratch(lib.desta_attention_bwd_workspace_floats(d.batch, d.n_q_heads, d.seq_q), do.device, "attn")
+    d._keep_bwd = (do, dq, dk, dv, ws)
     check(_attn_bwd(C.byref(d), p(ws), stream()), "desta_attention_bwd")
 
 

@@ -352,3 +352,29 @@ def test_attention_forced_rescale(hip):
     d2 = hip.attn_desc(q0.cuda(), q0.cuda(), bf(v2).cuda(), o2, lse2, batch=1, hq=1, hkv=1, sq=S2, sk=S2, hd=D, scale=1.0)
     hip.attention_fwd(d2)
     torch.testing.assert_close(o2.float().cpu(), v2.mean(0, keepdim=True).expand(S2, D), rtol=1e-2, atol=1e-2)
+
+
+def test_attention_desc_keeps_tensors_alive_and_clamps_kv_start(hip):
+    """The descriptor holds raw device pointers: it must keep temporaries alive (a freed kv_start buffer
+    reused by a later allocation once turned into garbage pad lengths).  Out-of-range pad lengths are
+    clamped to [0, Sk] inside the kernels instead of indexing out of bounds."""
+    B, H, S, D = 2, 2, 96, 128
+    g = torch.Generator().manual_seed(1)
+    qkv = bf(torch.randn(B * S, 3 * H * D, generator=g))
+    o = torch.zeros(B * S, H * D, dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros(B, H, S, device="cuda")
+    d = hip.attn_desc(qkv.cuda(), qkv.cuda(), qkv.cuda(), o, lse, batch=B, hq=H, hkv=H, sq=S, sk=S, hd=D, scale=D ** -0.5,
+                      causal=True, kv_start=torch.tensor([-5, 1000], dtype=torch.int32).cuda(), q_off=0, k_off=H * D, v_off=2 * H * D)
+    junk = [torch.full((1024,), -1.0, device="cuda") for _ in range(8)]       # would recycle freed temporaries
+    hip.attention_fwd(d)
+    dq = torch.zeros(B * S, 3 * H * D, dtype=torch.bfloat16, device="cuda")
+    hip.attention_bwd(d, bf(torch.randn(B * S, H * D, generator=g)).cuda(), dq, dq, dq, dk_off=H * D, dv_off=2 * H * D)
+    torch.cuda.synchronize()
+    out = o.float().cpu().view(B, S, H, D)
+    q = qkv[:, :H * D].float().view(B, S, H, D)
+    k = qkv[:, H * D:2 * H * D].float().view(B, S, H, D)
+    v = qkv[:, 2 * H * D:].float().view(B, S, H, D)
+    ref = _attn_ref(q, k, v, D ** -0.5, True, torch.tensor([0, S]))
+    assert rel_err(out, ref) < 8e-3
+    assert float(out[1].abs().max()) == 0.0 and torch.isfinite(dq.float()).all()
+    del junk
