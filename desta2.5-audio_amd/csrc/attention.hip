@@ -119,7 +119,8 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
     char* kimg = lds;
     char* vimg = lds + 64 * D * 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h2 = lane >> 5;
-    const int qb0 = blockIdx.x * 128, q0 = qb0 + wave * 32;
+    // causal: the last query blocks see the most keys -> dispatch them first
+    const int qb0 = (p.causal ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * 128, q0 = qb0 + wave * 32;
     const int h = blockIdx.y, b = blockIdx.z, hk = h / (p.Hq / p.Hkv);
     const int qcol = q0 + (lane & 31);
 
@@ -286,7 +287,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(AttnArgs p) {
     char* kimg = lds;
     char* vimg = lds + 64 * D * 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h2 = lane >> 5;
-    const int qb0 = blockIdx.x * 128, q0 = qb0 + wave * 32;
+    // causal: the last query blocks see the most keys -> dispatch them first
+    const int qb0 = (p.causal ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * 128, q0 = qb0 + wave * 32;
     const int h = blockIdx.y, b = blockIdx.z, hk = h / (p.Hq / p.Hkv);
     const int qcol = q0 + (lane & 31), qc = min(qcol, p.Sq - 1);
 
@@ -410,8 +412,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_k(AttnArgs p) {
     float* lse_s = (float*)(lds + 2 * 32 * D * 2);
     float* dlt_s = lse_s + 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h2 = lane >> 5;
-    const int kb0 = blockIdx.x * 128, k0 = kb0 + wave * 32;
-    const int hk = blockIdx.y, b = blockIdx.z, group = p.Hq / p.Hkv;
+    // 1-D grid with the key block as the SLOWEST index: under the causal mask low key blocks sweep the
+    // most query tiles, so the heaviest work items are dispatched first (longest-processing-time order)
+    const int nhb = p.Hkv * p.B;
+    const int kb0 = (blockIdx.x / nhb) * 128, k0 = kb0 + wave * 32;
+    const int hk = (blockIdx.x % nhb) % p.Hkv, b = (blockIdx.x % nhb) / p.Hkv, group = p.Hq / p.Hkv;
     const int kcol = k0 + (lane & 31), kc = min(kcol, p.Sk - 1);
     const int kv_lo = p.kv_start ? max(0, min(p.kv_start[b], p.Sk)) : 0;
     const int coff = p.Sk - p.Sq;
@@ -578,7 +583,7 @@ extern "C" int desta_attention_bwd(const desta_attn_desc* d, float* workspace, v
     const int G = d->head_dim / 8;
     dim3 gd((unsigned)((rows * G + 255) / 256));
     dim3 gq((a.Sq + 127) / 128, a.Hq, a.B);
-    dim3 gk((a.Sk + 127) / 128, a.Hkv, a.B);
+    dim3 gk((unsigned)((a.Sk + 127) / 128) * a.Hkv * a.B);
     if (d->head_dim == 128) {
         hipLaunchKernelGGL(attn_delta_k<128>, gd, dim3(256), 0, st, a, workspace);
         hipLaunchKernelGGL(attn_bwd_dq_k<128>, gq, dim3(256), 0, st, a);

@@ -34,6 +34,7 @@ struct GemmArgs {
     int out_f32;
     bf16_t* preact; long ldp; long sP;                  // optional copy of (acc+bias) before act
     float alpha;                                        // scales the accumulator before bias
+    bf16_t* aux; long lda_x;                            // act 2: SwiGLU output [M,N/2]; act 3: saved gate|up input [M,2N]
     int tilesM, tilesN;
     int full_tiles, split;                              // 256-kernel: tiles [0,full) whole-K; the rest in `split` K-slices
     float* ws;                                          // fp32 partial slabs [(tile-full)*split + slice][256][256]
@@ -62,6 +63,29 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& p, int z, int m, int n
     if (p.act == 1) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+    } else if (p.act == 2) {
+        // fused SwiGLU forward on an interleaved gate/up projection: columns (2i, 2i+1) = (gate_i, up_i).
+        // C keeps the bf16 pre-activations (saved for backward); aux[m][n0/2 ..] = bf16(silu(g)) * u,
+        // computed from the ROUNDED values exactly like the unfused HF path (LlamaMLP).
+        float g0 = bf2f(f2bf(v[0])), u0 = bf2f(f2bf(v[1])), g1 = bf2f(f2bf(v[2])), u1 = bf2f(f2bf(v[3]));
+        const float a0 = bf2f(f2bf(g0 / (1.0f + __expf(-g0)))) * u0;
+        const float a1 = bf2f(f2bf(g1 / (1.0f + __expf(-g1)))) * u1;
+        const unsigned pk = (unsigned)f2bf(a0) | ((unsigned)f2bf(a1) << 16);
+        *(unsigned*)(p.aux + (long)m * p.lda_x + (n0 >> 1)) = pk;
+    } else if (p.act == 3) {
+        // fused SwiGLU backward: v = d(act)[m][n0..n0+3]; aux = saved interleaved gate|up [M,2N];
+        // C[m][2n0..2n0+7] = (dgate, dup) interleaved (bf16), ldc counts the 2N-wide rows
+        const u16x8 gu = *(const u16x8*)(p.aux + (long)m * p.lda_x + 2 * n0);
+        u16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = bf2f(f2bf(v[e])), g = bf2f(gu[2 * e]), u = bf2f(gu[2 * e + 1]);
+            const float sig = 1.0f / (1.0f + __expf(-g));
+            o[2 * e] = f2bf(d * u * (sig * (1.0f + g * (1.0f - sig))));
+            o[2 * e + 1] = f2bf(d * (g * sig));
+        }
+        *(u16x8*)((bf16_t*)p.C + (long)z * p.sC + (long)m * p.ldc + 2 * n0) = o;
+        return;
     }
     if (p.res) {
         if (p.res_f32) {
@@ -81,6 +105,48 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& p, int z, int m, int n
         for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
         *(u16x4*)((bf16_t*)p.C + (long)z * p.sC + (long)m * p.ldc + n0) = o;
     }
+}
+
+// Fast bf16 epilogue for two horizontally adjacent 16x16 tiles (bias / GELU / bf16 or fp32 residual):
+// v_permlane16_swap exchanges the odd 16-lane rows of tile j with the even rows of tile j+1, after which
+// every lane owns 8 CONTIGUOUS outputs of one row -> one 16-B store instead of two 8-B stores
+// (half the store instructions of the epilogue, which is issue-bound with one block per CU).
+__device__ __forceinline__ void epilogue_pair_bf16(const GemmArgs& p, int z, int m, bool row_ok, int ncol0, int fq,
+                                                   const f32x4& a0, const f32x4& a1) {
+    unsigned pk[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const f32x4& a = t ? a1 : a0;
+        const int n0 = ncol0 + t * 16 + fq * 4;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = a[e] * p.alpha;
+        if (p.bias) {
+            const float4 b = *(const float4*)(p.bias + n0);
+            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        }
+        if (p.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        }
+        if (p.res) {
+            if (p.res_f32) {
+                const float4 r = *(const float4*)((const float*)p.res + (long)z * p.sR + (long)m * p.ldr + n0);
+                v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+            } else {
+                const u16x4 r = *(const u16x4*)((const bf16_t*)p.res + (long)z * p.sR + (long)m * p.ldr + n0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += bf2f(r[e]);
+            }
+        }
+        pk[t][0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+        pk[t][1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+    }
+    // rows (= lane >> 4) after the swap: X' = [X0, Y0, X2, Y2], Y' = [X1, Y1, X3, Y3]
+    const auto lo = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+    const int col = ncol0 + (fq & 1) * 16 + (fq >> 1) * 8;
+    if (row_ok) *(uint4*)((bf16_t*)p.C + (long)z * p.sC + (long)m * p.ldc + col) = make_uint4(lo[0], hi[0], lo[1], hi[1]);
 }
 
 __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs p) {
@@ -198,6 +264,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs p) {
 //   slots so the count stays constant.
 constexpr int HT = 128 * BK * 2;                         // half-tile bytes (128 rows x 128 B)
 
+template <int SCHED>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) char lds[2 * 4 * HT];            // [buf][A0,A1,B0,B1]
 
@@ -295,8 +362,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) a[i][kk] = *(const bf16x8*)(A0 + (offA[i] ^ (kk << 6)));
         stage(g + 7);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (SCHED == 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -315,8 +384,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) b1[i][kk] = *(const bf16x8*)(B1 + (offB[i] ^ (kk << 6)));
         stage(g + 8);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (SCHED == 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -335,8 +406,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) a[i][kk] = *(const bf16x8*)(A1 + (offA[i] ^ (kk << 6)));
         stage(g + 9);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (SCHED == 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -375,6 +448,23 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 *(f32x4*)(slab + (wm * 128 + i * 16 + fr) * 256 + wn * 64 + j * 16 + fq * 4) = acc[i][j];
+        return;
+    }
+    // whole 32-column pairs inside N, bf16 output, no side outputs: wide-store epilogue (block-uniform choice;
+    // the permlane swap needs all 64 lanes, so row guards only predicate the store)
+    const bool wide = !p.out_f32 && !p.preact && p.act <= 1 && (p.N % 32 == 0) && (p.ldc % 8 == 0);
+    if (wide) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = brow + wm * 128 + i * 16 + fr;
+            const int mc = min(m, p.M - 1);
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+                const int ncol0 = bcol + wn * 64 + j * 16;
+                if (ncol0 >= p.N) continue;                                   // wave-uniform
+                epilogue_pair_bf16(p, z, mc, m < p.M, ncol0, fq, acc[i][j], acc[i][j + 1]);   // all lanes swap; rows >= M only skip the store
+            }
+        }
         return;
     }
 #pragma unroll
@@ -439,6 +529,11 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
     a.act = d->act; a.out_f32 = d->out_f32;
     a.preact = (bf16_t*)d->preact; a.ldp = d->ldp; a.sP = d->stride_p;
     a.alpha = d->alpha;
+    a.aux = (bf16_t*)d->aux; a.lda_x = d->ld_aux;
+    DESTA_CHECK_ARG(d->act >= 0 && d->act <= 3, "gemm: unknown act %d", d->act);
+    DESTA_CHECK_ARG(d->act < 2 || (d->aux && !d->out_f32 && !d->bias && !d->residual && !d->preact && d->ld_aux % 8 == 0),
+                    "gemm: SwiGLU epilogues need aux, bf16 output and no bias/residual/preact");
+    DESTA_CHECK_ARG(d->act != 3 || d->ldc % 8 == 0, "gemm: act 3 needs ldc (2N-wide rows) to be a multiple of 8");
     // Tile choice.  The 256x256 8-phase kernel runs ONE block per CU, so the tile grid executes in rounds
     // of 256; a partial last round leaves CUs idle (M=5120 x N=4096: 320 tiles = 1.25 rounds).  Those tail
     // tiles are cut into `split` K-slices (<= 256 items, each 1/split long: "1 + 1/split" rounds instead
@@ -465,12 +560,13 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
         big = eff >= 0.78;
     }
     if (g_force_variant == 1) big = false;
-    if (g_force_variant == 2) big = true;
+    if (g_force_variant >= 2) big = true;
     if (big) {
         a.tilesM = tM; a.tilesN = tN;
         a.full_tiles = full; a.split = split; a.ws = (float*)d->workspace;
         const int items = full + (int)(T - full) * split;
-        hipLaunchKernelGGL(gemm_bf16_nt_256_kernel, dim3(items, d->batch), dim3(512), 0, (hipStream_t)stream, a);
+        if (g_force_variant == 3) hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<1>, dim3(items, d->batch), dim3(512), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<0>, dim3(items, d->batch), dim3(512), 0, (hipStream_t)stream, a);
         if (split > 1)
             hipLaunchKernelGGL(gemm_splitk_fixup_kernel, dim3((unsigned)(T - full) * 64, d->batch), dim3(256), 0, (hipStream_t)stream, a);
     } else {

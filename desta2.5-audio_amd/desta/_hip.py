@@ -32,6 +32,7 @@ class GemmDesc(C.Structure):
                 ("bias", vp), ("residual", vp), ("ldr", i64), ("stride_r", i64), ("residual_f32", i32),
                 ("act", i32), ("out_f32", i32),
                 ("preact", vp), ("ldp", i64), ("stride_p", i64), ("alpha", f32),
+                ("aux", vp), ("ld_aux", i64),
                 ("workspace", vp), ("workspace_bytes", C.c_size_t)]
 
 
@@ -65,7 +66,7 @@ _gemm = _sig("desta_gemm_bf16_nt", C.POINTER(GemmDesc), vp)
 
 def gemm(A, B, out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, residual=None, ldr=None,
          act=0, preact=None, ldp=None, alpha=1.0, batch=1, stride_a=0, stride_b=0, stride_c=0,
-         stride_r=0, stride_p=0):
+         stride_r=0, stride_p=0, aux=None, ld_aux=0):
     """out[M,N] = act(alpha * A[M,K] @ B[N,K]^T + bias) + residual  (bf16 operands, MFMA)."""
     d = GemmDesc()
     d.A, d.B, d.C = p(A), p(B), p(out)
@@ -85,6 +86,7 @@ def gemm(A, B, out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, residua
     d.ldp = N if ldp is None else ldp
     d.stride_p = stride_p
     d.alpha = alpha
+    d.aux, d.ld_aux = p(aux), ld_aux
     ws = _gemm_ws.get(A.device)
     if ws is None:
         ws = _gemm_ws[A.device] = torch.empty(GEMM_WS_BYTES // 4, dtype=torch.float32, device=A.device)

@@ -596,6 +596,8 @@ class CausalLMHIP:
             s["ad"] = ad
             H.gemm(s["att"], ly["wo"], s["xm"], M, h, self.hq * self.hd, residual=x)
             H.rmsnorm_fwd(s["xm"], ly["n2"], c.rms_norm_eps, self.hb, s["r2"])
+            # (the GEMM also has fused SwiGLU epilogues, act=2/3; measured SLOWER here: with one 256x256 block
+            #  per CU the extra epilogue traffic is not overlapped, the streaming kernels run at HBM rate)
             H.gemm(self.hb, ly["wgu"], s["gu"], M, 2 * self.I, h)
             H.swiglu_fwd(s["gu"], self.act, M, self.I)
             H.gemm(self.act, ly["wd"], self.xs[i + 1], M, h, self.I, residual=s["xm"])

@@ -51,11 +51,15 @@ typedef struct desta_gemm_desc {
     const void* residual;              /* [M,N] bf16 or fp32, or NULL */
     int64_t ldr, stride_r;
     int residual_f32;
-    int act;                           /* 0 = none, 1 = GELU(erf) */
+    int act;                           /* 0 = none, 1 = GELU(erf), 2 = SwiGLU fwd, 3 = SwiGLU bwd (see aux) */
     int out_f32;                       /* C dtype: 0 = bf16, 1 = fp32 */
     void* preact;                      /* optional bf16 [M,N] */
     int64_t ldp, stride_p;
     float alpha;
+    void* aux;                         /* act 2: columns are interleaved (gate_i, up_i): C keeps the bf16    */
+    int64_t ld_aux;                    /*   pre-activations, aux[M,N/2] (bf16, out) = silu(gate)*up.          */
+                                       /* act 3: C[M,2N] (bf16, ldc = row length) = d(gate|up) interleaved    */
+                                       /*   from v = d(act) and aux[M,2N] (bf16, in) = saved gate|up          */
     void* workspace;                   /* optional fp32 scratch for the split-K tail (NULL = never split);   */
     size_t workspace_bytes;            /* 64 MiB covers every shape (<= 256 slabs of 256x256 fp32)            */
 } desta_gemm_desc;

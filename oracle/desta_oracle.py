@@ -490,24 +490,29 @@ def adafactor_init(params: List[Tensor]) -> List[dict]:
 
 def adafactor_step(params: List[Tensor], grads: List[Tensor], state: List[dict], lr: float,
                    wd: List[float], eps1: float = 1e-30, clip_threshold: float = 1.0,
-                   decay_rate: float = -0.8) -> None:
+                   decay_rate: float = -0.8, f64_stats: bool = False) -> None:
     """``transformers.optimization.Adafactor.step`` with scale_parameter=False,
-    relative_step=False, beta1=None (``TF:optimization.py:1203-1294``)."""
+    relative_step=False, beta1=None (``TF:optimization.py:1203-1294``).
+    ``f64_stats=True`` accumulates the reductions (row/col means, RMS) in float64: torch's fp32 CPU
+    reductions over multi-million-element tensors carry ~1e-4 relative error of their own."""
     for p, g, s, wdk in zip(params, grads, state, wd):
         g = g.float()
         s["step"] += 1
         beta2t = 1.0 - math.pow(s["step"], decay_rate)
         upd = g * g + eps1
         if p.dim() >= 2:
-            s["row"].mul_(beta2t).add_(upd.mean(dim=-1), alpha=1.0 - beta2t)
-            s["col"].mul_(beta2t).add_(upd.mean(dim=-2), alpha=1.0 - beta2t)
-            r = (s["row"] / s["row"].mean(dim=-1, keepdim=True)).rsqrt().unsqueeze(-1)
+            rm = upd.double().mean(dim=-1).float() if f64_stats else upd.mean(dim=-1)
+            cm = upd.double().mean(dim=-2).float() if f64_stats else upd.mean(dim=-2)
+            s["row"].mul_(beta2t).add_(rm, alpha=1.0 - beta2t)
+            s["col"].mul_(beta2t).add_(cm, alpha=1.0 - beta2t)
+            rmean = s["row"].double().mean(dim=-1, keepdim=True).float() if f64_stats else s["row"].mean(dim=-1, keepdim=True)
+            r = (s["row"] / rmean).rsqrt().unsqueeze(-1)
             c = s["col"].unsqueeze(-2).rsqrt()
             upd = (r * c) * g
         else:
             s["sq"].mul_(beta2t).add_(upd, alpha=1.0 - beta2t)
             upd = s["sq"].rsqrt() * g
-        rms = upd.norm(2) / math.sqrt(upd.numel())
+        rms = (upd.double().norm(2).float() if f64_stats else upd.norm(2)) / math.sqrt(upd.numel())
         upd = upd / torch.clamp(rms / clip_threshold, min=1.0)
         upd = upd * lr
         if wdk != 0:

@@ -24,7 +24,10 @@ def main():
     variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2]
     dev = "cuda"
     print(f"{'shape':34s} " + " ".join(f"v{v:>2d} TF/s (med,max)" for v in variants))
+    flt = sys.argv[3] if len(sys.argv) > 3 else ""
     for M, N, K, what in SHAPES:
+        if flt and not any(f in what for f in flt.split(",")):
+            continue
         A = (torch.rand(M, K, device=dev) * 2 - 1).to(torch.bfloat16)
         B = (torch.rand(N, K, device=dev) * 2 - 1).to(torch.bfloat16)
         C = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
