@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs p) {
 //   slots so the count stays constant.
 constexpr int HT = 128 * BK * 2;                         // half-tile bytes (128 rows x 128 B)
 
-template <int SCHED>
+template <bool STAGGER>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) char lds[2 * 4 * HT];            // [buf][A0,A1,B0,B1]
 
@@ -348,6 +348,25 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
     __builtin_amdgcn_s_barrier();
 
     bf16x8 a[4][2], b0[2][2], b1[2][2];
+    // STAGGER: waves 4-7 (the SIMD partners of waves 0-3) run half a phase behind, so on every SIMD one wave
+    // issues its 16 MFMAs while the other issues its LDS reads / LDS-DMA: each phase is split into a LOAD
+    // slot and an MFMA slot with a barrier after each; group B enters the loop one barrier late and group A
+    // leaves it one barrier late.  Every slot ends with lgkmcnt(0) (its ds_reads have returned before any
+    // other wave may re-stage the slot) and the counted vmcnt (the shares this wave issued have landed).
+#define SLOT_END()                                        \
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");     \
+    __builtin_amdgcn_s_barrier();
+#define MFMA_SLOT(ACC_I0, ACC_J0, BF)                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    __builtin_amdgcn_s_setprio(1);                                                                           \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                         \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                        \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                    \
+                acc[ACC_I0 + i][ACC_J0 + j] =                                                                \
+                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j][kk], a[i][kk], acc[ACC_I0 + i][ACC_J0 + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                           \
+    __builtin_amdgcn_sched_barrier(0);
+    if (STAGGER && wave >= 4) __builtin_amdgcn_s_barrier();
     for (int t = 0; t < nk; ++t) {
         const char* base = lds + (t & 1) * 4 * HT;
         const char* A0 = base, *A1 = base + HT, *B0 = base + 2 * HT, *B1 = base + 3 * HT;
@@ -362,81 +381,39 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) a[i][kk] = *(const bf16x8*)(A0 + (offA[i] ^ (kk << 6)));
         stage(g + 7);
-        if constexpr (SCHED == 0) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j][kk], a[i][kk], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (STAGGER) { SLOT_END() }
+        MFMA_SLOT(0, 0, b0)
+        SLOT_END()
         // ---------------- P2: B1 -> Q01
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) b1[i][kk] = *(const bf16x8*)(B1 + (offB[i] ^ (kk << 6)));
         stage(g + 8);
-        if constexpr (SCHED == 0) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j][kk], a[i][kk], acc[i][2 + j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (STAGGER) { SLOT_END() }
+        MFMA_SLOT(0, 2, b1)
+        SLOT_END()
         // ---------------- P3: A1 -> Q11
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) a[i][kk] = *(const bf16x8*)(A1 + (offA[i] ^ (kk << 6)));
         stage(g + 9);
-        if constexpr (SCHED == 0) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j][kk], a[i][kk], acc[4 + i][2 + j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (STAGGER) { SLOT_END() }
+        MFMA_SLOT(4, 2, b1)
+        SLOT_END()
         // ---------------- P4: (B0 in registers) -> Q10
         stage(g + 10);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j][kk], a[i][kk], acc[4 + i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if (STAGGER) { SLOT_END() }
+        MFMA_SLOT(4, 0, b0)
+        SLOT_END()
     }
+    if (STAGGER && wave < 4) __builtin_amdgcn_s_barrier();
+#undef MFMA_SLOT
+#undef SLOT_END
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the dummy tail loads before LDS is released
 
     if (partial) {
@@ -505,7 +482,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_fixup_kernel(GemmArgs p) {
 
 }  // namespace
 
-static int g_force_variant = 0;   // 0 auto, 1 = 128x128, 2 = 256x256 (tuning / tests)
+static int g_force_variant = 0;   // 0 auto, 1 = 128x128, 2 = 256x256 lockstep, 3 = 256x256 staggered (tuning / tests)
 extern "C" int desta_gemm_force_variant(int v) { g_force_variant = v; return DESTA_OK; }
 
 extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
@@ -565,8 +542,9 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
         a.tilesM = tM; a.tilesN = tN;
         a.full_tiles = full; a.split = split; a.ws = (float*)d->workspace;
         const int items = full + (int)(T - full) * split;
-        if (g_force_variant == 3) hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<1>, dim3(items, d->batch), dim3(512), 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<0>, dim3(items, d->batch), dim3(512), 0, (hipStream_t)stream, a);
+        // default: staggered schedule (+4-7 % measured on the LLM shapes); variant 2 keeps the lockstep one for A/B runs
+        if (g_force_variant == 2) hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<false>, dim3(items, d->batch), dim3(512), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<true>, dim3(items, d->batch), dim3(512), 0, (hipStream_t)stream, a);
         if (split > 1)
             hipLaunchKernelGGL(gemm_splitk_fixup_kernel, dim3((unsigned)(T - full) * 64, d->batch), dim3(256), 0, (hipStream_t)stream, a);
     } else {

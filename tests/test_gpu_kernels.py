@@ -61,6 +61,26 @@ def test_gemm_256_tile_variant(hip, M, N, K):
         hip.gemm_force_variant(0)
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 768, 1024), (300, 520, 576), (2560, 1280, 4096), (256, 256, 64)])
+def test_gemm_256_staggered_variant(hip, M, N, K):
+    """Variant 3: waves 4-7 run half a phase behind waves 0-3 (same arithmetic, different barrier schedule)."""
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    A = _bf(torch.randn(M, K, generator=g)).cuda()
+    B = _bf(torch.randn(N, K, generator=g)).cuda()
+    outs = []
+    try:
+        for v in (2, 3):
+            hip.gemm_force_variant(v)
+            o = torch.empty(M, N, dtype=torch.float32, device="cuda")
+            for _ in range(3):                      # repeat: a schedule race would show up as run-to-run differences
+                hip.gemm(A, B, o, M, N, K)
+            outs.append(o)
+    finally:
+        hip.gemm_force_variant(0)
+    assert torch.equal(outs[0], outs[1])
+    torch.testing.assert_close(outs[1], A.float() @ B.float().T, rtol=1e-4, atol=2e-3)
+
+
 def test_gemm_256_identity_and_k64(hip):
     K = 64                                        # a single K-tile: the whole loop is prologue + dummy tail loads
     A = _bf(torch.eye(256)[:, :K]).cuda()
