@@ -808,7 +808,8 @@ class DeSTA25AudioModel:
                         out_logits = out_logits.clone()
                     else:
                         out_logits = None
-                loss = self.llm.loss_and_grad(labels, write_grad=need_grad).view(())
+                # clone: the kernel writes into a persistent 1-element buffer that the next step overwrites
+                loss = self.llm.loss_and_grad(labels, write_grad=need_grad).clone().view(())
             # audio rows of inputs_embeds, for the backward gather
             self._fwd = dict(B=B, S=S, N_audio=N_audio, starts=[(int(r), int(s)) for r, s in batch_start_positions],
                              has_grad=labels is not None and self.training and N_audio > 0)

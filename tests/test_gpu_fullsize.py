@@ -1,0 +1,115 @@
+"""Full-size (BASELINE.json configs[1]) checks through size-independent properties — the oracle cannot
+run an 8 B-parameter step in seconds, so at true shapes the HIP path is checked by exact-integer
+checksums, softmax row sums, determinism (bit-identical reruns = data-parallel replica consistency),
+loss == ln(V)-scale for random init, and loss descent over a few optimizer steps on a repeated batch."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    assert torch.cuda.is_available()
+    from desta import _hip
+    return _hip
+
+
+def test_gemm_exact_integer_checksum_llm_shapes(hip):
+    """Small-integer operands: every partial sum is exact in fp32, so ANY tile / K-slice schedule must agree
+    bit for bit with a plain fp32 matmul.  Shapes: down-proj (split-K tail path) and gate_up."""
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for M, N, K in ((5120, 4096, 14336), (5120, 28672, 4096), (12000, 1280, 5120)):
+        A = torch.randint(-4, 5, (M, K), generator=g, device="cuda").to(torch.bfloat16)
+        B = torch.randint(-4, 5, (N, K), generator=g, device="cuda").to(torch.bfloat16)
+        out = torch.empty(M, N, dtype=torch.float32, device="cuda")
+        hip.gemm(A, B, out, M, N, K)
+        # reference in chunks of K (fp32 exact for these magnitudes)
+        ref = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+        for k0 in range(0, K, 2048):
+            ref += A[:, k0:k0 + 2048].float() @ B[:, k0:k0 + 2048].float().T
+        assert torch.equal(out, ref), (M, N, K)
+        # linearity: (A + A) B^T == 2 (A B^T), exact
+        out2 = torch.empty_like(out)
+        hip.gemm((A.float() * 2).to(torch.bfloat16), B, out2, M, N, K)
+        assert torch.equal(out2, 2 * out)
+
+
+def test_attention_full_size_row_sums_and_determinism(hip):
+    """V = 1  =>  every visible row of softmax(QK^T)V is exactly 1 (row sums), pad rows are 0; rerun is bit-identical."""
+    for (B, Hq, Hkv, S, D, causal) in ((8, 32, 8, 640, 128, True), (8, 20, 20, 1500, 64, False)):
+        g = torch.Generator(device="cuda").manual_seed(1)
+        w = (Hq + 2 * Hkv) * D
+        qkv = torch.randn(B * S, w, generator=g, device="cuda").to(torch.bfloat16)
+        qkv[:, (Hq + Hkv) * D:] = 1.0
+        kvs = torch.tensor([0, 17, 0, 0, 100, 0, 0, 639 if causal else 0][:B], dtype=torch.int32, device="cuda") if causal else None
+        o = torch.zeros(B * S, Hq * D, dtype=torch.bfloat16, device="cuda")
+        lse = torch.zeros(B, Hq, S, device="cuda")
+        d = hip.attn_desc(qkv, qkv, qkv, o, lse, batch=B, hq=Hq, hkv=Hkv, sq=S, sk=S, hd=D, scale=D ** -0.5, causal=causal,
+                          kv_start=kvs, q_off=0, k_off=Hq * D, v_off=(Hq + Hkv) * D)
+        hip.attention_fwd(d)
+        out = o.float().view(B, S, Hq * D)
+        if causal:
+            for b in range(B):
+                p = int(kvs[b])
+                assert float(out[b, :p].abs().max()) == 0.0 if p else True
+                torch.testing.assert_close(out[b, p:], torch.ones_like(out[b, p:]), rtol=0, atol=8e-3)
+        else:
+            torch.testing.assert_close(out, torch.ones_like(out), rtol=0, atol=8e-3)
+        o2 = torch.zeros_like(o)
+        d2 = hip.attn_desc(qkv, qkv, qkv, o2, lse.clone(), batch=B, hq=Hq, hkv=Hkv, sq=S, sk=S, hd=D, scale=D ** -0.5,
+                           causal=causal, kv_start=kvs, q_off=0, k_off=Hq * D, v_off=(Hq + Hkv) * D)
+        hip.attention_fwd(d2)
+        assert torch.equal(o, o2)
+
+
+def test_logmel_full_batch_properties(hip):
+    """8 x 30 s: silence maps to the clamp floor everywhere; a pure tone peaks in the mel band of its frequency."""
+    wave = torch.zeros(8, 480000, device="cuda")
+    t = torch.arange(480000, device="cuda") / 16000.0
+    wave[1] = 0.5 * torch.sin(2 * math.pi * 1000.0 * t)
+    wave[2] = 0.5 * torch.sin(2 * math.pi * 4000.0 * t)
+    mel = hip.logmel(wave, 128)
+    assert mel.shape == (8, 128, 3000) and torch.isfinite(mel).all()
+    assert float((mel[0] - mel[0, 0, 0]).abs().max()) == 0.0            # silence: log10(1e-10) clamped, constant (-10+4)/4
+    assert abs(float(mel[0, 0, 0]) - (-10.0 + 4.0) / 4.0) < 1e-6
+    b1, b2 = int(mel[1, :, 1500].argmax()), int(mel[2, :, 1500].argmax())
+    assert b1 < b2 and float(mel[1].max()) > float(mel[1, b2, 1500])      # 1 kHz band below the 4 kHz band
+    assert torch.equal(mel, hip.logmel(wave, 128))                         # deterministic
+
+
+@pytest.fixture(scope="module")
+def full_model():
+    from desta.models.modeling_desta25 import DeSTA25AudioModel, DeSTA25Config
+    from desta.synthetic import FULL_CONFIGS, RandomWeights
+    cfg = DeSTA25Config(**FULL_CONFIGS["desta25_llama31-8B_Qformer6L"])
+    return DeSTA25AudioModel(cfg, weights=RandomWeights(cfg, "cuda:0", seed=0), device="cuda:0")
+
+
+def test_full_size_step_properties(hip, full_model):
+    from desta.synthetic import synthetic_inputs, synthetic_waveform
+    from desta.trainer.desta_trainer import DeSTA25Trainer, TrainingArguments
+    model = full_model
+    cfg = model.config
+    assert abs(model.arena.true_numel() - 131.54e6) < 0.05e6                # trainable parameter count of the 6L connector
+    B = 8
+    batch = synthetic_inputs(cfg, B, 64, 512, "cuda:0", seed=3)
+    batch["batch_features"] = hip.logmel(synthetic_waveform(B, "cuda:0", seed=3), 128)
+    model.train()
+    out = model(**batch)
+    loss0 = float(out.loss)
+    assert abs(loss0 - math.log(cfg.llm_config.vocab_size)) < 1.0           # random init: CE ~ ln V
+    model.backward()
+    g1 = model.arena.grads.clone()
+    assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
+    model.mark_weights_updated()
+    out = model(**batch)
+    model.backward()
+    assert float(out.loss) == loss0 and torch.equal(model.arena.grads, g1)  # bit-identical rerun (replica consistency)
+    # a few optimizer steps on the repeated batch lower the loss
+    tr = DeSTA25Trainer(model, args=TrainingArguments(learning_rate=2e-3, warmup_steps=0, max_steps=100, logging_steps=100))
+    losses = tr.train([batch] * 6)
+    assert losses[-1] < losses[0] - 0.05, losses
+    assert all(math.isfinite(x) for x in losses)

@@ -127,10 +127,16 @@ def test_train_steps_vs_oracle(name):
     st = O.adafactor_init([w[n] for n in names])
     batches = [O.synthetic_batch(d, B=2, S_ctx=5, S_tgt=24, seed=100 + i, pad=[0, i]) for i in range(3)]
     losses = tr.train(batches)
+    ref_losses = []
     for i, b in enumerate(batches):
         lr = O.linear_warmup_lr(i, 1e-3, 2, 10)
         lo, _, _, _ = O.train_step(w, d, b, st, lr)
-        assert abs(losses[i] - float(lo)) < 3e-2, (i, losses[i], float(lo))
+        ref_losses.append(float(lo))
+        assert abs(losses[i] - float(lo)) < 2e-2, (i, losses[i], float(lo))
+    assert len(set(losses)) == len(losses), losses            # per-step values, not aliases of one buffer
+    # step-to-step differences follow the oracle (tighter than the absolute bf16-vs-fp32 offset)
+    for i in range(1, len(losses)):
+        assert abs((losses[i] - losses[0]) - (ref_losses[i] - ref_losses[0])) < 1e-2
     sd = model.state_dict()
     # parameters moved by ~lr per step; compare the UPDATE (p_after - p_before) direction and size
     w0 = O.init_weights(d, seed=11)
