@@ -174,7 +174,7 @@ def main():
                                    f"S={S} ({a.ctx} ctx + {cfg.prompt_size} audio + {a.tgt} target tokens), random-init weights at true shapes",
                        "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}"},
             "final_loss": final_loss,
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_256_kernel (+ gemm_bf16_nt_kernel on small shapes)", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
                          "launches_per_step": n_launch / a.steps, "avg_launch_us": 1e3 * gemm_ms / max(n_launch, 1),
                          "flop_per_launch": flops / max(n_launch, 1), "gemm_ms_per_step": gemm_ms / a.steps},
