@@ -34,6 +34,7 @@ struct AttnArgs {
     const int* kv_start;                                             // [B] first valid key (left padding) or null
     float scale_log2;                                                // softmax scale * log2(e)
     float scale;
+    unsigned drop_thresh, seed_lo, seed_hi; float drop_scale;       // attention-probability dropout (DROP kernels)
 };
 
 template <int D>
@@ -113,7 +114,7 @@ __device__ __forceinline__ bf16x8 acc_frag(const f32x16& x, int s) {
 __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 // ------------------------------------------------------------------------------------------ forward
-template <int D>
+template <int D, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char lds[2 * 64 * D * 2];
     char* kimg = lds;
@@ -202,6 +203,17 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
             }
         rs += __shfl_xor(rs, 32, 64);
         l = l * alpha + rs;
+        if constexpr (DROP) {
+            // inverted dropout of the probabilities that enter P·V (the normaliser l keeps the full sum)
+            const unsigned long rowbase = (((unsigned long)b * p.Hq + h) * p.Sq + min(qcol, p.Sq - 1)) * p.Sk;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * 64 + kb * 32 + acc_row(r, lane);
+                    st[kb][r] = desta_rng32(p.seed_lo, p.seed_hi, rowbase + key) >= p.drop_thresh ? st[kb][r] * p.drop_scale : 0.f;
+                }
+        }
         if (__any(mnew != m)) {                            // rescale only when some row's max moved
 #pragma unroll
             for (int i = 0; i < D / 32; ++i)
@@ -281,7 +293,7 @@ __global__ __launch_bounds__(256) void attn_delta_k(AttnArgs p, float* __restric
 }
 
 // ------------------------------------------------------------------------------------------ backward: dQ
-template <int D>
+template <int D, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dq_k(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char lds[2 * 64 * D * 2];
     char* kimg = lds;
@@ -354,7 +366,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(AttnArgs p) {
                     const bool ok = key < p.Sk && key >= kv_lo && (!p.causal || key <= q_abs);
                     pv = ok ? pv : 0.f;
                 }
-                st[r] = pv * (dp[r] - dlt) * p.scale;      // dS^T
+                float dpr = dp[r];
+                if constexpr (DROP) {
+                    const int key = kt * 64 + kb * 32 + acc_row(r, lane);
+                    const unsigned long idx = (((unsigned long)b * p.Hq + h) * p.Sq + qc) * p.Sk + key;
+                    dpr = desta_rng32(p.seed_lo, p.seed_hi, idx) >= p.drop_thresh ? dpr * p.drop_scale : 0.f;
+                }
+                st[r] = pv * (dpr - dlt) * p.scale;        // dS^T
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -404,7 +422,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(AttnArgs p) {
 
 // ------------------------------------------------------------------------------------------ backward: dK, dV
 // block = 128 keys of one (batch, kv head); wave w owns keys [k0 + 32w, k0 + 32w + 32)
-template <int D>
+template <int D, bool DROP>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_k(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char lds[2 * 32 * D * 2 + 2 * 32 * 4];
     char* qimg = lds;
@@ -491,8 +509,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_k(AttnArgs p) {
                     const bool ok = key_ok && q < p.Sq && (!p.causal || kcol <= q + coff);
                     pv = ok ? pv : 0.f;
                 }
-                st[r] = pv;                                                  // P
-                dp[r] = pv * (dp[r] - dlt_s[ql]) * p.scale;                  // dS
+                float ms = 1.0f;
+                if constexpr (DROP) {
+                    const int hq = hk * group + it / nq;
+                    const unsigned long idx = (((unsigned long)b * p.Hq + hq) * p.Sq + min(qt * 32 + ql, p.Sq - 1)) * p.Sk + kc;
+                    ms = desta_rng32(p.seed_lo, p.seed_hi, idx) >= p.drop_thresh ? p.drop_scale : 0.f;
+                }
+                st[r] = pv * ms;                                             // (dropped) P for dV
+                dp[r] = pv * (ms * dp[r] - dlt_s[ql]) * p.scale;             // dS
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -549,6 +573,11 @@ int fill_args(const desta_attn_desc* d, AttnArgs& a) {
     a.B = d->batch; a.Hq = d->n_q_heads; a.Hkv = d->n_kv_heads; a.Sq = d->seq_q; a.Sk = d->seq_k;
     a.causal = d->causal; a.kv_start = d->kv_start;
     a.scale = d->scale; a.scale_log2 = d->scale * 1.44269504088896340736f;
+    DESTA_CHECK_ARG(d->dropout_p >= 0.f && d->dropout_p < 1.f, "attention: dropout_p must be in [0,1)");
+    DESTA_CHECK_ARG(d->dropout_p == 0.f || d->head_dim == 64, "attention: dropout is built for head_dim 64 (the Q-Former) only");
+    a.drop_thresh = d->dropout_p > 0.f ? desta_drop_thresh(d->dropout_p) : 0u;
+    a.drop_scale = 1.0f / (1.0f - d->dropout_p);
+    a.seed_lo = (unsigned)d->dropout_seed; a.seed_hi = (unsigned)(d->dropout_seed >> 32);
     return DESTA_OK;
 }
 
@@ -560,8 +589,9 @@ extern "C" int desta_attention_fwd(const desta_attn_desc* d, void* stream) {
     DESTA_CHECK_ARG(d->O, "attention_fwd: null output");
     DESTA_CHECK_ARG(d->o_row_stride % 4 == 0, "attention_fwd: o_row_stride must be a multiple of 4");
     dim3 grid((a.Sq + 127) / 128, a.Hq, a.B);
-    if (d->head_dim == 128) hipLaunchKernelGGL(attn_fwd_k<128>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(attn_fwd_k<64>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (d->head_dim == 128) hipLaunchKernelGGL((attn_fwd_k<128, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else if (a.drop_thresh) hipLaunchKernelGGL((attn_fwd_k<64, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((attn_fwd_k<64, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
     DESTA_CHECK_LAUNCH("attention_fwd");
     return DESTA_OK;
 }
@@ -586,12 +616,17 @@ extern "C" int desta_attention_bwd(const desta_attn_desc* d, float* workspace, v
     dim3 gk((unsigned)((a.Sk + 127) / 128) * a.Hkv * a.B);
     if (d->head_dim == 128) {
         hipLaunchKernelGGL(attn_delta_k<128>, gd, dim3(256), 0, st, a, workspace);
-        hipLaunchKernelGGL(attn_bwd_dq_k<128>, gq, dim3(256), 0, st, a);
-        if (d->dK) hipLaunchKernelGGL(attn_bwd_dkdv_k<128>, gk, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attn_bwd_dq_k<128, false>), gq, dim3(256), 0, st, a);
+        if (d->dK) hipLaunchKernelGGL((attn_bwd_dkdv_k<128, false>), gk, dim3(256), 0, st, a);
     } else {
         hipLaunchKernelGGL(attn_delta_k<64>, gd, dim3(256), 0, st, a, workspace);
-        hipLaunchKernelGGL(attn_bwd_dq_k<64>, gq, dim3(256), 0, st, a);
-        if (d->dK) hipLaunchKernelGGL(attn_bwd_dkdv_k<64>, gk, dim3(256), 0, st, a);
+        if (a.drop_thresh) {
+            hipLaunchKernelGGL((attn_bwd_dq_k<64, true>), gq, dim3(256), 0, st, a);
+            if (d->dK) hipLaunchKernelGGL((attn_bwd_dkdv_k<64, true>), gk, dim3(256), 0, st, a);
+        } else {
+            hipLaunchKernelGGL((attn_bwd_dq_k<64, false>), gq, dim3(256), 0, st, a);
+            if (d->dK) hipLaunchKernelGGL((attn_bwd_dkdv_k<64, false>), gk, dim3(256), 0, st, a);
+        }
     }
     DESTA_CHECK_LAUNCH("attention_bwd");
     return DESTA_OK;

@@ -86,6 +86,21 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return cdf + x * pdf;
 }
 
+// Counter-based dropout RNG: 32 random bits for element `idx` of the tensor/stream identified by `seed`
+// (murmur3-style mixing; stateless, so forward and backward recompute identical masks).
+__device__ __forceinline__ unsigned desta_rng32(unsigned seed_lo, unsigned seed_hi, unsigned long idx) {
+    unsigned x = (unsigned)idx ^ seed_lo;
+    x *= 0xcc9e2d51u; x = (x << 15) | (x >> 17); x *= 0x1b873593u;
+    x ^= (unsigned)(idx >> 32) * 0x85ebca6bu + seed_hi;
+    x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+    return x;
+}
+// keep-threshold for drop probability p: element kept iff rng >= thresh
+__host__ __device__ inline unsigned desta_drop_thresh(float p) {
+    const double t = (double)p * 4294967296.0;
+    return t >= 4294967295.0 ? 0xffffffffu : (unsigned)t;
+}
+
 // XCD-aware bijective remap of a 1-D block id: blocks that share an XCD (id % 8) get a contiguous
 // chunk of the logical grid so neighbouring tiles hit the same L2 (guide T1, bijective form).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

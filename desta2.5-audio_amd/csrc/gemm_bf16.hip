@@ -35,6 +35,7 @@ struct GemmArgs {
     bf16_t* preact; long ldp; long sP;                  // optional copy of (acc+bias) before act
     float alpha;                                        // scales the accumulator before bias
     bf16_t* aux; long lda_x;                            // act 2: SwiGLU output [M,N/2]; act 3: saved gate|up input [M,2N]
+    unsigned drop_thresh, seed_lo, seed_hi; float drop_scale;   // dropout on (acc+bias) after act, before residual (0 = off)
     int tilesM, tilesN;
     int full_tiles, split;                              // 256-kernel: tiles [0,full) whole-K; the rest in `split` K-slices
     float* ws;                                          // fp32 partial slabs [(tile-full)*split + slice][256][256]
@@ -86,6 +87,11 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& p, int z, int m, int n
         }
         *(u16x8*)((bf16_t*)p.C + (long)z * p.sC + (long)m * p.ldc + 2 * n0) = o;
         return;
+    }
+    if (p.drop_thresh) {
+        const unsigned long base = ((unsigned long)z * p.M + m) * p.N + n0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = desta_rng32(p.seed_lo, p.seed_hi, base + e) >= p.drop_thresh ? v[e] * p.drop_scale : 0.f;
     }
     if (p.res) {
         if (p.res_f32) {
@@ -429,7 +435,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
     }
     // whole 32-column pairs inside N, bf16 output, no side outputs: wide-store epilogue (block-uniform choice;
     // the permlane swap needs all 64 lanes, so row guards only predicate the store)
-    const bool wide = !p.out_f32 && !p.preact && p.act <= 1 && (p.N % 32 == 0) && (p.ldc % 8 == 0);
+    const bool wide = !p.out_f32 && !p.preact && p.act <= 1 && !p.drop_thresh && (p.N % 32 == 0) && (p.ldc % 8 == 0);
     if (wide) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -507,6 +513,10 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
     a.preact = (bf16_t*)d->preact; a.ldp = d->ldp; a.sP = d->stride_p;
     a.alpha = d->alpha;
     a.aux = (bf16_t*)d->aux; a.lda_x = d->ld_aux;
+    DESTA_CHECK_ARG(d->dropout_p >= 0.f && d->dropout_p < 1.f, "gemm: dropout_p must be in [0,1)");
+    a.drop_thresh = d->dropout_p > 0.f ? desta_drop_thresh(d->dropout_p) : 0u;
+    a.drop_scale = 1.0f / (1.0f - d->dropout_p);
+    a.seed_lo = (unsigned)d->dropout_seed; a.seed_hi = (unsigned)(d->dropout_seed >> 32);
     DESTA_CHECK_ARG(d->act >= 0 && d->act <= 3, "gemm: unknown act %d", d->act);
     DESTA_CHECK_ARG(d->act < 2 || (d->aux && !d->out_f32 && !d->bias && !d->residual && !d->preact && d->ld_aux % 8 == 0),
                     "gemm: SwiGLU epilogues need aux, bf16 output and no bias/residual/preact");

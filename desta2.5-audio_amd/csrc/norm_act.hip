@@ -443,6 +443,25 @@ __global__ __launch_bounds__(256) void mel_rows_k(const float* __restrict__ mel,
     }
 }
 
+__global__ __launch_bounds__(256) void dropout_bf16_k(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int rows, int cols,
+                                                      long ld, unsigned thresh, float scale, unsigned slo, unsigned shi) {
+    const long n4 = (long)rows * (cols / 4);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const long r = i / (cols / 4);
+        const int c = (int)(i % (cols / 4)) * 4;
+        const u16x4 v = *(const u16x4*)(x + r * ld + c);
+        u16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            o[e] = desta_rng32(slo, shi, (unsigned long)(r * cols + c + e)) >= thresh ? f2bf(bf2f(v[e]) * scale) : (bf16_t)0;
+        *(u16x4*)(y + r * ld + c) = o;
+    }
+}
+__global__ __launch_bounds__(256) void dropout_mask_k(unsigned slo, unsigned shi, long n, unsigned thresh, uint8_t* __restrict__ out) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        out[i] = desta_rng32(slo, shi, (unsigned long)i) >= thresh ? 1 : 0;
+}
+
 int nblocks(long n, int per = 256, int cap = 8192) {
     long b = (n + per - 1) / per;
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -608,5 +627,21 @@ extern "C" int desta_mel_to_rows(const float* mel, int batch, int n_mels, int fr
     dim3 grid((frames + 63) / 64, (c_pad + 63) / 64, batch);
     hipLaunchKernelGGL(mel_rows_k, grid, dim3(256), 0, (hipStream_t)stream, mel, batch, n_mels, frames, c_pad, (bf16_t*)out);
     DESTA_CHECK_LAUNCH("mel_to_rows");
+    return DESTA_OK;
+}
+
+extern "C" int desta_dropout_bf16(const void* x, void* y, int rows, int cols, int64_t ld, float p, uint64_t seed, void* stream) {
+    DESTA_CHECK_ARG(x && y && rows > 0 && cols > 0 && cols % 4 == 0 && ld % 4 == 0 && p >= 0.f && p < 1.f, "dropout: bad argument");
+    hipLaunchKernelGGL(dropout_bf16_k, dim3(nblocks((long)rows * (cols / 4))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                       (bf16_t*)y, rows, cols, (long)ld, p > 0.f ? desta_drop_thresh(p) : 0u, 1.0f / (1.0f - p), (unsigned)seed,
+                       (unsigned)(seed >> 32));
+    DESTA_CHECK_LAUNCH("dropout_bf16");
+    return DESTA_OK;
+}
+extern "C" int desta_dropout_mask_u8(uint64_t seed, int64_t n, float p, uint8_t* out, void* stream) {
+    DESTA_CHECK_ARG(out && n > 0 && p >= 0.f && p < 1.f, "dropout_mask: bad argument");
+    hipLaunchKernelGGL(dropout_mask_k, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, (unsigned)seed, (unsigned)(seed >> 32),
+                       (long)n, p > 0.f ? desta_drop_thresh(p) : 0u, out);
+    DESTA_CHECK_LAUNCH("dropout_mask");
     return DESTA_OK;
 }

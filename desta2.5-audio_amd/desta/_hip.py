@@ -32,7 +32,7 @@ class GemmDesc(C.Structure):
                 ("bias", vp), ("residual", vp), ("ldr", i64), ("stride_r", i64), ("residual_f32", i32),
                 ("act", i32), ("out_f32", i32),
                 ("preact", vp), ("ldp", i64), ("stride_p", i64), ("alpha", f32),
-                ("aux", vp), ("ld_aux", i64),
+                ("aux", vp), ("ld_aux", i64), ("dropout_p", f32), ("dropout_seed", C.c_uint64),
                 ("workspace", vp), ("workspace_bytes", C.c_size_t)]
 
 
@@ -66,7 +66,7 @@ _gemm = _sig("desta_gemm_bf16_nt", C.POINTER(GemmDesc), vp)
 
 def gemm(A, B, out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, residual=None, ldr=None,
          act=0, preact=None, ldp=None, alpha=1.0, batch=1, stride_a=0, stride_b=0, stride_c=0,
-         stride_r=0, stride_p=0, aux=None, ld_aux=0):
+         stride_r=0, stride_p=0, aux=None, ld_aux=0, dropout_p=0.0, dropout_seed=0):
     """out[M,N] = act(alpha * A[M,K] @ B[N,K]^T + bias) + residual  (bf16 operands, MFMA)."""
     d = GemmDesc()
     d.A, d.B, d.C = p(A), p(B), p(out)
@@ -87,6 +87,7 @@ def gemm(A, B, out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, residua
     d.stride_p = stride_p
     d.alpha = alpha
     d.aux, d.ld_aux = p(aux), ld_aux
+    d.dropout_p, d.dropout_seed = dropout_p, dropout_seed
     ws = _gemm_ws.get(A.device)
     if ws is None:
         ws = _gemm_ws[A.device] = torch.empty(GEMM_WS_BYTES // 4, dtype=torch.float32, device=A.device)
@@ -312,7 +313,8 @@ class AttnDesc(C.Structure):
                 ("do_batch_stride", i64), ("do_row_stride", i64), ("dq_batch_stride", i64), ("dq_row_stride", i64),
                 ("dk_batch_stride", i64), ("dk_row_stride", i64), ("dv_batch_stride", i64), ("dv_row_stride", i64),
                 ("batch", i32), ("n_q_heads", i32), ("n_kv_heads", i32), ("seq_q", i32), ("seq_k", i32),
-                ("head_dim", i32), ("causal", i32), ("kv_start", vp), ("scale", f32)]
+                ("head_dim", i32), ("causal", i32), ("kv_start", vp), ("scale", f32),
+                ("dropout_p", f32), ("dropout_seed", C.c_uint64)]
 
 
 _attn_fwd = _sig("desta_attention_fwd", C.POINTER(AttnDesc), vp)
@@ -326,7 +328,7 @@ def _elem_ptr(t, offset_elems):
 
 
 def attn_desc(q, k, v, o, lse, *, batch, hq, hkv, sq, sk, hd, scale, causal=False, kv_start=None,
-              q_off=0, k_off=0, v_off=0, q_rs=None, k_rs=None, v_rs=None, o_rs=None):
+              q_off=0, k_off=0, v_off=0, q_rs=None, k_rs=None, v_rs=None, o_rs=None, dropout_p=0.0, dropout_seed=0):
     """q/k/v are 2-D row-major [batch*seq, row_stride] buffers (possibly the same fused buffer);
     *_off = first column of the q/k/v slice."""
     d = AttnDesc()
@@ -344,6 +346,7 @@ def attn_desc(q, k, v, o, lse, *, batch, hq, hkv, sq, sk, hd, scale, causal=Fals
     d.causal = int(causal)
     d.kv_start = p(kv_start)
     d.scale = scale
+    d.dropout_p, d.dropout_seed = dropout_p, dropout_seed
     d._keep = (q, k, v, o, lse, kv_start)       # the descriptor holds RAW pointers: keep the tensors alive with it
     return d
 
@@ -387,3 +390,17 @@ def gemm_force_variant(v: int) -> None:
     """Tuning / tests: 0 = automatic tile choice, 1 = 128x128 kernel, 2 = 256x256 8-phase kernel."""
     lib.desta_gemm_force_variant.argtypes = [i32]
     lib.desta_gemm_force_variant(v)
+
+
+_dropout = _sig("desta_dropout_bf16", vp, vp, i32, i32, i64, f32, C.c_uint64, vp)
+_dropout_mask = _sig("desta_dropout_mask_u8", C.c_uint64, i64, f32, vp, vp)
+
+
+def dropout_bf16(x, y, rows, cols, ld, p_drop, seed):
+    check(_dropout(p(x), p(y), rows, cols, ld, p_drop, seed, stream()), "desta_dropout_bf16")
+
+
+def dropout_mask(seed, n, p_drop, device="cuda"):
+    out = torch.empty(n, dtype=torch.uint8, device=device)
+    check(_dropout_mask(seed, n, p_drop, p(out), stream()), "desta_dropout_mask_u8")
+    return out

@@ -94,7 +94,7 @@ class DeSTA25Config:
                  audio_locator="<|AUDIO|>", placeholder_token="<|reserved_special_token_87|>",
                  llm_config: Optional[dict] = None, encoder_config: Optional[dict] = None,
                  qformer_intermediate_size: int = 3072, target_layer_ids: Optional[List[int]] = None,
-                 orca_enabled=False, **kwargs):
+                 qformer_dropout: float = 0.1, orca_enabled=False, **kwargs):
         if connector_mode != "qformer_1" or orca_enabled:
             raise NotImplementedError(
                 f"connector_mode '{connector_mode}' not implemented. Supported modes: 'qformer_1' "
@@ -106,6 +106,9 @@ class DeSTA25Config:
         self.use_lora, self.audio_locator, self.placeholder_token = use_lora, audio_locator, placeholder_token
         self.orca_enabled = False
         self.qformer_intermediate_size = qformer_intermediate_size   # BertConfig() default (never overridden, :156-162)
+        # BertConfig() defaults hidden_dropout_prob = attention_probs_dropout_prob = 0.1 are never overridden
+        # either (hazard H3): active in training mode, own counter-based RNG (not torch's Philox stream)
+        self.qformer_dropout = float(qformer_dropout)
         lc = dict(llm_config) if llm_config is not None else _read_hf_config(llm_model_id)
         ec = dict(encoder_config) if encoder_config is not None else _read_hf_config(encoder_model_id)
         self.llm_config = self._llm_from_dict(lc)
@@ -144,6 +147,7 @@ class DeSTA25Config:
                 "prompt_size": self.prompt_size, "use_lora": self.use_lora, "audio_locator": self.audio_locator,
                 "placeholder_token": self.placeholder_token, "orca_enabled": False,
                 "qformer_intermediate_size": self.qformer_intermediate_size, "target_layer_ids": self.target_layer_ids,
+                "qformer_dropout": self.qformer_dropout,
                 "llm_config": asdict(self.llm_config), "encoder_config": asdict(self.encoder_config), "info": self.info}
 
     def save_pretrained(self, path: str) -> None:
@@ -320,6 +324,8 @@ class QformerConnectorHIP:
         assert (self.K * self.d) % 64 == 0, "layer_prompts must tile the arena without padding"
         self.w16 = torch.empty(arena.numel, dtype=BF16, device=device)          # bf16 image of the arena (autocast copy)
         self.B = 0
+        self.p_drop = 0.0                      # set per forward by the model (cfg.qformer_dropout in training mode)
+        self.seed_base = 0
         # transposed bf16 weights for the dX GEMMs: name -> [in, out]
         self.wT: Dict[str, torch.Tensor] = {}
 
@@ -388,7 +394,7 @@ class QformerConnectorHIP:
         self.af = b16(B * K, self.h)
         # backward scratch
         self.g32a, self.g32b = f32(R, d), f32(R, d)
-        self.dpre16, self.da, self.dq = b16(R, d), b16(R, d), b16(R, d)
+        self.dpre16, self.da, self.dq, self.dm16 = b16(R, d), b16(R, d), b16(R, d), b16(R, d)
         self.dqkv, self.dh = b16(R, 3 * d), b16(R, inter)
         self.dkv = b16(E, 2 * d)
         self.tA = b16(max(3 * d, inter, self.h) * max(self.Rp, self.BKp))     # transposed dY  [N, Rp]
@@ -408,30 +414,36 @@ class QformerConnectorHIP:
         H.prompt_expand(self.P32(f"{CON}layer_prompts.0", nt * K * d), nt, B, K * d, self.x0_32, self.x0_16)
         x32, x16 = self.x0_32, self.x0_16
         scale = 64 ** -0.5
+        pd = self.p_drop
         for i in range(self.Lq):
             p, s = f"{CON}qformer.layer.{i}.", self.sv[i]
+            sd = [(self.seed_base + 16 * i + k) & 0xFFFFFFFFFFFFFFFF for k in range(5)]   # attn-self, out1, attn-cross, out2, out3
+            s["seeds"], s["pd"] = sd, pd
             # self-attention over the K queries (bidirectional, H5)
             H.gemm(x16, self.W16(p + "attention.self.query.weight", 3 * d), s["qkv"], R, 3 * d, d, bias=self.P32(p + "attention.self.query.bias", 3 * d))
             ad = H.attn_desc(s["qkv"], s["qkv"], s["qkv"], s["a_s"], s["lse_s"], batch=nt * B, hq=self.heads, hkv=self.heads, sq=K, sk=K,
-                             hd=64, scale=scale, q_off=0, k_off=d, v_off=2 * d)
+                             hd=64, scale=scale, q_off=0, k_off=d, v_off=2 * d, dropout_p=pd, dropout_seed=sd[0])
             H.attention_fwd(ad)
             s["ad_s"] = ad
-            H.gemm(s["a_s"], self.W16(p + "attention.output.dense.weight"), s["pre1"], R, d, d, bias=self.P32(p + "attention.output.dense.bias"), residual=x32)
+            H.gemm(s["a_s"], self.W16(p + "attention.output.dense.weight"), s["pre1"], R, d, d, bias=self.P32(p + "attention.output.dense.bias"), residual=x32,
+                   dropout_p=pd, dropout_seed=sd[1])
             H.layernorm_fwd(s["pre1"], self.P32(p + "attention.output.LayerNorm.weight"), self.P32(p + "attention.output.LayerNorm.bias"), 1e-12,
                             y16=s["x1_16"], y32=s["x1_32"], stats=s["st1"])
             # cross-attention: K queries x T encoder states (unmasked)
             H.gemm(s["x1_16"], self.W16(p + "crossattention.self.query.weight"), s["qc"], R, d, d, bias=self.P32(p + "crossattention.self.query.bias"))
             H.gemm(self.enc, self.W16(p + "crossattention.self.key.weight", 2 * d), s["kv"], E, 2 * d, d, bias=self.P32(p + "crossattention.self.key.bias", 2 * d))
             ad = H.attn_desc(s["qc"], s["kv"], s["kv"], s["a_c"], s["lse_c"], batch=nt * B, hq=self.heads, hkv=self.heads, sq=K, sk=T,
-                             hd=64, scale=scale, q_off=0, k_off=0, v_off=d)
+                             hd=64, scale=scale, q_off=0, k_off=0, v_off=d, dropout_p=pd, dropout_seed=sd[2])
             H.attention_fwd(ad)
             s["ad_c"] = ad
-            H.gemm(s["a_c"], self.W16(p + "crossattention.output.dense.weight"), s["pre2"], R, d, d, bias=self.P32(p + "crossattention.output.dense.bias"), residual=s["x1_32"])
+            H.gemm(s["a_c"], self.W16(p + "crossattention.output.dense.weight"), s["pre2"], R, d, d, bias=self.P32(p + "crossattention.output.dense.bias"), residual=s["x1_32"],
+                   dropout_p=pd, dropout_seed=sd[3])
             H.layernorm_fwd(s["pre2"], self.P32(p + "crossattention.output.LayerNorm.weight"), self.P32(p + "crossattention.output.LayerNorm.bias"), 1e-12,
                             y16=s["x2_16"], y32=s["x2_32"], stats=s["st2"])
             # FFN
             H.gemm(s["x2_16"], self.W16(p + "intermediate.dense.weight"), s["hact"], R, self.inter, d, bias=self.P32(p + "intermediate.dense.bias"), act=1, preact=s["hpre"])
-            H.gemm(s["hact"], self.W16(p + "output.dense.weight"), s["pre3"], R, d, self.inter, bias=self.P32(p + "output.dense.bias"), residual=s["x2_32"])
+            H.gemm(s["hact"], self.W16(p + "output.dense.weight"), s["pre3"], R, d, self.inter, bias=self.P32(p + "output.dense.bias"), residual=s["x2_32"],
+                   dropout_p=pd, dropout_seed=sd[4])
             H.layernorm_fwd(s["pre3"], self.P32(p + "output.LayerNorm.weight"), self.P32(p + "output.LayerNorm.bias"), 1e-12,
                             y16=s["x3_16"], y32=s["x3_32"], stats=s["st3"])
             s["x_in32"], s["x_in16"] = x32, x16
@@ -455,6 +467,13 @@ class QformerConnectorHIP:
         H.gemm(tA, tB, self.G(wname) if N == self.arena.shapes[wname][0] else self._gwide(wname, N), N, Kin, Mp)
         if bname is not None:
             H.colsum(dY, M, N, dY.shape[-1], self.G32(bname, N))
+
+    def _drop_grad(self, dpre16, s, site):
+        """Gradient w.r.t. a dense output that went through epilogue dropout: same mask, same 1/(1-p)."""
+        if s["pd"] <= 0.0:
+            return dpre16
+        H.dropout_bf16(dpre16, self.dm16, self.R, self.d, self.d, s["pd"], s["seeds"][site])
+        return self.dm16
 
     def _gwide(self, name, rows):
         o = self.arena.offsets[name]
@@ -480,16 +499,18 @@ class QformerConnectorHIP:
             dpre, dpre16, dh, da, dq, dqkv = other, self.dpre16, self.dh, self.da, self.dq, self.dqkv
             H.layernorm_bwd(dx, s["pre3"], self.P32(p + "output.LayerNorm.weight"), s["st3"], dx32=dpre, dx16=dpre16,
                             dgamma=self.G32(p + "output.LayerNorm.weight"), dbeta=self.G32(p + "output.LayerNorm.bias"))
-            self._dW(dpre16, s["hact"], R, d, inter, p + "output.dense.weight", p + "output.dense.bias", self.Rp)
-            H.gemm(dpre16, self.wT[f"{i}.o"], dh, R, inter, d)
+            dm = self._drop_grad(dpre16, s, 4)                                                   # grad of the dense output (through its dropout)
+            self._dW(dm, s["hact"], R, d, inter, p + "output.dense.weight", p + "output.dense.bias", self.Rp)
+            H.gemm(dm, self.wT[f"{i}.o"], dh, R, inter, d)
             H.gelu_bwd(s["hpre"], dh, dh, R * inter)
             self._dW(dh, s["x2_16"], R, inter, d, p + "intermediate.dense.weight", p + "intermediate.dense.bias", self.Rp)
             H.gemm(dh, self.wT[f"{i}.i"], dx, R, d, inter, residual=dpre)                      # dx := d x2_32
             # --- cross-attention block: x2 = LN(pre2), pre2 = a_c@Wo^T + b + x1
             H.layernorm_bwd(dx, s["pre2"], self.P32(p + "crossattention.output.LayerNorm.weight"), s["st2"], dx32=dpre, dx16=dpre16,
                             dgamma=self.G32(p + "crossattention.output.LayerNorm.weight"), dbeta=self.G32(p + "crossattention.output.LayerNorm.bias"))
-            self._dW(dpre16, s["a_c"], R, d, d, p + "crossattention.output.dense.weight", p + "crossattention.output.dense.bias", self.Rp)
-            H.gemm(dpre16, self.wT[f"{i}.c.o"], da, R, d, d)
+            dm = self._drop_grad(dpre16, s, 3)
+            self._dW(dm, s["a_c"], R, d, d, p + "crossattention.output.dense.weight", p + "crossattention.output.dense.bias", self.Rp)
+            H.gemm(dm, self.wT[f"{i}.c.o"], da, R, d, d)
             H.attention_bwd(s["ad_c"], da, dq, self.dkv, self.dkv, dk_off=0, dv_off=d)
             self._dW(dq, s["x1_16"], R, d, d, p + "crossattention.self.query.weight", p + "crossattention.self.query.bias", self.Rp)
             # key/value projections of the encoder states (no dX into the frozen Whisper states)
@@ -500,8 +521,9 @@ class QformerConnectorHIP:
             # --- self-attention block: x1 = LN(pre1), pre1 = a_s@Wo^T + b + x_in
             H.layernorm_bwd(dx, s["pre1"], self.P32(p + "attention.output.LayerNorm.weight"), s["st1"], dx32=dpre, dx16=dpre16,
                             dgamma=self.G32(p + "attention.output.LayerNorm.weight"), dbeta=self.G32(p + "attention.output.LayerNorm.bias"))
-            self._dW(dpre16, s["a_s"], R, d, d, p + "attention.output.dense.weight", p + "attention.output.dense.bias", self.Rp)
-            H.gemm(dpre16, self.wT[f"{i}.s.o"], da, R, d, d)
+            dm = self._drop_grad(dpre16, s, 1)
+            self._dW(dm, s["a_s"], R, d, d, p + "attention.output.dense.weight", p + "attention.output.dense.bias", self.Rp)
+            H.gemm(dm, self.wT[f"{i}.s.o"], da, R, d, d)
             H.attention_bwd(s["ad_s"], da, dqkv, dqkv, dqkv, dq_off=0, dk_off=d, dv_off=2 * d)
             self._dW(dqkv, s["x_in16"], R, 3 * d, d, p + "attention.self.query.weight", p + "attention.self.query.bias", self.Rp)
             H.gemm(dqkv, self.wT[f"{i}.s.qkv"], dx, R, d, 3 * d, residual=dpre)                # dx := d x_in32
@@ -659,6 +681,8 @@ class DeSTA25AudioModel:
         self._weights_dirty = True
         self._fwd = None
         self._enc_prefetched = None
+        self.dropout_seed = 0                  # per-rank stream id of the Q-Former dropout RNG (trainer sets rank)
+        self._fwd_count = 0
 
     # -- weights -------------------------------------------------------------------------------
     @staticmethod
@@ -786,6 +810,9 @@ class DeSTA25AudioModel:
                 if self._enc_prefetched != (batch_features.data_ptr(), tuple(batch_features.shape)):
                     self.encoder.forward(mel, self.enc_all)
                 self._enc_prefetched = None
+                self.connector.p_drop = cfg.qformer_dropout if self.training else 0.0
+                self.connector.seed_base = ((self.dropout_seed & 0xFFFFFF) << 40) | ((self._fwd_count & 0xFFFFFFFF) << 8)
+                self._fwd_count += 1
                 af = self.connector.forward(self.enc_all, N_audio)
                 src = self._src_rows(input_ids, [t.to(dev) for t in batch_transcription_ids], batch_start_positions, None)
             else:

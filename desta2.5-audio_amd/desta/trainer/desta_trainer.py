@@ -70,6 +70,7 @@ class DeSTA25Trainer:
         self.total_steps = self.args.max_steps if self.args.max_steps > 0 else 10 ** 9
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
+        model.dropout_seed = 1 + self.rank                                    # ranks draw different dropout masks (as under DDP)
         self._side = torch.cuda.Stream(device=model.device) if self.args.overlap_comm else None
         self._side_done: Optional[torch.cuda.Event] = None
         self._log_buffer: List[Dict[str, Any]] = []

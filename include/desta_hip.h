@@ -60,6 +60,8 @@ typedef struct desta_gemm_desc {
     int64_t ld_aux;                    /*   pre-activations, aux[M,N/2] (bf16, out) = silu(gate)*up.          */
                                        /* act 3: C[M,2N] (bf16, ldc = row length) = d(gate|up) interleaved    */
                                        /*   from v = d(act) and aux[M,2N] (bf16, in) = saved gate|up          */
+    float dropout_p;                   /* > 0: inverted dropout of act(acc+bias) BEFORE the residual add, mask */
+    uint64_t dropout_seed;             /*   = desta_dropout_mask(seed, m*N + n) (BertSelfOutput/BertOutput, p=0.1) */
     void* workspace;                   /* optional fp32 scratch for the split-K tail (NULL = never split);   */
     size_t workspace_bytes;            /* 64 MiB covers every shape (<= 256 slabs of 256x256 fp32)            */
 } desta_gemm_desc;
@@ -207,6 +209,8 @@ typedef struct desta_attn_desc {
     int causal;
     const int32_t* kv_start;
     float scale;
+    float dropout_p;                   /* attention-probability dropout (head_dim 64 only), same mask in fwd and bwd */
+    uint64_t dropout_seed;
 } desta_attn_desc;
 int desta_attention_fwd(const desta_attn_desc* d, void* stream);
 size_t desta_attention_bwd_workspace_floats(int batch, int n_q_heads, int seq_q);
@@ -217,6 +221,16 @@ int desta_attention_bwd(const desta_attn_desc* d, float* workspace, void* stream
  * gradient back over the batch. */
 int desta_prompt_expand(const float* prompts, int taps, int batch, int64_t n, float* x_f32, void* x_bf16, void* stream);
 int desta_prompt_grad(const float* dx, int taps, int batch, int64_t n, float* dprompts, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Counter-based dropout (stateless: element `i` of stream `seed` is kept iff rng32(seed, i) >= p*2^32),
+ * used by the GEMM epilogue, the attention kernels (i = ((b*H + h)*seq_q + q)*seq_k + k) and:
+ *   desta_dropout_bf16      y[r][c] = keep(r*cols + c) ? x[r][c] / (1-p) : 0   (backward of the epilogue dropout)
+ *   desta_dropout_mask_u8   materialises the keep mask (tests / debugging)
+ * Replaces nn.Dropout(hidden_dropout_prob) / attention_probs dropout of the Q-Former
+ * (TF:models/bert/modeling_bert.py:150-160, 296, 350; BertConfig defaults 0.1, modeling_desta25.py:156). */
+int desta_dropout_bf16(const void* x, void* y, int rows, int cols, int64_t ld, float p, uint64_t seed, void* stream);
+int desta_dropout_mask_u8(uint64_t seed, int64_t n, float p, uint8_t* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -5,6 +5,7 @@
 Tolerances: the product computes in bf16 (fp32 accumulate / statistics) like the reference under
 autocast; the oracle / goldens are fp32.  Stated per check below."""
 import copy
+import math
 
 import pytest
 import torch
@@ -165,3 +166,41 @@ def test_checkpoint_roundtrip(tmp_path):
     m2 = DeSTA25AudioModel.from_pretrained(str(tmp_path), weights={k: v for k, v in w.items() if "connector" not in k})
     for n in O.trainable_names(d):
         assert torch.equal(m2.arena.param(n).cpu(), w[n])
+
+
+def test_qformer_dropout_training_semantics():
+    """Dropout 0.1 (BertConfig default, hazard H3) is live in train mode only, reproducible per forward count,
+    and the hand-written backward differentiates THROUGH the same masks (directional finite difference)."""
+    from desta.models.modeling_desta25 import DeSTA25AudioModel
+    d = O.tiny_dims(False)
+    w = O.init_weights(d, seed=7)
+    model = DeSTA25AudioModel(cfg_from_dims(d, dropout=0.1), weights=w)
+    ref = DeSTA25AudioModel(cfg_from_dims(d, dropout=0.0), weights=w)
+    batch = O.synthetic_batch(d, B=2, S_ctx=5, S_tgt=24, seed=8)
+    model.eval(); ref.eval()
+    assert float(model(**batch).loss) == float(ref(**batch).loss)             # eval: no dropout
+    model.train(); ref.train()
+    l_ref = float(ref(**batch).loss)
+
+    def loss_at(count):
+        model._fwd_count = count
+        model.mark_weights_updated()
+        return model(**batch)
+    l1, l1b, l2 = float(loss_at(5).loss), float(loss_at(5).loss), float(loss_at(6).loss)
+    assert l1 == l1b and l1 != l2 and l1 != l_ref                             # same masks <-> same forward count
+    # directional derivative along the gradient with the masks of forward #5 held fixed
+    loss_at(5)
+    model.backward()
+    gvec = model.arena.grads.clone()
+    gn = float(gvec.norm())
+    assert math.isfinite(gn) and gn > 0
+    p0 = model.arena.params.clone()
+    eps = 2e-2 / gn
+    model.arena.params.copy_(p0 + eps * gvec)
+    lp = float(loss_at(5).loss)
+    model.arena.params.copy_(p0 - eps * gvec)
+    lm = float(loss_at(5).loss)
+    model.arena.params.copy_(p0)
+    fd, an = (lp - lm) / (2 * eps), gn * gn
+    print("directional derivative: finite-diff", fd, "analytic", an)
+    assert abs(fd - an) < 0.2 * an + 2e-3 / eps * 0.5                         # bf16 loss noise ~1e-3 over a 2*eps*|g|^2 = 4e-2 signal

@@ -378,3 +378,64 @@ def test_attention_desc_keeps_tensors_alive_and_clamps_kv_start(hip):
     assert rel_err(out, ref) < 8e-3
     assert float(out[1].abs().max()) == 0.0 and torch.isfinite(dq.float()).all()
     del junk
+
+
+# ----------------------------------------------------------------------------- dropout (Q-Former, hazard H3)
+def test_dropout_mask_gemm_epilogue_and_backward_kernel(hip):
+    g = torch.Generator().manual_seed(4)
+    M, N, K, pdrop, seed = 320, 256, 128, 0.1, (7 << 40) | 12345
+    mask = hip.dropout_mask(seed, M * N, pdrop).float().cpu().view(M, N)
+    keep = float(mask.mean())
+    assert abs(keep - 0.9) < 0.01                                         # Bernoulli(0.9) over 82k elements
+    assert abs(float(mask[:, ::2].mean()) - float(mask[:, 1::2].mean())) < 0.01
+    m2 = hip.dropout_mask(seed + 1, M * N, pdrop).float().cpu().view(M, N)
+    assert abs(float((mask * m2).mean()) - 0.81) < 0.01                   # streams are independent
+    A, B = bf(torch.randn(M, K, generator=g)), bf(torch.randn(N, K, generator=g) / 8)
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    for variant in (1, 3):
+        try:
+            hip.gemm_force_variant(variant)
+            out = torch.empty(M, N, dtype=torch.float32, device="cuda")
+            hip.gemm(A.cuda(), B.cuda(), out, M, N, K, bias=bias.cuda(), residual=res.cuda(), dropout_p=pdrop, dropout_seed=seed)
+        finally:
+            hip.gemm_force_variant(0)
+        ref = (A.float() @ B.float().T + bias) * mask / (1 - pdrop) + res
+        torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-4)
+    x = bf(torch.randn(M, N, generator=g))
+    y = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    hip.dropout_bf16(x.cuda(), y, M, N, N, pdrop, seed)
+    torch.testing.assert_close(y.float().cpu(), x.float() * mask / (1 - pdrop), rtol=8e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize("Sq,Sk", [(64, 64), (64, 200)])
+def test_attention_dropout_fwd_bwd(hip, Sq, Sk):
+    B, H, D, pdrop, seed = 2, 3, 64, 0.1, (3 << 40) | 77
+    g = torch.Generator().manual_seed(Sq + Sk)
+    qb = bf(torch.randn(B * Sq, H * D, generator=g))
+    kvb = bf(torch.randn(B * Sk, 2 * H * D, generator=g))
+    do = bf(torch.randn(B * Sq, H * D, generator=g))
+    mask = hip.dropout_mask(seed, B * H * Sq * Sk, pdrop).float().cpu().view(B, H, Sq, Sk)
+    q = qb.float().view(B, Sq, H, D).clone().requires_grad_(True)
+    k = kvb[:, :H * D].float().reshape(B, Sk, H, D).clone().requires_grad_(True)
+    v = kvb[:, H * D:].float().reshape(B, Sk, H, D).clone().requires_grad_(True)
+    p = torch.softmax((q.permute(0, 2, 1, 3) @ k.permute(0, 2, 3, 1)) * D ** -0.5, dim=-1)
+    ref = ((p * mask / (1 - pdrop)) @ v.permute(0, 2, 1, 3)).permute(0, 2, 1, 3)
+    ref.backward(do.float().view(B, Sq, H, D))
+    qd, kvd, dod = qb.cuda(), kvb.cuda(), do.cuda()
+    o = torch.zeros(B * Sq, H * D, dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros(B, H, Sq, device="cuda")
+    d = hip.attn_desc(qd, kvd, kvd, o, lse, batch=B, hq=H, hkv=H, sq=Sq, sk=Sk, hd=D, scale=D ** -0.5, k_off=0, v_off=H * D,
+                      dropout_p=pdrop, dropout_seed=seed)
+    hip.attention_fwd(d)
+    assert rel_err(o.float().cpu().view(B, Sq, H, D), ref.detach()) < 8e-3
+    dq = torch.zeros(B * Sq, H * D, dtype=torch.bfloat16, device="cuda")
+    dkv = torch.zeros(B * Sk, 2 * H * D, dtype=torch.bfloat16, device="cuda")
+    hip.attention_bwd(d, dod, dq, dkv, dkv, dk_off=0, dv_off=H * D)
+    assert rel_err(dq.float().cpu().view(B, Sq, H, D), q.grad) < 1.5e-2
+    assert rel_err(dkv[:, :H * D].float().cpu().view(B, Sk, H, D), k.grad) < 1.5e-2
+    assert rel_err(dkv[:, H * D:].float().cpu().view(B, Sk, H, D), v.grad) < 1.5e-2
+    # p = 0 through the same entry point is the plain kernel
+    d0 = hip.attn_desc(qd, kvd, kvd, o, lse, batch=B, hq=H, hkv=H, sq=Sq, sk=Sk, hd=D, scale=D ** -0.5, k_off=0, v_off=H * D)
+    hip.attention_fwd(d0)
+    ref0 = (p @ v.permute(0, 2, 1, 3)).permute(0, 2, 1, 3)
+    assert rel_err(o.float().cpu().view(B, Sq, H, D), ref0.detach()) < 8e-3
