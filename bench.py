@@ -170,7 +170,8 @@ def main():
             "value": world * a.steps / elapsed, "unit": "steps/s (per-GPU batches of 8 clips, summed over GPUs)",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{a.config}: whisper-large-v3 + Llama-3.1-8B, Q-Former 6L, per-GPU batch {B} x 30 s clips, "
+            "config": {"workload": f"{a.config}: {os.path.basename(cfg.encoder_model_id)} + {os.path.basename(cfg.llm_model_id)}, "
+                                   f"Q-Former {cfg.qformer_num_hidden_layers}L, per-GPU batch {B} x 30 s clips, "
                                    f"S={S} ({a.ctx} ctx + {cfg.prompt_size} audio + {a.tgt} target tokens), random-init weights at true shapes",
                        "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}"},
             "final_loss": final_loss,

@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""Entry point of the MI355X-native DeSTA2.5 training path.
+
+Same command line and YAML schema as the reference's examples/train/train_desta.py (Hydra style):
+
+    torchrun --nproc_per_node=N examples/train/train_desta.py --config-name desta25_llama31-8B_Qformer6L \\
+        +dataset=synthetic exp_dir=/tmp/exp [key.sub=value ...]
+
+Hydra/OmegaConf are not installed here, so the few features the reference uses are restated on plain
+`yaml.safe_load`: `--config-name`, the `+dataset=<group file>` addition, dotted `key=value` overrides and
+the `???` mandatory marker.  `create_model` / `create_training_args` read exactly the keys the reference
+reads (train_desta.py:96-162).  Real manifests + audio file decode are out of scope:
+datasets must be `synthetic: true`.
+"""
+import argparse
+import logging
+import os
+import sys
+
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "desta2.5-audio_amd"))
+
+
+class Cfg(dict):
+    """dict with attribute access (the OmegaConf surface the entry point needs)."""
+
+    def __getattr__(self, k):
+        try:
+            v = self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+        return Cfg(v) if isinstance(v, dict) and not isinstance(v, Cfg) else v
+
+    def get(self, k, default=None):
+        v = dict.get(self, k, default)
+        return Cfg(v) if isinstance(v, dict) and not isinstance(v, Cfg) else v
+
+
+_NUM = __import__("re").compile(r"^[+-]?(\d+\.?\d*|\.\d+)([eE][+-]?\d+)$")
+
+
+def _numify(x):
+    """YAML 1.1 reads `1e-4` as a string; OmegaConf (and the reference's configs) mean a float."""
+    if isinstance(x, dict):
+        return {k: _numify(v) for k, v in x.items()}
+    if isinstance(x, list):
+        return [_numify(v) for v in x]
+    if isinstance(x, str) and _NUM.match(x):
+        return float(x)
+    return x
+
+
+def _set_dotted(d: dict, key: str, value):
+    parts = key.split(".")
+    for p in parts[:-1]:
+        d = d.setdefault(p, {})
+    d[parts[-1]] = value
+
+
+def load_config(argv, config_dir=None) -> Cfg:
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--config-name", default="desta25")
+    ns, rest = ap.parse_known_args(argv)
+    config_dir = config_dir or os.path.join(HERE, "config")
+    path = os.path.join(config_dir, ns.config_name + ".yaml")
+    if not os.path.isfile(path):
+        raise FileNotFoundError(f"config '{ns.config_name}' not found under {config_dir} (pass --config-name)")
+    with open(path) as f:
+        cfg = yaml.safe_load(f) or {}
+    for tok in rest:
+        if "=" not in tok:
+            raise ValueError(f"unrecognised argument '{tok}' (expected key=value or +group=name)")
+        k, v = tok.split("=", 1)
+        if k.startswith("+"):                                  # +dataset=NAME -> merge config/dataset/NAME.yaml under 'dataset'
+            with open(os.path.join(config_dir, k[1:], v + ".yaml")) as f:
+                cfg[k[1:]] = yaml.safe_load(f)
+        else:
+            _set_dotted(cfg, k, yaml.safe_load(v))
+    cfg = _numify(cfg)
+
+    def check(d, prefix=""):
+        for k, v in d.items():
+            if isinstance(v, dict):
+                check(v, prefix + k + ".")
+            elif v == "???":
+                raise ValueError(f"Missing mandatory value: {prefix}{k}")
+    check(cfg)
+    return Cfg(cfg)
+
+
+def create_model(cfg: Cfg, device="cuda:0"):
+    """Hydra config -> DeSTA25Config -> model (reference train_desta.py:96-130)."""
+    from desta.models.modeling_desta25 import DeSTA25AudioModel, DeSTA25Config
+    from desta.synthetic import RandomWeights
+    orca = cfg.model.get("orca", {}) or {}
+    llm, enc, con = cfg.model.llm, cfg.model.encoder, cfg.model.connector
+    model_config = DeSTA25Config(
+        llm_model_id=llm.model_id, encoder_model_id=enc.model_id, connector_mode=con.mode,
+        qformer_num_hidden_layers=con.num_hidden_layers, prompt_size=con.prompt_size,
+        use_lora=llm.get("use_lora", False), audio_locator=cfg.model.audio_locator,
+        placeholder_token=cfg.model.placeholder_token, orca_enabled=orca.get("enabled", False),
+        llm_config=dict(llm.config) if llm.get("config") else None,
+        encoder_config=dict(enc.config) if enc.get("config") else None,
+        qformer_intermediate_size=con.get("intermediate_size", 3072))
+    random_init = bool(llm.get("config")) or bool(llm.get("random_init", False))
+    weights = RandomWeights(model_config, device, seed=0) if random_init else None     # no checkpoints offline
+    model = DeSTA25AudioModel(model_config, weights=weights, device=device)
+    model.config.train_id = 30678
+    return model
+
+
+def create_training_args(cfg: Cfg):
+    """Reference train_desta.py:133-162, restricted to what the hot path consumes."""
+    from desta.trainer.desta_trainer import TrainingArguments
+    return TrainingArguments(
+        output_dir=cfg.exp_dir, num_train_epochs=cfg.trainer.max_epochs,
+        per_device_train_batch_size=cfg.dataset.train_ds.batch_size,
+        gradient_accumulation_steps=cfg.trainer.accumulate_grad_batches,
+        learning_rate=float(cfg.optim.lr), weight_decay=float(cfg.optim.weight_decay),
+        warmup_steps=cfg.optim.sched.warmup_steps, logging_steps=cfg.trainer.log_every_n_steps,
+        max_steps=cfg.trainer.get("max_steps", -1), bf16="bf16" in cfg.trainer.precision, optim="adafactor")
+
+
+def load_pretrained_weights(model, path: str) -> None:
+    """Lightning-style {'state_dict': ...} with a 'model.' prefix (reference :73-83); tensors only."""
+    import torch
+    blob = torch.load(path, map_location="cpu", weights_only=True)
+    sd = blob.get("state_dict", blob)
+    sd = {(k[len("model."):] if k.startswith("model.") else k): v for k, v in sd.items()}
+    model.load_state_dict(sd, strict=False)
+
+
+class SyntheticAudioTextDataset:
+    """Stands in for BaseAudioTextDataset: yields collated batches (simple_dataset.py:248-264 layout)."""
+
+    def __init__(self, cfg: Cfg, data_cfg: Cfg, model, rank: int = 0):
+        if not data_cfg.get("synthetic", False):
+            raise NotImplementedError("only `synthetic: true` datasets: manifest loading / audio decode are out of "
+                                      "scope of the MI355X hot path (SURVEY.md §2 rows 3-4)")
+        self.data_cfg, self.model, self.rank = data_cfg, model, rank
+        S = data_cfg.context_tokens + model.config.prompt_size + data_cfg.target_tokens
+        if S > data_cfg.max_seq_length:
+            raise ValueError(f"sequence {S} exceeds max_seq_length {data_cfg.max_seq_length} (hazard H10)")
+
+    def batches(self):
+        from desta import _hip
+        from desta.synthetic import synthetic_inputs, synthetic_waveform
+        dc, cfgm, dev = self.data_cfg, self.model.config, self.model.device
+        for i in range(dc.num_samples // dc.batch_size):
+            b = synthetic_inputs(cfgm, dc.batch_size, dc.context_tokens, dc.target_tokens, dev, seed=1234 + self.rank + 7919 * i)
+            wave = synthetic_waveform(dc.batch_size, dev, seed=1234 + self.rank + 7919 * i)
+            b["batch_features"] = _hip.logmel(wave, cfgm.encoder_config.num_mel_bins)
+            yield b
+
+
+def main(argv=None):
+    import torch
+    import torch.distributed as dist
+    cfg = load_config(sys.argv[1:] if argv is None else argv)
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    logging.basicConfig(level=logging.INFO if rank == 0 else logging.WARNING, format="%(asctime)s %(levelname)s %(message)s")
+    os.makedirs(cfg.exp_dir, exist_ok=True)
+    if cfg.get("resume_from_checkpoint") and cfg.get("init_from_pretrained_weights"):
+        raise AssertionError("Cannot provide both resume_from_checkpoint and init_from_pretrained_weights")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    from desta.trainer.desta_trainer import DeSTA25Trainer
+    model = create_model(cfg, device=f"cuda:{local}")
+    if cfg.get("init_from_pretrained_weights"):
+        load_pretrained_weights(model, cfg.init_from_pretrained_weights)
+    if cfg.get("resume_from_checkpoint"):
+        from safetensors.torch import load_file
+        model.load_state_dict(load_file(os.path.join(cfg.resume_from_checkpoint, "model.safetensors")), strict=False)
+    train_ds = SyntheticAudioTextDataset(cfg, cfg.dataset.train_ds, model, rank)
+    trainer = DeSTA25Trainer(model=model, args=create_training_args(cfg), cfg=cfg)
+    if rank == 0:
+        with open(os.path.join(cfg.exp_dir, "config.yaml"), "w") as f:
+            yaml.safe_dump(dict(cfg), f)
+        if not cfg.get("resume_from_checkpoint"):
+            trainer.save_model(os.path.join(cfg.exp_dir, "checkpoint-initial"))
+    max_steps = cfg.trainer.get("max_steps", -1)
+    for epoch in range(int(cfg.trainer.max_epochs)):
+        losses = trainer.train(train_ds.batches(), max_steps=max_steps if max_steps and max_steps > 0 else None)
+        logging.info(f"epoch {epoch}: {len(losses)} steps, loss {losses[0]:.4f} -> {losses[-1]:.4f}")
+        if cfg.trainer.enable_checkpointing:
+            trainer.save_model(os.path.join(cfg.exp_dir, f"checkpoint-{trainer.global_step}"))
+            trainer.save_optimizer(os.path.join(cfg.exp_dir, f"checkpoint-{trainer.global_step}"))
+        if max_steps and max_steps > 0 and trainer.global_step >= max_steps:
+            break
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,52 @@
+"""CPU: the Hydra-style entry point parses the reference's YAML schema / command line and maps it to
+DeSTA25Config and TrainingArguments the way examples/train/train_desta.py:96-162 does."""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _mod():
+    spec = importlib.util.spec_from_file_location("train_desta", os.path.join(ROOT, "examples", "train", "train_desta.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_config_loading_overrides_and_mandatory_values(tmp_path):
+    m = _mod()
+    with pytest.raises(ValueError, match="Missing mandatory value: exp_dir"):
+        m.load_config(["--config-name", "desta25_debug", "+dataset=debug"])
+    cfg = m.load_config(["--config-name", "desta25_debug", "+dataset=debug", f"exp_dir={tmp_path}", "optim.lr=3e-4",
+                         "trainer.max_steps=7", "dataset.train_ds.batch_size=4"])
+    assert cfg.exp_dir == str(tmp_path) and cfg.optim.lr == 3e-4 and cfg.trainer.max_steps == 7
+    assert cfg.dataset.train_ds.batch_size == 4 and cfg.model.connector.mode == "qformer_1"
+    args = m.create_training_args(cfg)
+    assert args.learning_rate == 3e-4 and args.weight_decay == 0.01 and args.warmup_steps == 5
+    assert args.per_device_train_batch_size == 4 and args.optim == "adafactor" and args.bf16 and args.max_steps == 7
+    assert args.max_grad_norm == 1.0                       # gradient_clip_val of the YAML is NOT read
+    with pytest.raises(FileNotFoundError):
+        m.load_config(["--config-name", "nope"])
+
+
+def test_full_configs_parse_and_map_to_model_config():
+    m = _mod()
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "desta2.5-audio_amd"))
+    from desta.models.modeling_desta25 import DeSTA25Config
+    from desta.synthetic import FULL_CONFIGS
+    for name in ("desta25_llama31-8B_Qformer6L", "desta25_qwen3-8B_Qformer6L"):
+        cfg = m.load_config(["--config-name", name, "+dataset=synthetic", "exp_dir=/tmp/x"])
+        assert cfg.model.connector.num_hidden_layers == 6 and cfg.model.connector.prompt_size == 64
+        assert cfg.optim.sched.warmup_steps == 5000 and cfg.trainer.accumulate_grad_batches == 1
+        assert cfg.dataset.train_ds.batch_size == 8
+        mc = DeSTA25Config(**FULL_CONFIGS[name])           # the dims bench.py uses for the same names
+        assert mc.qformer_num_hidden_layers == 6 and mc.target_layer_ids == [7, 15, 23, 31]
+        assert mc.to_dict()["model_type"] == "desta25"
+    with pytest.raises(NotImplementedError):
+        DeSTA25Config(connector_mode="orca_hybrid", llm_config=FULL_CONFIGS[name]["llm_config"],
+                      encoder_config=FULL_CONFIGS[name]["encoder_config"])
+    with pytest.raises(FileNotFoundError):
+        DeSTA25Config(llm_model_id="/nonexistent/llm", encoder_model_id="/nonexistent/enc")
