@@ -198,6 +198,21 @@ def connector_param_shapes(cfg: DeSTA25Config) -> "OrderedDict[str, Tuple[int, .
     return s
 
 
+def reference_parameter_names(cfg: DeSTA25Config) -> List[str]:
+    """Trainable tensors in the REFERENCE's `named_parameters()` order (registration order of
+    QformerConnector.__init__, modeling_desta25.py:148-168, and of BertLayer): the order HF Trainer uses to
+    number parameters inside `optimizer.pt`."""
+    names = [f"{CON}layer_prompts.{j}" for j in range(len(cfg.target_layer_ids))] + [f"{CON}layer_weights"]
+    for i in range(cfg.qformer_num_hidden_layers):
+        p = f"{CON}qformer.layer.{i}."
+        for blk in ("attention", "crossattention"):
+            for lin in ("self.query", "self.key", "self.value", "output.dense", "output.LayerNorm"):
+                names += [f"{p}{blk}.{lin}.weight", f"{p}{blk}.{lin}.bias"]
+        for lin in ("intermediate.dense", "output.dense", "output.LayerNorm"):
+            names += [f"{p}{lin}.weight", f"{p}{lin}.bias"]
+    return names + [CON + "proj.0.weight", CON + "proj.0.bias", CON + "proj.1.weight", CON + "proj.1.bias"]
+
+
 def rope_inv_freq(c: LLMConfig) -> torch.Tensor:
     """Default / llama3-scaled inverse frequencies (TF:modeling_rope_utils.py, `_compute_llama3_parameters`)."""
     dim = c.head_dim

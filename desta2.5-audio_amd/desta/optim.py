@@ -147,6 +147,42 @@ class FusedAdafactor:
         """Pre-clip global gradient norm of the last step (device scalar, no sync)."""
         return self.workspace[0]
 
+    # -- wire format of `transformers.optimization.Adafactor.state_dict()` as HF Trainer writes it to
+    #    checkpoint-<step>/optimizer.pt: two param groups (decay first, TF:trainer.py:1181-1195), parameters
+    #    numbered in the reference's named_parameters() order inside each group
+    def hf_state_dict(self, ref_names: Sequence[str], lr: float, weight_decay: float = 0.01) -> dict:
+        dm = dict(zip(ref_names, decay_mask(ref_names)))
+        order = [n for n in ref_names if dm[n]] + [n for n in ref_names if not dm[n]]
+        n_decay = sum(dm.values())
+        state = {}
+        for idx, name in enumerate(order):
+            sl, p = self.state_slices[name], self.arena.param(name)
+            ent = {"step": self.step_count, "RMS": (p.norm(2) / math.sqrt(p.numel())).cpu()}
+            for key, hf in (("row", "exp_avg_sq_row"), ("col", "exp_avg_sq_col"), ("sq", "exp_avg_sq")):
+                if key in sl:
+                    off, shape = sl[key]
+                    ent[hf] = self.state[off:off + int(math.prod(shape))].view(tuple(shape)).detach().cpu().clone()
+            state[idx] = ent
+        common = {"lr": lr, "eps": (self.eps1, 1e-3), "clip_threshold": self.clip_threshold, "decay_rate": self.decay_rate,
+                  "beta1": None, "scale_parameter": False, "relative_step": False, "warmup_init": False}
+        groups = [dict(common, weight_decay=weight_decay, params=list(range(n_decay))),
+                  dict(common, weight_decay=0.0, params=list(range(n_decay, len(order))))]
+        return {"state": state if self.step_count > 0 else {}, "param_groups": groups}
+
+    def load_hf_state_dict(self, sd: dict, ref_names: Sequence[str]) -> None:
+        dm = dict(zip(ref_names, decay_mask(ref_names)))
+        order = [n for n in ref_names if dm[n]] + [n for n in ref_names if not dm[n]]
+        self.step_count = 0
+        for idx, name in enumerate(order):
+            ent = sd["state"].get(idx)
+            if ent is None:
+                continue
+            self.step_count = int(ent["step"])
+            for key, hf in (("row", "exp_avg_sq_row"), ("col", "exp_avg_sq_col"), ("sq", "exp_avg_sq")):
+                if key in self.state_slices[name]:
+                    off, shape = self.state_slices[name][key]
+                    self.state[off:off + int(math.prod(shape))].copy_(ent[hf].reshape(-1))
+
     # -- HF `optimizer.pt`-shaped state (exp_avg_sq_row / exp_avg_sq_col / exp_avg_sq, step)
     def state_dict(self) -> dict:
         st = {}

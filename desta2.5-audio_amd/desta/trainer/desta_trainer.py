@@ -171,6 +171,47 @@ class DeSTA25Trainer:
         self._flush_logs()
         return [float(x) for x in losses]
 
+    # -- HF `checkpoint-<step>/` layout (TF:trainer.py:3079-3130): model.safetensors (trainable-only), config.json,
+    #    optimizer.pt (Adafactor state_dict wire format), scheduler.pt (LambdaLR state), trainer_state.json
+    def save_checkpoint(self, output_dir: str) -> None:
+        import json
+        from ..models.modeling_desta25 import reference_parameter_names
+        self.wait_update()
+        torch.cuda.synchronize(self.model.device)
+        if self.rank != 0:
+            return
+        os.makedirs(output_dir, exist_ok=True)
+        self.model.save_pretrained(output_dir)
+        lr = self.get_last_lr()
+        torch.save(self.optimizer.hf_state_dict(reference_parameter_names(self.model.config), lr, self.args.weight_decay),
+                   os.path.join(output_dir, "optimizer.pt"))
+        torch.save({"base_lrs": [self.args.learning_rate] * 2, "last_epoch": self.global_step, "_step_count": self.global_step + 1,
+                    "_get_lr_called_within_step": False, "_last_lr": [lr, lr], "lr_lambdas": [None, None]},
+                   os.path.join(output_dir, "scheduler.pt"))
+        self._flush_logs()
+        with open(os.path.join(output_dir, "trainer_state.json"), "w") as f:
+            json.dump({"global_step": self.global_step, "max_steps": self.args.max_steps, "log_history": self.log_history,
+                       "desta_hip": {"forward_count": self.model._fwd_count, "dropout_seed": self.model.dropout_seed}}, f, indent=1)
+
+    def resume_from_checkpoint(self, ckpt_dir: str) -> None:
+        """Restore parameters, optimizer moments, schedule position and the dropout stream position."""
+        import json
+        from safetensors.torch import load_file
+        from ..models.modeling_desta25 import reference_parameter_names
+        self.wait_update()
+        self.model.load_state_dict(load_file(os.path.join(ckpt_dir, "model.safetensors")), strict=False)
+        sd = torch.load(os.path.join(ckpt_dir, "optimizer.pt"), map_location="cpu", weights_only=True)
+        self.optimizer.load_hf_state_dict(sd, reference_parameter_names(self.model.config))
+        sched = torch.load(os.path.join(ckpt_dir, "scheduler.pt"), map_location="cpu", weights_only=True)
+        self.global_step = int(sched["last_epoch"])
+        st_path = os.path.join(ckpt_dir, "trainer_state.json")
+        if os.path.isfile(st_path):
+            with open(st_path) as f:
+                st = json.load(f)
+            self.model._fwd_count = int(st.get("desta_hip", {}).get("forward_count", self.model._fwd_count))
+        self.model.connector.refresh_weights()
+        self.model._weights_dirty = False
+
     # -- checkpoint (trainable-only model.safetensors + optimizer state) --------------------------
     def save_model(self, output_dir: str) -> None:
         self.wait_update()

@@ -5,6 +5,7 @@
 Tolerances: the product computes in bf16 (fp32 accumulate / statistics) like the reference under
 autocast; the oracle / goldens are fp32.  Stated per check below."""
 import copy
+import os
 import math
 
 import pytest
@@ -204,3 +205,61 @@ def test_qformer_dropout_training_semantics():
     fd, an = (lp - lm) / (2 * eps), gn * gn
     print("directional derivative: finite-diff", fd, "analytic", an)
     assert abs(fd - an) < 0.2 * an + 2e-3 / eps * 0.5                         # bf16 loss noise ~1e-3 over a 2*eps*|g|^2 = 4e-2 signal
+
+
+def test_hf_checkpoint_wire_format_and_resume(tmp_path):
+    """checkpoint-<step>/ written by the HIP trainer: (1) optimizer.pt loads into a REAL transformers Adafactor
+    built the way HF Trainer builds it (decay / no-decay groups over named_parameters order) and both continue
+    identically; (2) resuming the HIP trainer from the directory reproduces an uninterrupted run bit for bit."""
+    import json
+    from safetensors.torch import load_file
+    from transformers.optimization import Adafactor
+    from desta.models.modeling_desta25 import DeSTA25AudioModel, reference_parameter_names
+    from desta.trainer.desta_trainer import DeSTA25Trainer, TrainingArguments
+    d = O.tiny_dims(False)
+    w = O.init_weights(d, seed=5)
+    batches = [O.synthetic_batch(d, B=2, S_ctx=5, S_tgt=24, seed=300 + i) for i in range(4)]
+    args = TrainingArguments(learning_rate=1e-3, warmup_steps=2, max_steps=10, logging_steps=1, overlap_comm=False)
+
+    def fresh(dropout):
+        m = DeSTA25AudioModel(cfg_from_dims(d, dropout=dropout), weights=w)
+        return m, DeSTA25Trainer(m, args=args)
+    # uninterrupted 4 steps (dropout ON: the stream position must survive the checkpoint)
+    m_a, t_a = fresh(0.1)
+    la = t_a.train(batches)
+    # 2 steps, checkpoint, resume in a NEW model/trainer, 2 more steps
+    m_b, t_b = fresh(0.1)
+    lb = t_b.train(batches[:2])
+    ck = str(tmp_path / "checkpoint-2")
+    t_b.save_checkpoint(ck)
+    assert sorted(os.listdir(ck)) == ["config.json", "model.safetensors", "optimizer.pt", "scheduler.pt", "trainer_state.json"]
+    m_c, t_c = fresh(0.1)
+    t_c.resume_from_checkpoint(ck)
+    assert t_c.global_step == 2 and json.load(open(os.path.join(ck, "trainer_state.json")))["global_step"] == 2
+    lc = t_c.train(batches[2:])
+    assert lb + lc == la
+    assert torch.equal(m_c.arena.params, m_a.arena.params)
+    # HF interop: feed optimizer.pt to transformers' Adafactor and take one identical step on both sides
+    names = reference_parameter_names(m_b.config)
+    sdm = load_file(os.path.join(ck, "model.safetensors"))
+    params = {n: torch.nn.Parameter(sdm[n].clone()) for n in names}
+    dm = dict(zip(names, O.decay_mask(names)))
+    hf = Adafactor([{"params": [params[n] for n in names if dm[n]], "weight_decay": 0.01},
+                    {"params": [params[n] for n in names if not dm[n]], "weight_decay": 0.0}],
+                   lr=1e-3, scale_parameter=False, relative_step=False)
+    hf.load_state_dict(torch.load(os.path.join(ck, "optimizer.pt"), weights_only=True))
+    m_d, t_d = fresh(0.0)
+    t_d.resume_from_checkpoint(ck)
+    g = torch.Generator().manual_seed(9)
+    for n in names:
+        gr = 0.01 * torch.randn(params[n].shape, generator=g)
+        params[n].grad = gr.clone()
+        m_d.arena.grad(n).copy_(gr)
+    torch.nn.utils.clip_grad_norm_(list(params.values()), 1.0)
+    lr = O.linear_warmup_lr(2, 1e-3, 2, 10)
+    for gq in hf.param_groups:
+        gq["lr"] = lr
+    hf.step()
+    t_d.optimizer.step(lr)
+    for n in names:
+        torch.testing.assert_close(m_d.arena.param(n).cpu(), params[n].detach(), rtol=1e-5, atol=1e-6)
