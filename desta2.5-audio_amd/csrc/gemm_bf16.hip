@@ -463,6 +463,213 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// PERSISTENT form of the 256x256 kernel: gridDim.x = min(items, CUs) blocks, block b walks items b, b+G, ...
+// and the half-tile stream simply CONTINUES across item boundaries: while the last phases of item s run, the
+// LDS-DMA stream is already loading the first K-tiles of item s+1 (no per-tile prologue), and the epilogue
+// stores of item s drain behind the main loop of item s+1 (with one block per CU nothing else would hide
+// them).  With the staggered schedule the two wave groups run their epilogues half a phase apart, each
+// beside the other group's MFMA slot.  Same phase structure, LDS slot rule and counted vmcnt(10) as above.
+template <bool STAGGER>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256p_kernel(GemmArgs p, int n_items) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * 4 * HT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int G = gridDim.x, z = blockIdx.y;
+    const int n_my = (n_items - (int)blockIdx.x + G - 1) / G;
+    const bf16_t* A = p.A + (long)z * p.sA;
+    const bf16_t* B = p.B + (long)z * p.sB;
+    const int nk_all = p.K / BK;
+    constexpr int GROUP_M = 4;
+
+    // item id -> tile origin + K range
+    auto item_geom = [&](int s, int& brow, int& bcol, int& kt0, int& nk, bool& partial, int& slab) {
+        const int id = blockIdx.x + s * G;
+        int L, slice = 0;
+        partial = false;
+        if (id < p.full_tiles) {
+            L = xcd_remap(id, p.full_tiles);
+        } else {
+            const int j = id - p.full_tiles;
+            L = p.full_tiles + j / p.split;
+            slice = j % p.split;
+            partial = p.split > 1;
+        }
+        const int gspan = GROUP_M * p.tilesN;
+        const int first_m = (L / gspan) * GROUP_M;
+        const int gsz = min(p.tilesM - first_m, GROUP_M);
+        brow = (first_m + (L % gspan) % gsz) * 256;
+        bcol = ((L % gspan) / gsz) * 256;
+        kt0 = partial ? (int)((long)nk_all * slice / p.split) : 0;
+        const int kt1 = partial ? (int)((long)nk_all * (slice + 1) / p.split) : nk_all;
+        nk = kt1 - kt0;
+        slab = id - p.full_tiles;
+    };
+
+    // ---- issue side: stream state
+    const bf16_t* src[4][2];
+    int iss_s = 0, iss_t = 0, iss_nk = 1, iss_kt0 = 0, issT = 0;     // item, local K-tile, its count / first tile, global K-tile count
+    auto setup_issue = [&](int s) {
+        int brow, bcol, slab; bool partial;
+        item_geom(s, brow, bcol, iss_kt0, iss_nk, partial, slab);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = i * 512 + tid;
+            const int r = idx >> 3, pc = idx & 7;
+            const int c = pc ^ (r & 7);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int arow = (r >> 6) * 128 + s2 * 64 + (r & 63);
+                const int bcolr = (r >> 5) * 64 + s2 * 32 + (r & 31);
+                src[s2][i] = A + (long)min(brow + arow, p.M - 1) * p.lda + c * 8;
+                src[2 + s2][i] = B + (long)min(bcol + bcolr, p.N - 1) * p.ldb + c * 8;
+            }
+        }
+    };
+    // issue the next half-tile of the stream; Q = position within the (A0,B0,B1,A1) K-tile group (static per call site)
+#define STAGE_NEXT(Q)                                                                                   \
+    {                                                                                                   \
+        constexpr int kind_ = ((Q) == 0) ? 0 : ((Q) == 1) ? 2 : ((Q) == 2) ? 3 : 1;                      \
+        const long koff_ = (long)(iss_kt0 + min(iss_t, iss_nk - 1)) * BK;                               \
+        char* dst_ = lds + ((issT & 1) * 4 + kind_) * HT;                                               \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                \
+            glds16(src[kind_][i_] + koff_, dst_ + (i_ * 512 + wave * 64) * 16);                         \
+        if ((Q) == 3) {                                                                                 \
+            ++issT; ++iss_t;                                                                            \
+            if (iss_t == iss_nk && iss_s + 1 < n_my) { ++iss_s; iss_t = 0; setup_issue(iss_s); }        \
+        }                                                                                               \
+    }
+
+    f32x4 acc[8][4];
+    const int fr = lane & 15, fq = lane >> 4;
+    int offA[4], offB[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = wm * 64 + i * 16 + fr;
+        offA[i] = r * 128 + ((fq ^ (r & 7)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = wn * 32 + i * 16 + fr;
+        offB[i] = r * 128 + ((fq ^ (r & 7)) << 4);
+    }
+
+    setup_issue(0);
+    STAGE_NEXT(0) STAGE_NEXT(1) STAGE_NEXT(2) STAGE_NEXT(3) STAGE_NEXT(0) STAGE_NEXT(1) STAGE_NEXT(2)
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    bf16x8 a[4][2], b0[2][2], b1[2][2];
+#define SLOT_END()                                        \
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");     \
+    __builtin_amdgcn_s_barrier();
+#define MFMA_SLOT(ACC_I0, ACC_J0, BF)                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    __builtin_amdgcn_s_setprio(1);                                                                           \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                         \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                        \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                    \
+                acc[ACC_I0 + i][ACC_J0 + j] =                                                                \
+                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j][kk], a[i][kk], acc[ACC_I0 + i][ACC_J0 + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                           \
+    __builtin_amdgcn_sched_barrier(0);
+    if (STAGGER && wave >= 4) __builtin_amdgcn_s_barrier();
+    int Tc = 0;                                                       // global K-tile counter of the consumer
+    for (int s = 0; s < n_my; ++s) {
+        int brow, bcol, kt0, nk, slab; bool partial;
+        item_geom(s, brow, bcol, kt0, nk, partial, slab);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < nk; ++t, ++Tc) {
+            const char* base = lds + (Tc & 1) * 4 * HT;
+            const char* A0 = base, *A1 = base + HT, *B0 = base + 2 * HT, *B1 = base + 3 * HT;
+            // P1: A0, B0 -> Q00            (stream position g+7 : A1 of the K-tile after next)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) b0[i][kk] = *(const bf16x8*)(B0 + (offB[i] ^ (kk << 6)));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) a[i][kk] = *(const bf16x8*)(A0 + (offA[i] ^ (kk << 6)));
+            STAGE_NEXT(3)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (STAGGER) { SLOT_END() }
+            MFMA_SLOT(0, 0, b0)
+            SLOT_END()
+            // P2: B1 -> Q01
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) b1[i][kk] = *(const bf16x8*)(B1 + (offB[i] ^ (kk << 6)));
+            STAGE_NEXT(0)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (STAGGER) { SLOT_END() }
+            MFMA_SLOT(0, 2, b1)
+            SLOT_END()
+            // P3: A1 -> Q11
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) a[i][kk] = *(const bf16x8*)(A1 + (offA[i] ^ (kk << 6)));
+            STAGE_NEXT(1)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (STAGGER) { SLOT_END() }
+            MFMA_SLOT(4, 2, b1)
+            SLOT_END()
+            // P4: (B0 in registers) -> Q10
+            STAGE_NEXT(2)
+            if (STAGGER) { SLOT_END() }
+            MFMA_SLOT(4, 0, b0)
+            SLOT_END()
+        }
+        // ---- epilogue of item s (no barrier inside: the other wave group keeps streaming)
+        if (partial) {
+            float* slabp = p.ws + ((long)z * (p.tilesM * p.tilesN - p.full_tiles) * p.split + (long)slab) * (256 * 256);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *(f32x4*)(slabp + (wm * 128 + i * 16 + fr) * 256 + wn * 64 + j * 16 + fq * 4) = acc[i][j];
+            continue;
+        }
+        const bool wide = !p.out_f32 && !p.preact && p.act <= 1 && !p.drop_thresh && (p.N % 32 == 0) && (p.ldc % 8 == 0);
+        if (wide) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = brow + wm * 128 + i * 16 + fr;
+                const int mc = min(m, p.M - 1);
+#pragma unroll
+                for (int j = 0; j < 4; j += 2) {
+                    const int ncol0 = bcol + wn * 64 + j * 16;
+                    if (ncol0 >= p.N) continue;
+                    epilogue_pair_bf16(p, z, mc, m < p.M, ncol0, fq, acc[i][j], acc[i][j + 1]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = brow + wm * 128 + i * 16 + fr;
+                if (m >= p.M) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n0 = bcol + wn * 64 + j * 16 + fq * 4;
+                    if (n0 >= p.N) continue;
+                    epilogue4(p, z, m, n0, acc[i][j]);
+                }
+            }
+        }
+    }
+    if (STAGGER && wave < 4) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the tail of the stream before LDS is released
+#undef MFMA_SLOT
+#undef SLOT_END
+#undef STAGE_NEXT
+}
+
 // sum the K-slice slabs of the split tiles (fixed order) and run the normal epilogue
 __global__ __launch_bounds__(256) void gemm_splitk_fixup_kernel(GemmArgs p) {
     const int rem = p.tilesM * p.tilesN - p.full_tiles;
@@ -488,7 +695,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_fixup_kernel(GemmArgs p) {
 
 }  // namespace
 
-static int g_force_variant = 0;   // 0 auto, 1 = 128x128, 2 = 256x256 lockstep, 3 = 256x256 staggered (tuning / tests)
+static int g_force_variant = 0;   // 0 auto, 1 = 128x128, 2 = 256x256 lockstep, 3 = staggered, 4 = staggered persistent (tuning / tests)
 extern "C" int desta_gemm_force_variant(int v) { g_force_variant = v; return DESTA_OK; }
 
 extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
@@ -552,8 +759,11 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
         a.tilesM = tM; a.tilesN = tN;
         a.full_tiles = full; a.split = split; a.ws = (float*)d->workspace;
         const int items = full + (int)(T - full) * split;
-        // default: staggered schedule (+4-7 % measured on the LLM shapes); variant 2 keeps the lockstep one for A/B runs
+        // variants: 2 = lockstep, 3 = staggered (+4-7 %), 4 = staggered + persistent cross-tile streaming
+        //           (default when a block gets more than one item; +3-7 % on the LLM shapes)
+        const bool persistent = g_force_variant == 4 || (g_force_variant == 0 && items > NCU);
         if (g_force_variant == 2) hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<false>, dim3(items, d->batch), dim3(512), 0, (hipStream_t)stream, a);
+        else if (persistent) hipLaunchKernelGGL(gemm_bf16_nt_256p_kernel<true>, dim3(items < NCU ? items : NCU, d->batch), dim3(512), 0, (hipStream_t)stream, a, items);
         else hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<true>, dim3(items, d->batch), dim3(512), 0, (hipStream_t)stream, a);
         if (split > 1)
             hipLaunchKernelGGL(gemm_splitk_fixup_kernel, dim3((unsigned)(T - full) * 64, d->batch), dim3(256), 0, (hipStream_t)stream, a);

@@ -66,8 +66,8 @@ typedef struct desta_gemm_desc {
     size_t workspace_bytes;            /* 64 MiB covers every shape (<= 256 slabs of 256x256 fp32)            */
 } desta_gemm_desc;
 int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream);
-/* tuning / tests only: 0 = automatic tile choice, 1 = force 128x128, 2 / 3 = force the 256x256 kernel with the
- * lockstep / staggered wave schedule */
+/* tuning / tests only: 0 = automatic tile choice, 1 = force 128x128, 2 / 3 / 4 = force the 256x256 kernel with the
+ * lockstep / staggered / staggered-persistent schedule */
 int desta_gemm_force_variant(int variant);
 
 /* ------------------------------------------------------------------------------------------

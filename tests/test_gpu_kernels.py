@@ -61,15 +61,17 @@ def test_gemm_256_tile_variant(hip, M, N, K):
         hip.gemm_force_variant(0)
 
 
-@pytest.mark.parametrize("M,N,K", [(512, 768, 1024), (300, 520, 576), (2560, 1280, 4096), (256, 256, 64)])
+@pytest.mark.parametrize("M,N,K", [(512, 768, 1024), (300, 520, 576), (2560, 1280, 4096), (256, 256, 64), (5120, 4096, 1024),
+                                   (12000, 1280, 512), (4352, 4352, 512)])
 def test_gemm_256_staggered_variant(hip, M, N, K):
-    """Variant 3: waves 4-7 run half a phase behind waves 0-3 (same arithmetic, different barrier schedule)."""
+    """Variants 3 / 4: waves 4-7 run half a phase behind waves 0-3; 4 additionally walks several tiles per block
+    with the LDS-DMA stream continuing across tile boundaries (same arithmetic, different schedules)."""
     g = torch.Generator().manual_seed(M * 3 + N + K)
     A = _bf(torch.randn(M, K, generator=g)).cuda()
     B = _bf(torch.randn(N, K, generator=g)).cuda()
     outs = []
     try:
-        for v in (2, 3):
+        for v in (2, 3, 4):
             hip.gemm_force_variant(v)
             o = torch.empty(M, N, dtype=torch.float32, device="cuda")
             for _ in range(3):                      # repeat: a schedule race would show up as run-to-run differences
@@ -77,7 +79,7 @@ def test_gemm_256_staggered_variant(hip, M, N, K):
             outs.append(o)
     finally:
         hip.gemm_force_variant(0)
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     torch.testing.assert_close(outs[1], A.float() @ B.float().T, rtol=1e-4, atol=2e-3)
 
 
