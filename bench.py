@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--tgt", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--persistent-gemm", action="store_true", help="A/B: enable the persistent GEMM kernel")
+    ap.add_argument("--no-stagger", action="store_true", help="A/B: lockstep GEMM schedule")
+    ap.add_argument("--repeat", type=int, default=1, help="repeat the timed region (reports the best), for A/B runs")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,6 +116,10 @@ def main():
     from desta.synthetic import FULL_CONFIGS, RandomWeights, synthetic_inputs, synthetic_waveform
     from desta.trainer.desta_trainer import DeSTA25Trainer, TrainingArguments
 
+    if a.persistent_gemm:
+        H.gemm_set_option(0, 1)
+    if a.no_stagger:
+        H.gemm_set_option(1, 0)
     cfg = DeSTA25Config(**FULL_CONFIGS[a.config])
     t0 = time.time()
     model = DeSTA25AudioModel(cfg, weights=RandomWeights(cfg, dev, seed=0), device=dev)

@@ -62,8 +62,13 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& p, int z, int m, int n
         *(u16x4*)(p.preact + (long)z * p.sP + (long)m * p.ldp + n0) = o;
     }
     if (p.act == 1) {
+        if (p.out_f32) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        } else {                                           // bf16 store: the 1.5e-7 erf approximation is exact after rounding
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf_fast(v[e]);
+        }
     } else if (p.act == 2) {
         // fused SwiGLU forward on an interleaved gate/up projection: columns (2i, 2i+1) = (gate_i, up_i).
         // C keeps the bf16 pre-activations (saved for backward); aux[m][n0/2 ..] = bf16(silu(g)) * u,
@@ -133,7 +138,7 @@ __device__ __forceinline__ void epilogue_pair_bf16(const GemmArgs& p, int z, int
         }
         if (p.act == 1) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf_fast(v[e]);
         }
         if (p.res) {
             if (p.res_f32) {
@@ -697,6 +702,15 @@ __global__ __launch_bounds__(256) void gemm_splitk_fixup_kernel(GemmArgs p) {
 
 static int g_force_variant = 0;   // 0 auto, 1 = 128x128, 2 = 256x256 lockstep, 3 = staggered, 4 = staggered persistent (tuning / tests)
 extern "C" int desta_gemm_force_variant(int v) { g_force_variant = v; return DESTA_OK; }
+static int g_persistent = 0;      // automatic choice may use the persistent kernel (in-situ A/B: no gain)
+static int g_stagger = 1;         // automatic choice uses the staggered schedule
+extern "C" int desta_gemm_set_persistent(int on) { g_persistent = on; return DESTA_OK; }
+extern "C" int desta_gemm_set_option(int option, int value) {
+    if (option == 0) g_persistent = value;
+    else if (option == 1) g_stagger = value;
+    else { desta_set_error("gemm_set_option: unknown option %d", option); return DESTA_EINVAL; }
+    return DESTA_OK;
+}
 
 extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
     DESTA_CHECK_ARG(d && d->A && d->B && d->C, "gemm: null operand");
@@ -761,8 +775,8 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
         const int items = full + (int)(T - full) * split;
         // variants: 2 = lockstep, 3 = staggered (+4-7 %), 4 = staggered + persistent cross-tile streaming
         //           (default when a block gets more than one item; +3-7 % on the LLM shapes)
-        const bool persistent = g_force_variant == 4 || (g_force_variant == 0 && items > NCU);
-        if (g_force_variant == 2) hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<false>, dim3(items, d->batch), dim3(512), 0, (hipStream_t)stream, a);
+        const bool persistent = g_force_variant == 4 || (g_force_variant == 0 && g_persistent && items > NCU);
+        if (g_force_variant == 2 || (g_force_variant == 0 && !g_stagger)) hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<false>, dim3(items, d->batch), dim3(512), 0, (hipStream_t)stream, a);
         else if (persistent) hipLaunchKernelGGL(gemm_bf16_nt_256p_kernel<true>, dim3(items < NCU ? items : NCU, d->batch), dim3(512), 0, (hipStream_t)stream, a, items);
         else hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<true>, dim3(items, d->batch), dim3(512), 0, (hipStream_t)stream, a);
         if (split > 1)

@@ -404,3 +404,14 @@ def dropout_mask(seed, n, p_drop, device="cuda"):
     out = torch.empty(n, dtype=torch.uint8, device=device)
     check(_dropout_mask(seed, n, p_drop, p(out), stream()), "desta_dropout_mask_u8")
     return out
+
+
+def gemm_set_persistent(on: bool) -> None:
+    lib.desta_gemm_set_persistent.argtypes = [i32]
+    lib.desta_gemm_set_persistent(int(on))
+
+
+def gemm_set_option(option: int, value: int) -> None:
+    """A/B switches of the automatic GEMM choice: 0 = persistent kernel, 1 = staggered schedule."""
+    lib.desta_gemm_set_option.argtypes = [i32, i32]
+    check(lib.desta_gemm_set_option(option, value), "desta_gemm_set_option")

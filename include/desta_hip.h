@@ -69,6 +69,8 @@ int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream);
 /* tuning / tests only: 0 = automatic tile choice, 1 = force 128x128, 2 / 3 / 4 = force the 256x256 kernel with the
  * lockstep / staggered / staggered-persistent schedule */
 int desta_gemm_force_variant(int variant);
+int desta_gemm_set_persistent(int on);   /* 1: the automatic choice uses the persistent kernel when a block owns > 1 item */
+int desta_gemm_set_option(int option, int value);   /* A/B switches of the automatic choice: 0 = persistent, 1 = staggered */
 
 /* ------------------------------------------------------------------------------------------
  * Global-norm clip + Adafactor over a flat fp32 arena.

@@ -98,6 +98,7 @@ def test_full_size_step_properties(hip, full_model):
     batch = synthetic_inputs(cfg, B, 64, 512, "cuda:0", seed=3)
     batch["batch_features"] = hip.logmel(synthetic_waveform(B, "cuda:0", seed=3), 128)
     model.train()
+    model._fwd_count = 0                                                    # dropout stream position (masks depend on it)
     out = model(**batch)
     loss0 = float(out.loss)
     assert abs(loss0 - math.log(cfg.llm_config.vocab_size)) < 1.0           # random init: CE ~ ln V
@@ -105,6 +106,7 @@ def test_full_size_step_properties(hip, full_model):
     g1 = model.arena.grads.clone()
     assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
     model.mark_weights_updated()
+    model._fwd_count = 0                                                    # same masks -> the rerun must be bit-identical
     out = model(**batch)
     model.backward()
     assert float(out.loss) == loss0 and torch.equal(model.arena.grads, g1)  # bit-identical rerun (replica consistency)
