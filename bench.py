@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--tgt", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for rehearsals)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--persistent-gemm", action="store_true", help="A/B: enable the persistent GEMM kernel")
     ap.add_argument("--no-stagger", action="store_true", help="A/B: lockstep GEMM schedule")
     ap.add_argument("--repeat", type=int, default=1, help="repeat the timed region (reports the best), for A/B runs")
@@ -102,10 +104,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.single_device:
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(a.backend)
     if a.gpus != world and rank == 0 and world > 1:
         print(f"[bench] --gpus {a.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
     dev = torch.device(f"cuda:{local}")
@@ -182,13 +189,15 @@ def main():
             traffic = tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"]
         out = {
             "metric": "train steps/sec (node) Whisper-v3+Llama3.1-8B Q-Former6L at 1/2/4/8 MI355X",
-            "value": world * a.steps / elapsed, "unit": "steps/s (per-GPU batches of 8 clips, summed over GPUs)",
+            "value": world * a.steps / elapsed, "unit": "steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{a.config}: {os.path.basename(cfg.encoder_model_id)} + {os.path.basename(cfg.llm_model_id)}, "
                                    f"Q-Former {cfg.qformer_num_hidden_layers}L, per-GPU batch {B} x 30 s clips, "
                                    f"S={S} ({a.ctx} ctx + {cfg.prompt_size} audio + {a.tgt} target tokens), random-init weights at true shapes",
-                       "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}"},
+                       "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}",
+                       "step_definition": "one pass of the hot path over one per-GPU batch; value = per-GPU batch-steps per second "
+                                          "summed over the node (N x K / max-over-ranks time), weak scaling"},
             "final_loss": final_loss,
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_256_kernel (+ gemm_bf16_nt_kernel on small shapes)", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
