@@ -268,14 +268,16 @@ template <int HD, int NORM, bool BWD>
 __global__ __launch_bounds__(256) void rope_k(bf16_t* __restrict__ buf, long ld, int rows, int S, int n_heads, int n_q,
                                               const float* __restrict__ cs, const float* __restrict__ wq,
                                               const float* __restrict__ wk, float eps, const bf16_t* __restrict__ pre,
-                                              long ld_pre) {
+                                              long ld_pre, const int* __restrict__ pos_shift) {
     constexpr int G = HD / 16, H2 = HD / 2;
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     const long grp = gid / G;
     const int j = (int)(gid % G);
     const bool active = grp < (long)rows * n_heads;
     const int row = active ? (int)(grp / n_heads) : 0, head = active ? (int)(grp % n_heads) : 0;
-    const int pos = row % S;
+    // position_ids: arange(S) for every row in training (H7); generate() passes a per-sequence shift
+    // (-left_pad for the prompt, cache_length - left_pad for a decode step) as HF derives them from the mask
+    const int pos = pos_shift ? max(0, row % S + pos_shift[row / S]) : row % S;
     bf16_t* p = buf + (long)row * ld + (long)head * HD;
     float a[8], b[8], c[8], s[8];
     load8(p, 8 * j, 0, a);
@@ -462,6 +464,32 @@ __global__ __launch_bounds__(256) void dropout_mask_k(unsigned slo, unsigned shi
         out[i] = desta_rng32(slo, shi, (unsigned long)i) >= thresh ? 1 : 0;
 }
 
+// greedy decoding: out[r] = argmax_c x[r][c] (first maximum, like torch.argmax), one block per row
+__global__ __launch_bounds__(256) void argmax_bf16_k(const bf16_t* __restrict__ x, long ld, int cols, long* __restrict__ out) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const bf16_t* row = x + (long)blockIdx.x * ld;
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        const float v = bf2f(row[c]);
+        if (v > best) { best = v; idx = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        out[blockIdx.x] = idx;
+    }
+}
+
 int nblocks(long n, int per = 256, int cap = 8192) {
     long b = (n + per - 1) / per;
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -556,7 +584,7 @@ extern "C" int desta_rmsnorm_bwd(const void* dy, const void* x, const float* wei
 
 extern "C" int desta_rope(void* buf, int64_t ld, int rows, int seq, int n_q_heads, int n_kv_heads, int head_dim,
                           const float* cos_sin, const float* q_norm_w, const float* k_norm_w, float eps,
-                          const void* pre_norm, int64_t ld_pre, int backward, void* stream) {
+                          const void* pre_norm, int64_t ld_pre, int backward, const int32_t* pos_shift, void* stream) {
     DESTA_CHECK_ARG(buf && cos_sin, "rope: null argument");
     DESTA_CHECK_ARG(head_dim == 64 || head_dim == 128, "rope: head_dim %d unsupported (64 or 128)", head_dim);
     DESTA_CHECK_ARG(ld % 8 == 0 && rows > 0 && seq > 0, "rope: bad shape");
@@ -567,7 +595,7 @@ extern "C" int desta_rope(void* buf, int64_t ld, int rows, int seq, int n_q_head
     const long nthreads = (long)rows * nh * (head_dim / 16);
     dim3 grid((unsigned)((nthreads + 255) / 256));
     hipStream_t st = (hipStream_t)stream;
-#define ROPE_ARGS grid, dim3(256), 0, st, (bf16_t*)buf, (long)ld, rows, seq, nh, n_q_heads, cos_sin, q_norm_w, k_norm_w, eps, (const bf16_t*)pre_norm, (long)ld_pre
+#define ROPE_ARGS grid, dim3(256), 0, st, (bf16_t*)buf, (long)ld, rows, seq, nh, n_q_heads, cos_sin, q_norm_w, k_norm_w, eps, (const bf16_t*)pre_norm, (long)ld_pre, pos_shift
     if (head_dim == 128) {
         if (!backward) { if (norm) hipLaunchKernelGGL((rope_k<128, 1, false>), ROPE_ARGS); else hipLaunchKernelGGL((rope_k<128, 0, false>), ROPE_ARGS); }
         else { if (norm) hipLaunchKernelGGL((rope_k<128, 2, true>), ROPE_ARGS); else hipLaunchKernelGGL((rope_k<128, 0, true>), ROPE_ARGS); }
@@ -643,5 +671,12 @@ extern "C" int desta_dropout_mask_u8(uint64_t seed, int64_t n, float p, uint8_t*
     hipLaunchKernelGGL(dropout_mask_k, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, (unsigned)seed, (unsigned)(seed >> 32),
                        (long)n, p > 0.f ? desta_drop_thresh(p) : 0u, out);
     DESTA_CHECK_LAUNCH("dropout_mask");
+    return DESTA_OK;
+}
+
+extern "C" int desta_argmax_bf16(const void* x, int64_t ld, int rows, int cols, int64_t* out, void* stream) {
+    DESTA_CHECK_ARG(x && out && rows > 0 && cols > 0, "argmax: bad argument");
+    hipLaunchKernelGGL(argmax_bf16_k, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long)ld, cols, (long*)out);
+    DESTA_CHECK_LAUNCH("argmax_bf16");
     return DESTA_OK;
 }

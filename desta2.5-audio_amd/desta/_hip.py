@@ -186,7 +186,7 @@ _rms_bwd = _sig("desta_rmsnorm_bwd", vp, vp, vp, vp, vp, i32, i32, vp, vp)
 lib.desta_colsum_workspace_floats.restype = c_size_t
 lib.desta_colsum_workspace_floats.argtypes = [i32, i32]
 _colsum = _sig("desta_colsum_bf16", vp, i32, i32, i64, vp, i32, vp, vp)
-_rope = _sig("desta_rope", vp, i64, i32, i32, i32, i32, i32, vp, vp, vp, f32, vp, i64, i32, vp)
+_rope = _sig("desta_rope", vp, i64, i32, i32, i32, i32, i32, vp, vp, vp, f32, vp, i64, i32, vp, vp)
 _swiglu_fwd = _sig("desta_swiglu_fwd", vp, vp, i64, i32, vp)
 _swiglu_bwd = _sig("desta_swiglu_bwd", vp, vp, vp, i64, i32, vp)
 _gelu_bwd = _sig("desta_gelu_bwd", vp, vp, vp, i64, vp)
@@ -237,9 +237,9 @@ def colsum(x, rows, cols, ld, out, accumulate=False):
 
 
 def rope(buf, ld, rows, seq, n_q, n_kv, hd, cos_sin, q_norm_w=None, k_norm_w=None, eps=1e-6, pre_norm=None,
-         ld_pre=0, backward=False):
+         ld_pre=0, backward=False, pos_shift=None):
     check(_rope(p(buf), ld, rows, seq, n_q, n_kv, hd, p(cos_sin), p(q_norm_w), p(k_norm_w), eps, p(pre_norm), ld_pre,
-                int(backward), stream()), "desta_rope")
+                int(backward), p(pos_shift), stream()), "desta_rope")
 
 
 def swiglu_fwd(gate_up, act, rows, inter):
@@ -328,7 +328,8 @@ def _elem_ptr(t, offset_elems):
 
 
 def attn_desc(q, k, v, o, lse, *, batch, hq, hkv, sq, sk, hd, scale, causal=False, kv_start=None,
-              q_off=0, k_off=0, v_off=0, q_rs=None, k_rs=None, v_rs=None, o_rs=None, dropout_p=0.0, dropout_seed=0):
+              q_off=0, k_off=0, v_off=0, q_rs=None, k_rs=None, v_rs=None, o_rs=None, dropout_p=0.0, dropout_seed=0,
+              q_bs=None, k_bs=None, v_bs=None, o_bs=None):
     """q/k/v are 2-D row-major [batch*seq, row_stride] buffers (possibly the same fused buffer);
     *_off = first column of the q/k/v slice."""
     d = AttnDesc()
@@ -338,10 +339,10 @@ def attn_desc(q, k, v, o, lse, *, batch, hq, hkv, sq, sk, hd, scale, causal=Fals
     o_rs = o.shape[-1] if o_rs is None else o_rs
     d.Q, d.K, d.V, d.O = _elem_ptr(q, q_off), _elem_ptr(k, k_off), _elem_ptr(v, v_off), p(o)
     d.lse = p(lse)
-    d.q_row_stride, d.q_batch_stride = q_rs, sq * q_rs
-    d.k_row_stride, d.k_batch_stride = k_rs, sk * k_rs
-    d.v_row_stride, d.v_batch_stride = v_rs, sk * v_rs
-    d.o_row_stride, d.o_batch_stride = o_rs, sq * o_rs
+    d.q_row_stride, d.q_batch_stride = q_rs, (sq * q_rs if q_bs is None else q_bs)
+    d.k_row_stride, d.k_batch_stride = k_rs, (sk * k_rs if k_bs is None else k_bs)     # explicit batch strides: KV cache
+    d.v_row_stride, d.v_batch_stride = v_rs, (sk * v_rs if v_bs is None else v_bs)
+    d.o_row_stride, d.o_batch_stride = o_rs, (sq * o_rs if o_bs is None else o_bs)
     d.batch, d.n_q_heads, d.n_kv_heads, d.seq_q, d.seq_k, d.head_dim = batch, hq, hkv, sq, sk, hd
     d.causal = int(causal)
     d.kv_start = p(kv_start)
@@ -415,3 +416,10 @@ def gemm_set_option(option: int, value: int) -> None:
     """A/B switches of the automatic GEMM choice: 0 = persistent kernel, 1 = staggered schedule."""
     lib.desta_gemm_set_option.argtypes = [i32, i32]
     check(lib.desta_gemm_set_option(option, value), "desta_gemm_set_option")
+
+
+_argmax = _sig("desta_argmax_bf16", vp, i64, i32, i32, vp, vp)
+
+
+def argmax_bf16(x, ld, rows, cols, out):
+    check(_argmax(p(x), ld, rows, cols, p(out), stream()), "desta_argmax_bf16")

@@ -67,6 +67,7 @@ class LLMConfig:
     rope_theta: float = 500000.0
     rope_scaling: Optional[dict] = None          # {"rope_type":"llama3","factor":8,"low_freq_factor":1,...} or None
     tie_word_embeddings: bool = False
+    eos_token_id: Optional[List[int]] = None     # generation stops on any of these (HF generation_config semantics)
 
     @property
     def qk_norm(self) -> bool:
@@ -139,7 +140,9 @@ class DeSTA25Config:
             head_dim=c.get("head_dim") or c["hidden_size"] // heads, intermediate_size=c["intermediate_size"],
             vocab_size=c["vocab_size"], rms_norm_eps=c.get("rms_norm_eps", 1e-5),
             rope_theta=float(c.get("rope_theta", rp.get("rope_theta", 10000.0))), rope_scaling=scaling,
-            tie_word_embeddings=bool(c.get("tie_word_embeddings", False)))
+            tie_word_embeddings=bool(c.get("tie_word_embeddings", False)),
+            eos_token_id=(None if c.get("eos_token_id") is None else
+                          [int(t) for t in (c["eos_token_id"] if isinstance(c["eos_token_id"], (list, tuple)) else [c["eos_token_id"]])]))
 
     def to_dict(self) -> dict:
         return {"model_type": self.model_type, "llm_model_id": self.llm_model_id, "encoder_model_id": self.encoder_model_id,
@@ -614,19 +617,23 @@ class CausalLMHIP:
         self.dqkv = b16(M, self.qkvw)
         self.datt = b16(M, self.hq * self.hd)
 
-    def forward(self, x0_filler, B: int, S: int, kv_start: Optional[torch.Tensor], labels: Optional[torch.Tensor], need_grad: bool):
-        """`x0_filler(buf)` writes inputs_embeds [B*S, h] bf16 into buf.  Returns (loss tensor|None, logits view)."""
+    def forward(self, x0_filler, B: int, S: int, kv_start: Optional[torch.Tensor], labels: Optional[torch.Tensor], need_grad: bool,
+                pos_shift: Optional[torch.Tensor] = None, cos_sin: Optional[torch.Tensor] = None, last_logits: Optional[torch.Tensor] = None):
+        """`x0_filler(buf)` writes inputs_embeds [B*S, h] bf16 into buf.  Returns the logits buffer [B*S, Vp].
+        Training uses position_ids = arange(S) (H7); generate() passes pos_shift (= -left_pad per sequence, with a
+        `cos_sin` table that also covers the new tokens) and `last_logits` [B, Vp] to project only the last row."""
         if (B, S) != (self.B, self.S):
             self._alloc(B, S)
         c, h, M = self.c, self.h, self.M
         x0_filler(self.xs[0])
         self.kv_start = kv_start
         scale = self.hd ** -0.5
+        cs = self.cos_sin if cos_sin is None else cos_sin
         for i, (ly, s) in enumerate(zip(self.layers, self.sv)):
             x = self.xs[i]
             H.rmsnorm_fwd(x, ly["n1"], c.rms_norm_eps, self.hb, s["r1"])
             H.gemm(self.hb, ly["wqkv"], s["qkv"], M, self.qkvw, h, preact=s.get("pre"))
-            H.rope(s["qkv"], self.qkvw, M, S, self.hq, self.hkv, self.hd, self.cos_sin, ly.get("qn"), ly.get("kn"), c.rms_norm_eps)
+            H.rope(s["qkv"], self.qkvw, M, S, self.hq, self.hkv, self.hd, cs, ly.get("qn"), ly.get("kn"), c.rms_norm_eps, pos_shift=pos_shift)
             ad = H.attn_desc(s["qkv"], s["qkv"], s["qkv"], s["att"], s["lse"], batch=B, hq=self.hq, hkv=self.hkv, sq=S, sk=S, hd=self.hd,
                              scale=scale, causal=True, kv_start=kv_start, q_off=0, k_off=self.hq * self.hd, v_off=(self.hq + self.hkv) * self.hd)
             H.attention_fwd(ad)
@@ -639,8 +646,106 @@ class CausalLMHIP:
             H.swiglu_fwd(s["gu"], self.act, M, self.I)
             H.gemm(self.act, ly["wd"], self.xs[i + 1], M, h, self.I, residual=s["xm"])
         H.rmsnorm_fwd(self.xs[self.L], self.norm, c.rms_norm_eps, self.hb, self.rf)
+        if last_logits is not None:                      # rows b*S + S-1 only: A is a strided view of hb
+            H.gemm(self.hb[S - 1:], self.head, last_logits, B, self.V, h, lda=S * h, ldc=self.Vp)
+            return last_logits
         H.gemm(self.hb, self.head, self.logits, M, self.V, h, ldc=self.Vp)
         return self.logits
+
+    # -- greedy decoding with a KV cache (reference: llm_model.generate, modeling_desta25.py:1419) ------
+    def _gen_alloc(self, B: int, Smax: int):
+        if getattr(self, "_gen_shape", None) == (B, Smax):
+            return
+        dev, h = self.dev, self.h
+
+        def b16(*s):
+            return torch.empty(*s, dtype=BF16, device=dev)
+        self._gen_shape = (B, Smax)
+        self.kvw = 2 * self.hkv * self.hd
+        # one [B, Smax, K|V] slab per layer: a decode step reads keys/values with row stride kvw, batch stride Smax*kvw
+        self.kv_cache = [b16(B, Smax, self.kvw) for _ in range(self.L)]
+        fr = torch.outer(torch.arange(Smax, device=dev, dtype=F32), self.inv_freq)
+        self.gen_cos_sin = torch.stack([fr.cos(), fr.sin()], dim=1).contiguous()
+        self.g_x, self.g_xm, self.g_hb = b16(B, h), b16(B, h), b16(B, h)
+        self.g_qkv, self.g_att = b16(B, self.qkvw), b16(B, self.hq * self.hd)
+        self.g_lse = torch.empty(B, self.hq, 1, dtype=F32, device=dev)
+        self.g_gu, self.g_act = b16(B, 2 * self.I), b16(B, self.I)
+        self.g_r = torch.empty(B, dtype=F32, device=dev)
+        self.g_logits = torch.zeros(B, self.Vp, dtype=BF16, device=dev)
+        self.g_next = torch.zeros(B, dtype=torch.int64, device=dev)
+
+    def decode_step(self, tokens: torch.Tensor, cur: int, kv_start: torch.Tensor, pos_shift: torch.Tensor) -> torch.Tensor:
+        """One token per sequence: `tokens` [B] (ids) sit at cache slot `cur`; returns logits [B, Vp] for slot cur+1."""
+        c, h, B = self.c, self.h, self._gen_shape[0]
+        Smax = self._gen_shape[1]
+        koff, scale = self.hq * self.hd, self.hd ** -0.5
+        H.embed_gather(self.embed, None, tokens.to(torch.int32), B, h, self.g_x)
+        x = self.g_x
+        for ly, cache in zip(self.layers, self.kv_cache):
+            H.rmsnorm_fwd(x, ly["n1"], c.rms_norm_eps, self.g_hb, self.g_r)
+            H.gemm(self.g_hb, ly["wqkv"], self.g_qkv, B, self.qkvw, h)
+            H.rope(self.g_qkv, self.qkvw, B, 1, self.hq, self.hkv, self.hd, self.gen_cos_sin, ly.get("qn"), ly.get("kn"), c.rms_norm_eps,
+                   pos_shift=pos_shift)
+            cache[:, cur].copy_(self.g_qkv[:, koff:])                                          # append K|V (device memcpy)
+            ad = H.attn_desc(self.g_qkv, cache, cache, self.g_att, self.g_lse, batch=B, hq=self.hq, hkv=self.hkv, sq=1, sk=cur + 1,
+                             hd=self.hd, scale=scale, causal=False, kv_start=kv_start, q_off=0, k_off=0, v_off=self.hkv * self.hd,
+                             q_rs=self.qkvw, k_rs=self.kvw, v_rs=self.kvw, o_rs=self.hq * self.hd,
+                             q_bs=self.qkvw, k_bs=Smax * self.kvw, v_bs=Smax * self.kvw, o_bs=self.hq * self.hd)
+            H.attention_fwd(ad)
+            H.gemm(self.g_att, ly["wo"], self.g_xm, B, h, self.hq * self.hd, residual=x)
+            H.rmsnorm_fwd(self.g_xm, ly["n2"], c.rms_norm_eps, self.g_hb, self.g_r)
+            H.gemm(self.g_hb, ly["wgu"], self.g_gu, B, 2 * self.I, h)
+            H.swiglu_fwd(self.g_gu, self.g_act, B, self.I)
+            H.gemm(self.g_act, ly["wd"], self.g_x, B, h, self.I, residual=self.g_xm)
+        H.rmsnorm_fwd(self.g_x, self.norm, c.rms_norm_eps, self.g_hb, self.g_r)
+        H.gemm(self.g_hb, self.head, self.g_logits, B, self.V, h, ldc=self.Vp)
+        return self.g_logits
+
+    def generate_greedy(self, x0_filler, B: int, S: int, kv_start: torch.Tensor, max_new_tokens: int, pad_token_id: int,
+                        eos_token_ids=None, forced_tokens: Optional[torch.Tensor] = None, collect_logits: bool = False):
+        """Prompt pass + KV-cached greedy decode.  Returns new token ids [B, n_new] (int64; finished sequences are
+        filled with pad_token_id, generation stops early once every sequence has produced an EOS), and, with
+        collect_logits, the per-step logits [n_new, B, V] (bf16).  `forced_tokens` [B, T] teacher-forces the
+        continuation (parity tests compare per-step logits with the oracle on the same prefix)."""
+        assert max_new_tokens >= 1
+        Smax = S + max_new_tokens
+        self._gen_alloc(B, Smax)
+        dev = self.dev
+        kv_start = kv_start.to(torch.int32).contiguous()
+        neg_pad = (-kv_start).contiguous()                                   # prompt: position = index - left_pad
+        logits = self.forward(x0_filler, B, S, kv_start, None, False, pos_shift=neg_pad, cos_sin=self.gen_cos_sin, last_logits=self.g_logits)
+        koff = self.hq * self.hd
+        for s, cache in zip(self.sv, self.kv_cache):
+            cache[:, :S].copy_(s["qkv"].view(B, S, self.qkvw)[:, :, koff:])
+        out = torch.full((B, max_new_tokens), int(pad_token_id), dtype=torch.int64, device=dev)
+        steps_logits = []
+        finished = torch.zeros(B, dtype=torch.bool, device=dev)
+        eos = None if not eos_token_ids else torch.tensor(list(eos_token_ids), dtype=torch.int64, device=dev)
+        n_new = 0
+        for t in range(max_new_tokens):
+            if collect_logits:
+                steps_logits.append(logits[:, :self.V].clone())
+            H.argmax_bf16(logits, self.Vp, B, self.V, self.g_next)
+            nxt = self.g_next if forced_tokens is None else forced_tokens[:, t].to(dev, torch.int64)
+            nxt = torch.where(finished, torch.full_like(nxt, int(pad_token_id)), nxt)
+            out[:, t] = nxt
+            n_new = t + 1
+            if eos is not None:
+                finished |= (nxt.unsqueeze(1) == eos.unsqueeze(0)).any(dim=1)
+                if (t & 7) == 7 and bool(finished.all()):                    # host sync only every 8 tokens
+                    break
+            if t + 1 == max_new_tokens:
+                break
+            cur = S + t
+            shift = (cur - kv_start).to(torch.int32).contiguous()            # decode: position = slot - left_pad
+            logits = self.decode_step(nxt, cur, kv_start, shift)
+        if eos is not None and n_new > 1:                                    # trim columns after every sequence finished
+            done_at = (out.unsqueeze(2) == eos.view(1, 1, -1)).any(dim=2).int().argmax(dim=1)
+            has = (out.unsqueeze(2) == eos.view(1, 1, -1)).any(dim=2).any(dim=1)
+            last = int(torch.where(has, done_at + 1, torch.full_like(done_at, n_new)).max())
+            n_new = min(n_new, last)
+        out = out[:, :n_new]
+        return (out, torch.stack(steps_logits[:n_new])) if collect_logits else out
 
     def loss_and_grad(self, labels: torch.Tensor, write_grad: bool) -> torch.Tensor:
         """ForCausalLMLoss on the logits of the last forward; with write_grad the logits buffer becomes dlogits."""
@@ -858,6 +963,65 @@ class DeSTA25AudioModel:
         return _Out(loss, out_logits)
 
     __call__ = forward
+
+    @torch.no_grad()
+    def _generate_step(self, inputs, pad_token_id, temperature=0.7, top_p=0.9, max_new_tokens=512, do_sample=True,
+                       eos_token_id=None, forced_tokens=None, collect_logits=False):
+        """Reference `_generate_step` (modeling_desta25.py:1358-1431): audio features spliced into the prompt
+        embeddings, then `llm_model.generate(inputs_embeds=…)` — here the KV-cached greedy decoder on the HIP path.
+        Returns ONLY the new tokens, as HF does for inputs_embeds prompts.  Sampling (do_sample=True: temperature /
+        top-p) is not implemented on this path; the trainer's evaluation configs all use do_sample=False."""
+        if do_sample:
+            raise NotImplementedError("do_sample=True (temperature / top-p sampling) is not implemented on the MI355X path; "
+                                      "pass do_sample=False for greedy decoding")
+        cfg, dev = self.config, self.device
+        input_ids = inputs["context_input_ids"].to(dev)                      # only the context (prompt) part of the batch
+        attention_mask = inputs["context_attention_mask"].to(dev)
+        B, S = input_ids.shape
+        starts = inputs["context_batch_start_positions"]
+        N_audio = len(starts)
+        was_training = self.training
+        self.training = False                                                # no Q-Former dropout while generating
+        try:
+            with torch.cuda.device(dev):
+                if self._weights_dirty:
+                    self.connector.refresh_weights()
+                    self._weights_dirty = False
+                af = None
+                if N_audio > 0:
+                    feats = inputs["batch_features"]
+                    trs = [t.to(dev) for t in inputs["batch_transcription_ids"]]
+                    assert len(starts) == len(trs) == feats.shape[0]
+                    e, nt = cfg.encoder_config, len(cfg.target_layer_ids)
+                    if self.enc_all is None or self.enc_all.shape[1] != N_audio * e.max_source_positions:
+                        self.enc_all = torch.empty(nt, N_audio * e.max_source_positions, e.d_model, dtype=BF16, device=dev)
+                    self.encoder.forward(feats.to(dev, F32).contiguous(), self.enc_all)
+                    self._enc_prefetched = None
+                    self.connector.p_drop = 0.0
+                    af = self.connector.forward(self.enc_all, N_audio)
+                    src = self._src_rows(input_ids, trs, starts, None)
+                else:
+                    src = input_ids.to(torch.int32).reshape(-1).contiguous()
+                kv_start = (attention_mask == 0).sum(dim=1).to(torch.int32).contiguous()
+                h = cfg.llm_config.hidden_size
+
+                def fill(buf):
+                    H.embed_gather(self.llm.embed, af, src, B * S, h, buf)
+                eos = eos_token_id if eos_token_id is not None else cfg.llm_config.eos_token_id
+                if isinstance(eos, int):
+                    eos = [eos]
+                self._fwd = None
+                return self.llm.generate_greedy(fill, B, S, kv_start, int(max_new_tokens), int(pad_token_id), eos,
+                                                forced_tokens=forced_tokens, collect_logits=collect_logits)
+        finally:
+            self.training = was_training
+
+    def generate(self, messages, *args, **kwargs):
+        """The reference's chat-level `generate` (modeling_desta25.py:1491-1730) also runs the tokenizer, the
+        Whisper processor, optional VAD and Whisper ASR on audio FILES; none of that is on the MI355X hot path.
+        Build the batch with the reference's processor/collate code and call `_generate_step(batch, …)`."""
+        raise NotImplementedError("chat-level generate() (tokenizer + audio-file front end) is out of scope of the MI355X hot path; "
+                                  "use _generate_step(inputs, pad_token_id, do_sample=False, max_new_tokens=…) on a collated batch")
 
     def prefetch_encoder(self, batch_features: torch.Tensor) -> None:
         """Run the FROZEN Whisper encoder for the next batch now (it does not depend on the connector

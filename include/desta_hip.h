@@ -143,10 +143,12 @@ int desta_colsum_bf16(const void* x, int rows, int cols, int64_t ld, float* out,
  * TF:models/llama/modeling_llama.py:386-389); cos_sin = fp32 [seq][2][head_dim/2].
  * With q_norm_w/k_norm_w != NULL the Qwen3 per-head RMSNorm (TF:models/qwen3/modeling_qwen3.py:237-257)
  * runs first (forward) / is differentiated (backward, needs the saved pre-norm q|k in pre_norm).
- * backward != 0 applies the transposed rotation to gradients. head_dim 64 or 128. */
+ * backward != 0 applies the transposed rotation to gradients. head_dim 64 or 128.
+ * pos_shift (int32 [rows/seq] or NULL): position = max(0, row % seq + pos_shift[row / seq]) — generate() derives
+ * position_ids from the attention mask (prompt: -left_pad; decode step: cache_len - left_pad). */
 int desta_rope(void* buf, int64_t ld, int rows, int seq, int n_q_heads, int n_kv_heads, int head_dim,
                const float* cos_sin, const float* q_norm_w, const float* k_norm_w, float eps,
-               const void* pre_norm, int64_t ld_pre, int backward, void* stream);
+               const void* pre_norm, int64_t ld_pre, int backward, const int32_t* pos_shift, void* stream);
 
 /* SwiGLU on a fused [rows, 2*inter] gate|up buffer (LlamaMLP, TF:models/llama/modeling_llama.py:163-176),
  * GELU'(erf) for the Q-Former FFN backward, and small layout helpers. */
@@ -233,6 +235,10 @@ int desta_prompt_grad(const float* dx, int taps, int batch, int64_t n, float* dp
  * (TF:models/bert/modeling_bert.py:150-160, 296, 350; BertConfig defaults 0.1, modeling_desta25.py:156). */
 int desta_dropout_bf16(const void* x, void* y, int rows, int cols, int64_t ld, float p, uint64_t seed, void* stream);
 int desta_dropout_mask_u8(uint64_t seed, int64_t n, float p, uint8_t* out, void* stream);
+
+/* Greedy decoding helper: out[r] = argmax over the first `cols` entries of bf16 row r (first maximum).
+ * Replaces the argmax of `llm_model.generate(do_sample=False)` (modeling_desta25.py:1419). */
+int desta_argmax_bf16(const void* x, int64_t ld, int rows, int cols, int64_t* out, void* stream);
 
 #ifdef __cplusplus
 }

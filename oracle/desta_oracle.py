@@ -385,15 +385,21 @@ def _rot_half(x):
     return torch.cat([-x[..., h:], x[..., :h]], dim=-1)
 
 
-def llm_forward(w, d: Dims, inputs_embeds: Tensor, attention_mask: Tensor, keep: Optional[dict] = None) -> Tensor:
-    """Returns logits [B,S,V].  position_ids = arange(S) for every row (H7); additive causal mask
-    AND left-pad key mask, as ``create_causal_mask`` builds it."""
+def llm_forward(w, d: Dims, inputs_embeds: Tensor, attention_mask: Tensor, keep: Optional[dict] = None,
+                position_ids: Optional[Tensor] = None) -> Tensor:
+    """Returns logits [B,S,V].  position_ids = arange(S) for every row (H7) unless given ([B,S], the
+    generate() path); additive causal mask AND left-pad key mask, as ``create_causal_mask`` builds it."""
     B, S, _ = inputs_embeds.shape
     x = inputs_embeds
-    pos = torch.arange(S, dtype=torch.float32)
-    fr = torch.outer(pos, rope_inv_freq(d))
-    cos = torch.cat([fr, fr], -1).cos()[None, None]
-    sin = torch.cat([fr, fr], -1).sin()[None, None]
+    if position_ids is None:
+        pos = torch.arange(S, dtype=torch.float32)
+        fr = torch.outer(pos, rope_inv_freq(d))
+        cos = torch.cat([fr, fr], -1).cos()[None, None]
+        sin = torch.cat([fr, fr], -1).sin()[None, None]
+    else:
+        fr = position_ids.float()[:, :, None] * rope_inv_freq(d)[None, None, :]            # [B,S,hd/2]
+        cos = torch.cat([fr, fr], -1).cos()[:, None]
+        sin = torch.cat([fr, fr], -1).sin()[:, None]
     neg = torch.finfo(torch.float32).min
     causal = torch.ones(S, S, dtype=torch.bool).tril()
     allowed = causal[None, None] & attention_mask.bool()[:, None, None, :]
@@ -426,6 +432,39 @@ def llm_forward(w, d: Dims, inputs_embeds: Tensor, attention_mask: Tensor, keep:
     x = _rmsnorm(x, w[LLM + "model.norm.weight"], d.rms_eps)
     head = w[LLM + "model.embed_tokens.weight"] if d.tie_embeddings else w[LLM + "lm_head.weight"]
     return F.linear(x, head)
+
+
+def generation_position_ids(attention_mask: Tensor) -> Tensor:
+    """``GenerationMixin._prepare_position_ids_for_generation`` (TF:generation/utils.py:751-773):
+    cumsum(mask) - 1, pads at 0."""
+    pos = attention_mask.long().cumsum(-1) - 1
+    return pos.masked_fill(attention_mask == 0, 0)
+
+
+def greedy_generate(w, d: Dims, inputs_embeds: Tensor, attention_mask: Tensor, max_new_tokens: int, pad_token_id: int,
+                    eos_token_ids: Optional[List[int]] = None, forced_tokens: Optional[Tensor] = None):
+    """Restatement of ``llm_model.generate(inputs_embeds=…, attention_mask=…, do_sample=False)``
+    (reference call site modeling_desta25.py:1419-1427) WITHOUT a KV cache: every step re-runs the whole
+    prefix, so the result is what any correct cache must reproduce.  Returns (new tokens [B,n], per-step
+    logits [n,B,V]).  Finished sequences emit pad_token_id; stops once all sequences have emitted an EOS."""
+    B = inputs_embeds.shape[0]
+    emb = w[LLM + "model.embed_tokens.weight"]
+    x, mask = inputs_embeds, attention_mask.long()
+    unfinished = torch.ones(B, dtype=torch.long)
+    toks, step_logits = [], []
+    for t in range(max_new_tokens):
+        logits = llm_forward(w, d, x, mask, position_ids=generation_position_ids(mask))[:, -1]
+        step_logits.append(logits)
+        nxt = logits.argmax(-1) if forced_tokens is None else forced_tokens[:, t]
+        nxt = nxt * unfinished + pad_token_id * (1 - unfinished)
+        toks.append(nxt)
+        if eos_token_ids:
+            unfinished = unfinished & ~torch.isin(nxt, torch.tensor(eos_token_ids)).long()
+            if int(unfinished.max()) == 0:
+                break
+        x = torch.cat([x, emb[nxt][:, None]], 1)
+        mask = torch.cat([mask, torch.ones(B, 1, dtype=torch.long)], 1)
+    return torch.stack(toks, 1), torch.stack(step_logits)
 
 
 def causal_lm_loss(logits: Tensor, labels: Tensor) -> Tensor:

@@ -166,6 +166,25 @@ def main():
                 "conn_states": torch.stack(states), "conn_out": conn_out.contiguous()}
         for n, gv in grads.items():
             blob["grad::" + n] = gv.contiguous()
+        # greedy generation through the reference's own _generate_step (modeling_desta25.py:1358-1431): the context is
+        # the left-padded prompt up to 3 tokens past the audio span; once without EOS, once with an EOS that row 0
+        # emits as its 4th token (so the finished-row padding / early-stop rules are part of the golden)
+        n_ctx = batch["input_ids"].shape[1] - 12 + 3
+        gen_inputs = {"context_input_ids": batch["input_ids"][:, :n_ctx], "context_attention_mask": batch["attention_mask"][:, :n_ctx],
+                      "context_batch_start_positions": starts, "batch_transcription_ids": batch["batch_transcription_ids"],
+                      "batch_features": batch["batch_features"]}
+        with torch.no_grad():
+            model.llm_model.generation_config.eos_token_id = None
+            gen = model._generate_step(gen_inputs, pad_token_id=0, max_new_tokens=10, do_sample=False)
+            eos = int(gen[0, 3])
+            model.llm_model.generation_config.eos_token_id = eos
+            gen_eos = model._generate_step(gen_inputs, pad_token_id=0, max_new_tokens=10, do_sample=False)
+        assert gen.shape == (2, 10), gen.shape
+        blob["gen_ctx_len"] = torch.tensor([n_ctx])
+        blob["gen_ids"] = gen.contiguous()
+        blob["gen_eos_id"] = torch.tensor([eos])
+        blob["gen_ids_eos"] = gen_eos.contiguous()
+        print(name, "generate:", gen.tolist(), "| eos", eos, "->", gen_eos.tolist())
         # only the trainable weights + seed are stored; frozen weights are regenerated from seed 7
         path = os.path.join(HERE, f"ref_tiny_{name}.safetensors")
         save_file({k: v.contiguous() for k, v in blob.items()}, path)

@@ -43,6 +43,29 @@ def test_oracle_matches_reference_forward_backward(golden_dir, name):
         torch.testing.assert_close(w[n].grad, gr, rtol=2e-3, atol=1e-6 + 1e-4 * float(gr.abs().max()))
 
 
+@pytest.mark.parametrize("name", ["llama", "qwen3"])
+def test_oracle_greedy_generate_matches_reference(golden_dir, name):
+    """oracle.greedy_generate (cache-free) == the reference's _generate_step token for token, with and without EOS."""
+    g = _load(golden_dir, name)
+    d = O.tiny_dims(name == "qwen3")
+    w = O.init_weights(d, seed=7)
+    n_ctx = int(g["gen_ctx_len"])
+    ids, am = g["input_ids"][:, :n_ctx], g["attention_mask"][:, :n_ctx]
+    starts = [(int(b), int(s)) for b, s in g["starts"].tolist()]
+    with torch.no_grad():
+        af = O.perception(w, d, g["batch_features"])
+        x = O.embed_splice(w, d, ids, af, [torch.zeros(1, 0, dtype=torch.long) for _ in starts], starts)
+        toks, logits = O.greedy_generate(w, d, x, am, 10, pad_token_id=0)
+        assert toks.tolist() == g["gen_ids"].tolist()
+        assert logits.shape == (10, 2, d.vocab)
+        toks_e, _ = O.greedy_generate(w, d, x, am, 10, pad_token_id=0, eos_token_ids=[int(g["gen_eos_id"])])
+        assert toks_e.tolist() == g["gen_ids_eos"].tolist()
+        # teacher forcing with the free-running tokens reproduces them
+        toks_f, logits_f = O.greedy_generate(w, d, x, am, 10, pad_token_id=0, forced_tokens=g["gen_ids"])
+        assert toks_f.tolist() == g["gen_ids"].tolist()
+        torch.testing.assert_close(logits_f, logits)
+
+
 def test_oracle_connector_matches_reference_standalone(golden_dir):
     g = _load(golden_dir, "llama")
     d = O.tiny_dims(False)
