@@ -698,6 +698,109 @@ __global__ __launch_bounds__(256) void gemm_splitk_fixup_kernel(GemmArgs p) {
     if (m < p.M && n0 < p.N) epilogue4(p, z, m, n0, acc);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Skinny GEMM, M <= 16 (the projections of a KV-cached decode step: M = batch).  Pure weight streaming, bound
+// by HBM: every weight byte is read once, 2*M flops per weight element.  One block owns COLS output columns;
+// its 8 waves walk K in interleaved 64-element chunks, so at any moment the block reads COLS rows x 1 KiB of
+// contiguous weight bytes (each lane 2 x 16 B of one row; 4 lanes = 128 B per row per wave).  The WEIGHT
+// tile is the MFMA A operand (rows = n) and the activations the B operand (cols = m): a lane then owns 4
+// consecutive n of one row m, which is exactly what epilogue4 stores.  k inside a chunk is permuted
+// (lane group g holds k = 16g..16g+15, first 8 in MFMA 0, last 8 in MFMA 1) identically for both operands.
+// COLS = 32/64 reuse one activation fragment for 2/4 weight tiles (fewer L2 loads per HBM byte; used when N
+// is large enough to still fill the chip).  The K loop is software pipelined over two register stages of U
+// chunks: the loads of group i+1 are in flight while group i feeds the MFMAs, so a block streams continuously
+// instead of paying one memory latency per group.  Partial sums of the 8 waves are reduced through LDS in
+// fixed order (deterministic).
+template <int COLS, int U>
+struct SkinnyStage {
+    bf16x8 w0[U][COLS / 16], w1[U][COLS / 16], x0[U], x1[U];
+};
+
+// SWIGLU: B holds gate rows [0,N) and up rows [N,2N) (the concatenated gate|up projection); a block owns 8 output
+// columns and streams the 8 gate + 8 matching up rows, the epilogue stores bf16(silu(gate)) * up to C[M,N] with the
+// rounding points of the unfused path (projection rounded to bf16, then swiglu_fwd).
+template <int COLS, int U, bool NT, bool SWIGLU>
+__global__ __launch_bounds__(512) void gemm_bf16_nt_skinny_kernel(GemmArgs p) {
+#define SK_WLOAD(P) (NT ? __builtin_nontemporal_load(P) : *(P))
+    static_assert(!SWIGLU || COLS == 16, "SwiGLU pairing uses one 16-row weight tile");
+    constexpr int T = COLS / 16;
+    __shared__ f32x4 red[8][T][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, z = blockIdx.y;
+    const int n0 = blockIdx.x * (SWIGLU ? 8 : COLS);
+    const int r = lane & 15, g = lane >> 4;
+    const bool mok = r < p.M;
+    const bf16_t* bp[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {                                        // clamped rows are computed, never stored
+        const int wrow = SWIGLU ? (r < 8 ? min(n0 + r, p.N - 1) : p.N + min(n0 + r - 8, p.N - 1)) : min(n0 + t * 16 + r, p.N - 1);
+        bp[t] = p.B + (long)z * p.sB + (long)wrow * p.ldb + g * 16;
+    }
+    const bf16_t* ap = p.A + (long)z * p.sA + (long)(mok ? r : 0) * p.lda + g * 16;
+    const int nchunks = p.K >> 6;
+    f32x4 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    SkinnyStage<COLS, U> sa, sb;
+
+#define SK_LOAD(S, C0)                                                                  \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                     \
+        const int cc = (C0) + 8 * u;                                                    \
+        if (cc < nchunks) {                                                             \
+            _Pragma("unroll") for (int t = 0; t < T; ++t) {                             \
+                S.w0[u][t] = SK_WLOAD((const bf16x8*)(bp[t] + (long)cc * 64));          \
+                S.w1[u][t] = SK_WLOAD((const bf16x8*)(bp[t] + (long)cc * 64 + 8));      \
+            }                                                                           \
+            S.x0[u] = *(const bf16x8*)(ap + (long)cc * 64);                             \
+            S.x1[u] = *(const bf16x8*)(ap + (long)cc * 64 + 8);                         \
+        }                                                                               \
+    }
+#define SK_MMA(S, C0)                                                                   \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                     \
+        if ((C0) + 8 * u < nchunks) {                                                   \
+            const bf16x8 zero = {};                                                     \
+            const bf16x8 a0 = mok ? S.x0[u] : zero, a1 = mok ? S.x1[u] : zero;          \
+            _Pragma("unroll") for (int t = 0; t < T; ++t) {                             \
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(S.w0[u][t], a0, acc[t], 0, 0, 0); \
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(S.w1[u][t], a1, acc[t], 0, 0, 0); \
+            }                                                                           \
+        }                                                                               \
+    }
+    constexpr int STEP = 8 * U;
+    SK_LOAD(sa, wave)
+    for (int c = wave; c < nchunks; c += 2 * STEP) {
+        SK_LOAD(sb, c + STEP)
+        SK_MMA(sa, c)
+        SK_LOAD(sa, c + 2 * STEP)
+        SK_MMA(sb, c + STEP)
+    }
+#undef SK_LOAD
+#undef SK_MMA
+#undef SK_WLOAD
+#pragma unroll
+    for (int t = 0; t < T; ++t) red[wave][t][lane] = acc[t];
+    __syncthreads();
+    if (wave < T) {                                                      // wave t finishes column tile t
+        f32x4 s = red[0][wave][lane];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) s += red[w][wave][lane];
+        if (SWIGLU) {
+            // lane groups 0,1 hold gate columns n0+4g.., groups 2,3 the matching up columns: fetch up from lane+32
+            u16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float up = __shfl(s[e], (lane + 32) & 63, 64);
+                const float gt = bf2f(f2bf(s[e] * p.alpha)), u = bf2f(f2bf(up * p.alpha));
+                o[e] = f2bf(bf2f(f2bf(gt / (1.0f + __expf(-gt)))) * u);
+            }
+            const int n = n0 + g * 4;
+            if (mok && g < 2 && n < p.N) *(u16x4*)((bf16_t*)p.C + (long)z * p.sC + (long)r * p.ldc + n) = o;
+        } else {
+            const int n = n0 + wave * 16 + g * 4;
+            if (mok && n < p.N) epilogue4(p, z, r, n, s);
+        }
+    }
+}
+
 }  // namespace
 
 static int g_force_variant = 0;   // 0 auto, 1 = 128x128, 2 = 256x256 lockstep, 3 = staggered, 4 = staggered persistent (tuning / tests)
@@ -705,9 +808,19 @@ extern "C" int desta_gemm_force_variant(int v) { g_force_variant = v; return DES
 static int g_persistent = 0;      // automatic choice may use the persistent kernel (in-situ A/B: no gain)
 static int g_stagger = 1;         // automatic choice uses the staggered schedule
 extern "C" int desta_gemm_set_persistent(int on) { g_persistent = on; return DESTA_OK; }
+static int g_skinny = 0;          // 0 auto, else COLS*10 + U of the skinny (M <= 16) kernel (tuning)
+static int g_skinny_nt = 0;       // skinny kernel streams the weights with non-temporal loads
 extern "C" int desta_gemm_set_option(int option, int value) {
     if (option == 0) g_persistent = value;
     else if (option == 1) g_stagger = value;
+    else if (option == 2) {
+        if (value != 0 && value != 162 && value != 164 && value != 322 && value != 641) {
+            desta_set_error("gemm_set_option: skinny variant %d unknown (COLS*10+U: 162 164 322 641)", value);
+            return DESTA_EINVAL;
+        }
+        g_skinny = value;
+    }
+    else if (option == 3) g_skinny_nt = value;
     else { desta_set_error("gemm_set_option: unknown option %d", option); return DESTA_EINVAL; }
     return DESTA_OK;
 }
@@ -738,8 +851,8 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
     a.drop_thresh = d->dropout_p > 0.f ? desta_drop_thresh(d->dropout_p) : 0u;
     a.drop_scale = 1.0f / (1.0f - d->dropout_p);
     a.seed_lo = (unsigned)d->dropout_seed; a.seed_hi = (unsigned)(d->dropout_seed >> 32);
-    DESTA_CHECK_ARG(d->act >= 0 && d->act <= 3, "gemm: unknown act %d", d->act);
-    DESTA_CHECK_ARG(d->act < 2 || (d->aux && !d->out_f32 && !d->bias && !d->residual && !d->preact && d->ld_aux % 8 == 0),
+    DESTA_CHECK_ARG(d->act >= 0 && d->act <= 4, "gemm: unknown act %d", d->act);
+    DESTA_CHECK_ARG(d->act < 2 || d->act == 4 || (d->aux && !d->out_f32 && !d->bias && !d->residual && !d->preact && d->ld_aux % 8 == 0),
                     "gemm: SwiGLU epilogues need aux, bf16 output and no bias/residual/preact");
     DESTA_CHECK_ARG(d->act != 3 || d->ldc % 8 == 0, "gemm: act 3 needs ldc (2N-wide rows) to be a multiple of 8");
     // Tile choice.  The 256x256 8-phase kernel runs ONE block per CU, so the tile grid executes in rounds
@@ -759,6 +872,31 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
             if (sp > nk / 16) sp = nk / 16;              // >= 16 K-tiles per slice, or the 7-half-tile prologue dominates
             if (sp >= 2 && (size_t)rem * sp * 256 * 256 * sizeof(float) <= d->workspace_bytes) { split = sp; full = (int)(T - rem); }
         }
+    }
+    if (d->act == 4) {
+        DESTA_CHECK_ARG(d->M <= 16 && d->batch >= 1 && !d->out_f32 && !d->bias && !d->residual && !d->preact && d->dropout_p == 0.f,
+                        "gemm: act 4 (SwiGLU over concatenated gate|up rows) is the decode path: M <= 16, bf16 out, no other epilogue");
+        a.tilesM = 1; a.tilesN = (d->N + 7) / 8; a.full_tiles = a.tilesN; a.split = 1; a.ws = nullptr;
+        if (g_skinny_nt) hipLaunchKernelGGL((gemm_bf16_nt_skinny_kernel<16, 2, true, true>), dim3(a.tilesN, d->batch), dim3(512), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((gemm_bf16_nt_skinny_kernel<16, 2, false, true>), dim3(a.tilesN, d->batch), dim3(512), 0, (hipStream_t)stream, a);
+        DESTA_CHECK_LAUNCH("gemm_bf16_nt_skinny_swiglu");
+        return DESTA_OK;
+    }
+    if (d->M <= 16 && g_force_variant == 0) {                           // decode-time projections: weight streaming
+        // 16 columns x 8 K-slices per block measured fastest on every decode shape (tools/skinny_bench.py);
+        // tuning override: option 2 = COLS*10 + U, option 3 = non-temporal weight loads
+        int cols = 16, u = 2;
+        if (g_skinny) { cols = g_skinny / 10; u = g_skinny % 10; }
+        a.tilesM = 1; a.tilesN = (d->N + cols - 1) / cols; a.full_tiles = a.tilesN; a.split = 1; a.ws = nullptr;
+        const dim3 grid(a.tilesN, d->batch);
+        hipStream_t st = (hipStream_t)stream;
+        if (cols == 64) hipLaunchKernelGGL((gemm_bf16_nt_skinny_kernel<64, 1, false, false>), grid, dim3(512), 0, st, a);
+        else if (cols == 32) hipLaunchKernelGGL((gemm_bf16_nt_skinny_kernel<32, 2, false, false>), grid, dim3(512), 0, st, a);
+        else if (u == 4) hipLaunchKernelGGL((gemm_bf16_nt_skinny_kernel<16, 4, false, false>), grid, dim3(512), 0, st, a);
+        else if (g_skinny_nt) hipLaunchKernelGGL((gemm_bf16_nt_skinny_kernel<16, 2, true, false>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((gemm_bf16_nt_skinny_kernel<16, 2, false, false>), grid, dim3(512), 0, st, a);
+        DESTA_CHECK_LAUNCH("gemm_bf16_nt_skinny");
+        return DESTA_OK;
     }
     bool big = false;
     if (d->M >= 128 && d->N >= 128 && d->K >= 512) {

@@ -264,17 +264,28 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_k(const bf16_t* __restrict__ 
 // buf: [rows, ld] bf16; heads [0, n_heads) of width HD starting at column 0 are rotated in place.
 // G = HD/16 lanes own one head: lane j holds elements 8j..8j+7 of both halves.
 // NORM: 0 = plain rope; 1 = fwd (rmsnorm with weight then rope); 2 = bwd of (1) given saved pre-norm x.
+// KV-cache append (generate()): with kv.dst the grid also covers the V heads that follow K in `buf`; rotated K heads and
+// plain V heads of row (b, s) are ALSO written to kv.dst + b*bs + (slot0 + s)*rs + (head - n_q)*HD (the K|V slab).
+struct RopeKV { bf16_t* dst; long bs, rs; int slot0; int n_v; };
 template <int HD, int NORM, bool BWD>
 __global__ __launch_bounds__(256) void rope_k(bf16_t* __restrict__ buf, long ld, int rows, int S, int n_heads, int n_q,
                                               const float* __restrict__ cs, const float* __restrict__ wq,
                                               const float* __restrict__ wk, float eps, const bf16_t* __restrict__ pre,
-                                              long ld_pre, const int* __restrict__ pos_shift) {
+                                              long ld_pre, const int* __restrict__ pos_shift, RopeKV kv) {
     constexpr int G = HD / 16, H2 = HD / 2;
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     const long grp = gid / G;
     const int j = (int)(gid % G);
-    const bool active = grp < (long)rows * n_heads;
-    const int row = active ? (int)(grp / n_heads) : 0, head = active ? (int)(grp % n_heads) : 0;
+    const int all_heads = n_heads + kv.n_v;                              // kv.n_v = 0 without a cache
+    const bool active = grp < (long)rows * all_heads;
+    const int row = active ? (int)(grp / all_heads) : 0, head = active ? (int)(grp % all_heads) : 0;
+    if (!BWD && head >= n_heads) {                                       // V head: copy into the cache (no whole-wave op follows)
+        const bf16_t* src = buf + (long)row * ld + (long)head * HD;
+        bf16_t* d = kv.dst + (long)(row / S) * kv.bs + (long)(kv.slot0 + row % S) * kv.rs + (long)(head - n_q) * HD;
+        *(u16x8*)(d + 8 * j) = *(const u16x8*)(src + 8 * j);
+        *(u16x8*)(d + H2 + 8 * j) = *(const u16x8*)(src + H2 + 8 * j);
+        return;
+    }
     // position_ids: arange(S) for every row in training (H7); generate() passes a per-sequence shift
     // (-left_pad for the prompt, cache_length - left_pad for a decode step) as HF derives them from the mask
     const int pos = pos_shift ? max(0, row % S + pos_shift[row / S]) : row % S;
@@ -305,7 +316,13 @@ __global__ __launch_bounds__(256) void rope_k(bf16_t* __restrict__ buf, long ld,
         float oa[8], ob[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { oa[e] = a[e] * c[e] - b[e] * s[e]; ob[e] = b[e] * c[e] + a[e] * s[e]; }
-        if (active) { store8_bf16(p, 8 * j, oa); store8_bf16(p, H2 + 8 * j, ob); }
+        if (active) {
+            store8_bf16(p, 8 * j, oa); store8_bf16(p, H2 + 8 * j, ob);
+            if (kv.dst && head >= n_q) {
+                bf16_t* d = kv.dst + (long)(row / S) * kv.bs + (long)(kv.slot0 + row % S) * kv.rs + (long)(head - n_q) * HD;
+                store8_bf16(d, 8 * j, oa); store8_bf16(d, H2 + 8 * j, ob);
+            }
+        }
     } else {
         float ga[8], gb[8];
 #pragma unroll
@@ -464,30 +481,45 @@ __global__ __launch_bounds__(256) void dropout_mask_k(unsigned slo, unsigned shi
         out[i] = desta_rng32(slo, shi, (unsigned long)i) >= thresh ? 1 : 0;
 }
 
-// greedy decoding: out[r] = argmax_c x[r][c] (first maximum, like torch.argmax), one block per row
-__global__ __launch_bounds__(256) void argmax_bf16_k(const bf16_t* __restrict__ x, long ld, int cols, long* __restrict__ out) {
-    __shared__ float bv[4];
-    __shared__ int bi[4];
-    const bf16_t* row = x + (long)blockIdx.x * ld;
-    float best = -INFINITY;
-    int idx = 0x7fffffff;
-    for (int c = threadIdx.x; c < cols; c += 256) {
-        const float v = bf2f(row[c]);
-        if (v > best) { best = v; idx = c; }
+// greedy decoding: out[r] = argmax_c x[r][c] (first maximum, like torch.argmax).  Keys order by value, then by
+// SMALLER index: (monotone float bits << 32) | ~index.  Stage 1: ARGMAX_SPLIT blocks per row reduce a column slice
+// each to one key in the workspace; stage 2: one wave per row reduces the slice keys.
+constexpr int ARGMAX_SPLIT = 64;
+__device__ __forceinline__ unsigned long argmax_key(float v, int idx) {
+    unsigned b = __float_as_uint(v);
+    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);                     // monotone map of float order onto unsigned
+    return ((unsigned long)b << 32) | (unsigned)(~(unsigned)idx);
+}
+__global__ __launch_bounds__(256) void argmax_part_k(const bf16_t* __restrict__ x, long ld, int cols, unsigned long* __restrict__ ws) {
+    __shared__ unsigned long red[4];
+    const bf16_t* row = x + (long)blockIdx.y * ld;
+    const int per = (cols + ARGMAX_SPLIT - 1) / ARGMAX_SPLIT;
+    const int c0 = blockIdx.x * per, c1 = min(cols, c0 + per);
+    unsigned long best = 0;                                              // below every real key (NaN-free logits)
+    for (int c = c0 + threadIdx.x; c < c1; c += 256) {
+        const unsigned long k = argmax_key(bf2f(row[c]), c);
+        best = k > best ? k : best;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(idx, o, 64);
-        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+        const unsigned long ok = __shfl_xor(best, o, 64);
+        best = ok > best ? ok : best;
     }
-    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w)
-            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
-        out[blockIdx.x] = idx;
+        for (int w = 1; w < 4; ++w) best = red[w] > best ? red[w] : best;
+        ws[(long)blockIdx.y * ARGMAX_SPLIT + blockIdx.x] = best;
     }
+}
+__global__ __launch_bounds__(64) void argmax_final_k(const unsigned long* __restrict__ ws, long* __restrict__ out) {
+    unsigned long best = ws[(long)blockIdx.x * ARGMAX_SPLIT + threadIdx.x];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long ok = __shfl_xor(best, o, 64);
+        best = ok > best ? ok : best;
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = (long)(unsigned)(~(unsigned)(best & 0xffffffffu));
 }
 
 int nblocks(long n, int per = 256, int cap = 8192) {
@@ -582,9 +614,9 @@ extern "C" int desta_rmsnorm_bwd(const void* dy, const void* x, const float* wei
     return DESTA_OK;
 }
 
-extern "C" int desta_rope(void* buf, int64_t ld, int rows, int seq, int n_q_heads, int n_kv_heads, int head_dim,
-                          const float* cos_sin, const float* q_norm_w, const float* k_norm_w, float eps,
-                          const void* pre_norm, int64_t ld_pre, int backward, const int32_t* pos_shift, void* stream) {
+static int rope_launch(void* buf, int64_t ld, int rows, int seq, int n_q_heads, int n_kv_heads, int head_dim,
+                       const float* cos_sin, const float* q_norm_w, const float* k_norm_w, float eps,
+                       const void* pre_norm, int64_t ld_pre, int backward, const int32_t* pos_shift, RopeKV kv, void* stream) {
     DESTA_CHECK_ARG(buf && cos_sin, "rope: null argument");
     DESTA_CHECK_ARG(head_dim == 64 || head_dim == 128, "rope: head_dim %d unsupported (64 or 128)", head_dim);
     DESTA_CHECK_ARG(ld % 8 == 0 && rows > 0 && seq > 0, "rope: bad shape");
@@ -592,10 +624,10 @@ extern "C" int desta_rope(void* buf, int64_t ld, int rows, int seq, int n_q_head
     DESTA_CHECK_ARG(!norm || k_norm_w, "rope: q_norm without k_norm");
     DESTA_CHECK_ARG(!(norm && backward) || pre_norm, "rope: backward with q/k norm needs the saved pre-norm q/k");
     const int nh = n_q_heads + n_kv_heads;
-    const long nthreads = (long)rows * nh * (head_dim / 16);
+    const long nthreads = (long)rows * (nh + kv.n_v) * (head_dim / 16);
     dim3 grid((unsigned)((nthreads + 255) / 256));
     hipStream_t st = (hipStream_t)stream;
-#define ROPE_ARGS grid, dim3(256), 0, st, (bf16_t*)buf, (long)ld, rows, seq, nh, n_q_heads, cos_sin, q_norm_w, k_norm_w, eps, (const bf16_t*)pre_norm, (long)ld_pre, pos_shift
+#define ROPE_ARGS grid, dim3(256), 0, st, (bf16_t*)buf, (long)ld, rows, seq, nh, n_q_heads, cos_sin, q_norm_w, k_norm_w, eps, (const bf16_t*)pre_norm, (long)ld_pre, pos_shift, kv
     if (head_dim == 128) {
         if (!backward) { if (norm) hipLaunchKernelGGL((rope_k<128, 1, false>), ROPE_ARGS); else hipLaunchKernelGGL((rope_k<128, 0, false>), ROPE_ARGS); }
         else { if (norm) hipLaunchKernelGGL((rope_k<128, 2, true>), ROPE_ARGS); else hipLaunchKernelGGL((rope_k<128, 0, true>), ROPE_ARGS); }
@@ -606,6 +638,24 @@ extern "C" int desta_rope(void* buf, int64_t ld, int rows, int seq, int n_q_head
 #undef ROPE_ARGS
     DESTA_CHECK_LAUNCH("rope");
     return DESTA_OK;
+}
+
+extern "C" int desta_rope(void* buf, int64_t ld, int rows, int seq, int n_q_heads, int n_kv_heads, int head_dim,
+                          const float* cos_sin, const float* q_norm_w, const float* k_norm_w, float eps,
+                          const void* pre_norm, int64_t ld_pre, int backward, const int32_t* pos_shift, void* stream) {
+    const RopeKV kv = {nullptr, 0, 0, 0, 0};
+    return rope_launch(buf, ld, rows, seq, n_q_heads, n_kv_heads, head_dim, cos_sin, q_norm_w, k_norm_w, eps, pre_norm, ld_pre, backward,
+                       pos_shift, kv, stream);
+}
+
+extern "C" int desta_rope_kv_append(void* qkv, int64_t ld, int rows, int seq, int n_q_heads, int n_kv_heads, int head_dim,
+                                    const float* cos_sin, const float* q_norm_w, const float* k_norm_w, float eps,
+                                    const int32_t* pos_shift, void* kv_cache, int64_t kv_batch_stride, int64_t kv_row_stride,
+                                    int slot0, void* stream) {
+    DESTA_CHECK_ARG(kv_cache && kv_row_stride % 8 == 0 && kv_batch_stride % 8 == 0 && slot0 >= 0, "rope_kv_append: bad cache argument");
+    DESTA_CHECK_ARG((uintptr_t)kv_cache % 16 == 0 && (uintptr_t)qkv % 16 == 0, "rope_kv_append: buffers must be 16-byte aligned");
+    const RopeKV kv = {(bf16_t*)kv_cache, (long)kv_batch_stride, (long)kv_row_stride, slot0, n_kv_heads};
+    return rope_launch(qkv, ld, rows, seq, n_q_heads, n_kv_heads, head_dim, cos_sin, q_norm_w, k_norm_w, eps, nullptr, 0, 0, pos_shift, kv, stream);
 }
 
 extern "C" int desta_swiglu_fwd(const void* gate_up, void* act, int64_t rows, int inter, void* stream) {
@@ -674,9 +724,13 @@ extern "C" int desta_dropout_mask_u8(uint64_t seed, int64_t n, float p, uint8_t*
     return DESTA_OK;
 }
 
-extern "C" int desta_argmax_bf16(const void* x, int64_t ld, int rows, int cols, int64_t* out, void* stream) {
-    DESTA_CHECK_ARG(x && out && rows > 0 && cols > 0, "argmax: bad argument");
-    hipLaunchKernelGGL(argmax_bf16_k, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long)ld, cols, (long*)out);
+extern "C" size_t desta_argmax_workspace_bytes(int rows) { return (size_t)(rows > 0 ? rows : 0) * ARGMAX_SPLIT * sizeof(unsigned long); }
+extern "C" int desta_argmax_bf16(const void* x, int64_t ld, int rows, int cols, int64_t* out, void* workspace, void* stream) {
+    DESTA_CHECK_ARG(x && out && workspace && rows > 0 && cols > 0, "argmax: bad argument");
+    static_assert(ARGMAX_SPLIT == 64, "final stage is one 64-lane wave");
+    hipLaunchKernelGGL(argmax_part_k, dim3(ARGMAX_SPLIT, rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long)ld, cols,
+                       (unsigned long*)workspace);
+    hipLaunchKernelGGL(argmax_final_k, dim3(rows), dim3(64), 0, (hipStream_t)stream, (const unsigned long*)workspace, (long*)out);
     DESTA_CHECK_LAUNCH("argmax_bf16");
     return DESTA_OK;
 }

@@ -418,8 +418,24 @@ def gemm_set_option(option: int, value: int) -> None:
     check(lib.desta_gemm_set_option(option, value), "desta_gemm_set_option")
 
 
-_argmax = _sig("desta_argmax_bf16", vp, i64, i32, i32, vp, vp)
+_argmax = _sig("desta_argmax_bf16", vp, i64, i32, i32, vp, vp, vp)
+lib.desta_argmax_workspace_bytes.restype = C.c_size_t
+lib.desta_argmax_workspace_bytes.argtypes = [i32]
+_argmax_ws = {}
 
 
 def argmax_bf16(x, ld, rows, cols, out):
-    check(_argmax(p(x), ld, rows, cols, p(out), stream()), "desta_argmax_bf16")
+    key = (x.device, rows)
+    ws = _argmax_ws.get(key)
+    if ws is None:
+        ws = _argmax_ws[key] = torch.empty(lib.desta_argmax_workspace_bytes(rows), dtype=torch.uint8, device=x.device)
+    check(_argmax(p(x), ld, rows, cols, p(out), p(ws), stream()), "desta_argmax_bf16")
+
+
+_rope_kv = _sig("desta_rope_kv_append", vp, i64, i32, i32, i32, i32, i32, vp, vp, vp, f32, vp, vp, i64, i64, i32, vp)
+
+
+def rope_kv_append(buf, ld, rows, seq, n_q, n_kv, hd, cos_sin, q_norm_w, k_norm_w, eps, pos_shift, cache, kv_bs, kv_rs, slot0):
+    """Forward rope on a fused q|k|v buffer + append of the rotated K and the V heads to the KV cache slab."""
+    check(_rope_kv(p(buf), ld, rows, seq, n_q, n_kv, hd, p(cos_sin), p(q_norm_w), p(k_norm_w), eps, p(pos_shift), p(cache), kv_bs,
+                   kv_rs, slot0, stream()), "desta_rope_kv_append")

@@ -618,10 +618,12 @@ class CausalLMHIP:
         self.datt = b16(M, self.hq * self.hd)
 
     def forward(self, x0_filler, B: int, S: int, kv_start: Optional[torch.Tensor], labels: Optional[torch.Tensor], need_grad: bool,
-                pos_shift: Optional[torch.Tensor] = None, cos_sin: Optional[torch.Tensor] = None, last_logits: Optional[torch.Tensor] = None):
+                pos_shift: Optional[torch.Tensor] = None, cos_sin: Optional[torch.Tensor] = None, last_logits: Optional[torch.Tensor] = None,
+                kv_cache: Optional[List[torch.Tensor]] = None):
         """`x0_filler(buf)` writes inputs_embeds [B*S, h] bf16 into buf.  Returns the logits buffer [B*S, Vp].
         Training uses position_ids = arange(S) (H7); generate() passes pos_shift (= -left_pad per sequence, with a
-        `cos_sin` table that also covers the new tokens) and `last_logits` [B, Vp] to project only the last row."""
+        `cos_sin` table that also covers the new tokens), `last_logits` [B, Vp] to project only the last row, and the
+        per-layer KV cache slabs that the rope kernel fills with the prompt's keys / values."""
         if (B, S) != (self.B, self.S):
             self._alloc(B, S)
         c, h, M = self.c, self.h, self.M
@@ -633,7 +635,11 @@ class CausalLMHIP:
             x = self.xs[i]
             H.rmsnorm_fwd(x, ly["n1"], c.rms_norm_eps, self.hb, s["r1"])
             H.gemm(self.hb, ly["wqkv"], s["qkv"], M, self.qkvw, h, preact=s.get("pre"))
-            H.rope(s["qkv"], self.qkvw, M, S, self.hq, self.hkv, self.hd, cs, ly.get("qn"), ly.get("kn"), c.rms_norm_eps, pos_shift=pos_shift)
+            if kv_cache is None:
+                H.rope(s["qkv"], self.qkvw, M, S, self.hq, self.hkv, self.hd, cs, ly.get("qn"), ly.get("kn"), c.rms_norm_eps, pos_shift=pos_shift)
+            else:
+                H.rope_kv_append(s["qkv"], self.qkvw, M, S, self.hq, self.hkv, self.hd, cs, ly.get("qn"), ly.get("kn"), c.rms_norm_eps,
+                                 pos_shift, kv_cache[i], kv_cache[i].stride(0), kv_cache[i].stride(1), 0)
             ad = H.attn_desc(s["qkv"], s["qkv"], s["qkv"], s["att"], s["lse"], batch=B, hq=self.hq, hkv=self.hkv, sq=S, sk=S, hd=self.hd,
                              scale=scale, causal=True, kv_start=kv_start, q_off=0, k_off=self.hq * self.hd, v_off=(self.hq + self.hkv) * self.hd)
             H.attention_fwd(ad)
@@ -669,7 +675,7 @@ class CausalLMHIP:
         self.g_x, self.g_xm, self.g_hb = b16(B, h), b16(B, h), b16(B, h)
         self.g_qkv, self.g_att = b16(B, self.qkvw), b16(B, self.hq * self.hd)
         self.g_lse = torch.empty(B, self.hq, 1, dtype=F32, device=dev)
-        self.g_gu, self.g_act = b16(B, 2 * self.I), b16(B, self.I)
+        self.g_act = b16(B, self.I)
         self.g_r = torch.empty(B, dtype=F32, device=dev)
         self.g_logits = torch.zeros(B, self.Vp, dtype=BF16, device=dev)
         self.g_next = torch.zeros(B, dtype=torch.int64, device=dev)
@@ -678,15 +684,14 @@ class CausalLMHIP:
         """One token per sequence: `tokens` [B] (ids) sit at cache slot `cur`; returns logits [B, Vp] for slot cur+1."""
         c, h, B = self.c, self.h, self._gen_shape[0]
         Smax = self._gen_shape[1]
-        koff, scale = self.hq * self.hd, self.hd ** -0.5
+        scale = self.hd ** -0.5
         H.embed_gather(self.embed, None, tokens.to(torch.int32), B, h, self.g_x)
         x = self.g_x
         for ly, cache in zip(self.layers, self.kv_cache):
             H.rmsnorm_fwd(x, ly["n1"], c.rms_norm_eps, self.g_hb, self.g_r)
             H.gemm(self.g_hb, ly["wqkv"], self.g_qkv, B, self.qkvw, h)
-            H.rope(self.g_qkv, self.qkvw, B, 1, self.hq, self.hkv, self.hd, self.gen_cos_sin, ly.get("qn"), ly.get("kn"), c.rms_norm_eps,
-                   pos_shift=pos_shift)
-            cache[:, cur].copy_(self.g_qkv[:, koff:])                                          # append K|V (device memcpy)
+            H.rope_kv_append(self.g_qkv, self.qkvw, B, 1, self.hq, self.hkv, self.hd, self.gen_cos_sin, ly.get("qn"), ly.get("kn"),
+                             c.rms_norm_eps, pos_shift, cache, Smax * self.kvw, self.kvw, cur)     # rotate q,k + append K|V at slot cur
             ad = H.attn_desc(self.g_qkv, cache, cache, self.g_att, self.g_lse, batch=B, hq=self.hq, hkv=self.hkv, sq=1, sk=cur + 1,
                              hd=self.hd, scale=scale, causal=False, kv_start=kv_start, q_off=0, k_off=0, v_off=self.hkv * self.hd,
                              q_rs=self.qkvw, k_rs=self.kvw, v_rs=self.kvw, o_rs=self.hq * self.hd,
@@ -694,8 +699,7 @@ class CausalLMHIP:
             H.attention_fwd(ad)
             H.gemm(self.g_att, ly["wo"], self.g_xm, B, h, self.hq * self.hd, residual=x)
             H.rmsnorm_fwd(self.g_xm, ly["n2"], c.rms_norm_eps, self.g_hb, self.g_r)
-            H.gemm(self.g_hb, ly["wgu"], self.g_gu, B, 2 * self.I, h)
-            H.swiglu_fwd(self.g_gu, self.g_act, B, self.I)
+            H.gemm(self.g_hb, ly["wgu"], self.g_act, B, self.I, h, act=4)                       # gate|up projection + SwiGLU in one pass
             H.gemm(self.g_act, ly["wd"], self.g_x, B, h, self.I, residual=self.g_xm)
         H.rmsnorm_fwd(self.g_x, self.norm, c.rms_norm_eps, self.g_hb, self.g_r)
         H.gemm(self.g_hb, self.head, self.g_logits, B, self.V, h, ldc=self.Vp)
@@ -713,10 +717,8 @@ class CausalLMHIP:
         dev = self.dev
         kv_start = kv_start.to(torch.int32).contiguous()
         neg_pad = (-kv_start).contiguous()                                   # prompt: position = index - left_pad
-        logits = self.forward(x0_filler, B, S, kv_start, None, False, pos_shift=neg_pad, cos_sin=self.gen_cos_sin, last_logits=self.g_logits)
-        koff = self.hq * self.hd
-        for s, cache in zip(self.sv, self.kv_cache):
-            cache[:, :S].copy_(s["qkv"].view(B, S, self.qkvw)[:, :, koff:])
+        logits = self.forward(x0_filler, B, S, kv_start, None, False, pos_shift=neg_pad, cos_sin=self.gen_cos_sin, last_logits=self.g_logits,
+                              kv_cache=self.kv_cache)
         out = torch.full((B, max_new_tokens), int(pad_token_id), dtype=torch.int64, device=dev)
         steps_logits = []
         finished = torch.zeros(B, dtype=torch.bool, device=dev)

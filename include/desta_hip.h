@@ -51,7 +51,9 @@ typedef struct desta_gemm_desc {
     const void* residual;              /* [M,N] bf16 or fp32, or NULL */
     int64_t ldr, stride_r;
     int residual_f32;
-    int act;                           /* 0 = none, 1 = GELU(erf), 2 = SwiGLU fwd, 3 = SwiGLU bwd (see aux) */
+    int act;                           /* 0 = none, 1 = GELU(erf), 2 = SwiGLU fwd, 3 = SwiGLU bwd (see aux),   */
+                                       /* 4 = decode SwiGLU (M <= 16): B = [2N,K] gate rows then up rows,      */
+                                       /*     C[M,N] (bf16) = silu(gate) * up                                   */
     int out_f32;                       /* C dtype: 0 = bf16, 1 = fp32 */
     void* preact;                      /* optional bf16 [M,N] */
     int64_t ldp, stride_p;
@@ -70,7 +72,9 @@ int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream);
  * lockstep / staggered / staggered-persistent schedule */
 int desta_gemm_force_variant(int variant);
 int desta_gemm_set_persistent(int on);   /* 1: the automatic choice uses the persistent kernel when a block owns > 1 item */
-int desta_gemm_set_option(int option, int value);   /* A/B switches of the automatic choice: 0 = persistent, 1 = staggered */
+/* A/B switches of the automatic choice: option 0 = persistent, 1 = staggered, 2 = skinny (M <= 16) kernel variant
+ * (0 auto, else COLS*10 + U: 162 164 322 641), 3 = non-temporal weight loads in the skinny kernel */
+int desta_gemm_set_option(int option, int value);
 
 /* ------------------------------------------------------------------------------------------
  * Global-norm clip + Adafactor over a flat fp32 arena.
@@ -236,9 +240,20 @@ int desta_prompt_grad(const float* dx, int taps, int batch, int64_t n, float* dp
 int desta_dropout_bf16(const void* x, void* y, int rows, int cols, int64_t ld, float p, uint64_t seed, void* stream);
 int desta_dropout_mask_u8(uint64_t seed, int64_t n, float p, uint8_t* out, void* stream);
 
-/* Greedy decoding helper: out[r] = argmax over the first `cols` entries of bf16 row r (first maximum).
+/* Greedy decoding helper: out[r] = argmax over the first `cols` entries of bf16 row r (first maximum, two-stage
+ * reduction; `workspace` holds desta_argmax_workspace_bytes(rows) bytes).
  * Replaces the argmax of `llm_model.generate(do_sample=False)` (modeling_desta25.py:1419). */
-int desta_argmax_bf16(const void* x, int64_t ld, int rows, int cols, int64_t* out, void* stream);
+size_t desta_argmax_workspace_bytes(int rows);
+int desta_argmax_bf16(const void* x, int64_t ld, int rows, int cols, int64_t* out, void* workspace, void* stream);
+
+/* desta_rope (forward) on a fused q|k|v projection [rows, ld] that ALSO appends the rotated K heads and the V heads of
+ * row (b, s) to a KV cache slab: kv_cache + b*kv_batch_stride + (slot0 + s)*kv_row_stride, K heads then V heads.
+ * This is what `DynamicCache.update` does inside `llm_model.generate` (modeling_desta25.py:1419) for the prompt
+ * (seq = prompt length, slot0 = 0) and for every decode step (seq = 1, slot0 = cache length). */
+int desta_rope_kv_append(void* qkv, int64_t ld, int rows, int seq, int n_q_heads, int n_kv_heads, int head_dim,
+                         const float* cos_sin, const float* q_norm_w, const float* k_norm_w, float eps,
+                         const int32_t* pos_shift, void* kv_cache, int64_t kv_batch_stride, int64_t kv_row_stride,
+                         int slot0, void* stream);
 
 #ifdef __cplusplus
 }

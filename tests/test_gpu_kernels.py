@@ -83,6 +83,88 @@ def test_gemm_256_staggered_variant(hip, M, N, K):
     torch.testing.assert_close(outs[1], A.float() @ B.float().T, rtol=1e-4, atol=2e-3)
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 16, 64), (3, 100, 192), (8, 4096, 4096), (16, 1028, 2048), (8, 6144, 14336), (5, 36, 64 * 37)])
+def test_gemm_skinny(hip, M, N, K):
+    """M <= 16 takes the weight-streaming kernel (decode projections): same results as the tile kernel / fp32 torch,
+    incl. ragged N (multiple of 4 only), strided A rows, bias / GELU / residual epilogues and fp32 output."""
+    g = torch.Generator().manual_seed(M * 11 + N + K)
+    Abig = _bf(torch.randn(M, 3, K, generator=g)).cuda()              # rows strided by 3K, like hb[S-1::S]
+    A = Abig[:, 1]
+    B = _bf(torch.randn(N, K, generator=g) / math.sqrt(K)).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    res = _bf(torch.randn(M, N, generator=g)).cuda()
+    ref = A.float() @ B.float().T
+    out = torch.full((M + 1, N), 7.0, dtype=torch.float32, device="cuda")
+    hip.gemm(A, B, out, M, N, K, lda=3 * K)
+    torch.testing.assert_close(out[:M], ref, rtol=1e-4, atol=1e-4)
+    assert bool((out[M] == 7.0).all())                                 # rows >= M untouched
+    outb = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    hip.gemm(A, B, outb, M, N, K, lda=3 * K, bias=bias, residual=res, act=1, alpha=0.5)
+    ref2 = torch.nn.functional.gelu(0.5 * ref + bias) + res.float()
+    torch.testing.assert_close(outb.float(), ref2, rtol=1e-2, atol=1e-2)
+    try:                                                               # identical math on the 128x128 tile kernel
+        hip.gemm_force_variant(1)
+        outt = torch.empty(M, N, dtype=torch.float32, device="cuda")
+        hip.gemm(A, B, outt, M, N, K, lda=3 * K)
+    finally:
+        hip.gemm_force_variant(0)
+    torch.testing.assert_close(out[:M], outt, rtol=1e-5, atol=1e-5)
+    o2 = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    hip.gemm(A, B, o2, M, N, K, lda=3 * K)
+    assert torch.equal(o2, out[:M])                                    # fixed reduction order
+
+
+@pytest.mark.parametrize("M,I,K", [(8, 512, 256), (3, 104, 192), (16, 14336, 4096)])
+def test_gemm_skinny_fused_swiglu(hip, M, I, K):
+    """act=4: concatenated gate|up rows, SwiGLU in the epilogue == skinny GEMM + swiglu kernel bit for bit."""
+    g = torch.Generator().manual_seed(M + I)
+    x = _bf(torch.randn(M, K, generator=g)).cuda()
+    w = _bf(torch.randn(2 * I, K, generator=g) / math.sqrt(K) * 2).cuda()
+    gu = torch.empty(M, 2 * I, dtype=torch.bfloat16, device="cuda")
+    hip.gemm(x, w, gu, M, 2 * I, K)
+    ref = torch.empty(M, I, dtype=torch.bfloat16, device="cuda")
+    hip.swiglu_fwd(gu, ref, M, I)
+    out = torch.empty(M, I, dtype=torch.bfloat16, device="cuda")
+    hip.gemm(x, w, out, M, I, K, act=4)
+    assert torch.equal(out, ref)
+    for nt in (1, 0):                                                   # non-temporal weight loads: same bits
+        hip.gemm_set_option(3, nt)
+        o2 = torch.empty_like(out)
+        hip.gemm(x, w, o2, M, I, K, act=4)
+        g2 = torch.empty_like(gu)
+        hip.gemm(x, w, g2, M, 2 * I, K)
+        assert torch.equal(o2, ref) and torch.equal(g2, gu)
+
+
+def test_rope_kv_append(hip):
+    """rope + KV-cache append == rope in place followed by copying the K|V columns into the slab (prompt and decode forms)."""
+    g = torch.Generator().manual_seed(4)
+    B, S, hq, hkv, hd, Smax = 3, 5, 4, 2, 128, 9
+    ld = (hq + 2 * hkv) * hd
+    qkv = _bf(torch.randn(B * S, ld, generator=g)).cuda()
+    fr = torch.outer(torch.arange(Smax, dtype=torch.float32), 1.0 / (10000 ** (torch.arange(0, hd, 2).float() / hd)))
+    cs = torch.stack([fr.cos(), fr.sin()], 1).contiguous().cuda()
+    shift = torch.tensor([-2, 0, -1], dtype=torch.int32).cuda()
+    for qn in (None, torch.rand(hd, generator=g).cuda() + 0.5):
+        ref = qkv.clone()
+        hip.rope(ref, ld, B * S, S, hq, hkv, hd, cs, qn, qn, 1e-6, pos_shift=shift)
+        cache = torch.zeros(B, Smax, 2 * hkv * hd, dtype=torch.bfloat16, device="cuda")
+        got = qkv.clone()
+        hip.rope_kv_append(got, ld, B * S, S, hq, hkv, hd, cs, qn, qn, 1e-6, shift, cache, cache.stride(0), cache.stride(1), 0)
+        assert torch.equal(got, ref)
+        assert torch.equal(cache[:, :S], ref.view(B, S, ld)[:, :, hq * hd:])
+        assert bool((cache[:, S:] == 0).all())
+        # decode form: one row per sequence appended at slot 7
+        q1 = _bf(torch.randn(B, ld, generator=g)).cuda()
+        r1 = q1.clone()
+        sh1 = (7 + shift).contiguous()
+        hip.rope(r1, ld, B, 1, hq, hkv, hd, cs, qn, qn, 1e-6, pos_shift=sh1)
+        g1 = q1.clone()
+        hip.rope_kv_append(g1, ld, B, 1, hq, hkv, hd, cs, qn, qn, 1e-6, sh1, cache, cache.stride(0), cache.stride(1), 7)
+        assert torch.equal(g1, r1) and torch.equal(cache[:, 7], r1[:, hq * hd:])
+        assert bool((cache[:, 8] == 0).all()) and torch.equal(cache[:, :S], ref.view(B, S, ld)[:, :, hq * hd:])
+
+
 def test_gemm_256_identity_and_k64(hip):
     K = 64                                        # a single K-tile: the whole loop is prologue + dummy tail loads
     A = _bf(torch.eye(256)[:, :K]).cuda()
