@@ -39,6 +39,7 @@ struct GemmArgs {
     int tilesM, tilesN;
     int full_tiles, split;                              // 256-kernel: tiles [0,full) whole-K; the rest in `split` K-slices
     float* ws;                                          // fp32 partial slabs [(tile-full)*split + slice][256][256]
+    const float* rms_w; float rms_eps;                  // skinny kernel: RMSNorm(A rows; weight rms_w) applied on the fly
 };
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
@@ -716,89 +717,157 @@ struct SkinnyStage {
     bf16x8 w0[U][COLS / 16], w1[U][COLS / 16], x0[U], x1[U];
 };
 
-// SWIGLU: B holds gate rows [0,N) and up rows [N,2N) (the concatenated gate|up projection); a block owns 8 output
-// columns and streams the 8 gate + 8 matching up rows, the epilogue stores bf16(silu(gate)) * up to C[M,N] with the
+// SWIGLU: B holds gate rows [0,N) and up rows [N,2N) (the concatenated gate|up projection); a tile is 8 output
+// columns = the 8 gate + 8 matching up rows, the epilogue stores bf16(silu(gate)) * up to C[M,N] with the
 // rounding points of the unfused path (projection rounded to bf16, then swiglu_fwd).
-template <int COLS, int U, bool NT, bool SWIGLU>
-__global__ __launch_bounds__(512) void gemm_bf16_nt_skinny_kernel(GemmArgs p) {
-#define SK_WLOAD(P) (NT ? __builtin_nontemporal_load(P) : *(P))
+// RMS: A holds the UN-normalised residual stream; the block first normalises the M rows itself (RMSNorm with
+// weight rms_w, the rounding points of rmsnorm_fwd_k: rms_w * bf16(x * rstd) -> bf16) into LDS while its first
+// weight loads are in flight, and the MFMA activation fragments are then read from LDS instead of global memory.
+// This removes the separate norm launch of a decode layer (~8 us for 8 rows, launch-latency bound).  The 16-byte
+// slots of LDS row m are XOR-swizzled with m so the 16 row-strided ds_read_b128 of a fragment hit distinct banks
+// without padding (8 rows x 4096 + the reduction buffers = exactly 80 KiB: two blocks per CU).
+// The grid is PERSISTENT (<= 2 blocks per CU): a block walks column tiles blockIdx.x, +gridDim.x, ... and the
+// two-stage load pipeline runs across tile boundaries, so the weight stream never drains while a tile is being
+// reduced and the RMS prologue is paid once per block, not once per tile.
+constexpr int SKINNY_XS_BYTES = 8 * 4096 * 2;                           // M * 2K must fit: 8 rows x 4096
+struct SkinnyCursor { int tile, grp; };
+
+template <int COLS, int U, bool SWIGLU, bool RMS>
+__global__ __launch_bounds__(512, (COLS == 16 && U == 2) ? 2 : 1) void gemm_bf16_nt_skinny_kernel(GemmArgs p, int ntiles) {
     static_assert(!SWIGLU || COLS == 16, "SwiGLU pairing uses one 16-row weight tile");
     constexpr int T = COLS / 16;
-    __shared__ f32x4 red[8][T][64];
+    constexpr int RED_BYTES = 8 * T * 64 * 16;                           // one buffer of per-wave partial tiles
+    __shared__ __attribute__((aligned(16))) char smem[2 * RED_BYTES + (RMS ? SKINNY_XS_BYTES : 0)];
+    const char* xs = smem + 2 * RED_BYTES;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, z = blockIdx.y;
-    const int n0 = blockIdx.x * (SWIGLU ? 8 : COLS);
     const int r = lane & 15, g = lane >> 4;
     const bool mok = r < p.M;
-    const bf16_t* bp[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) {                                        // clamped rows are computed, never stored
-        const int wrow = SWIGLU ? (r < 8 ? min(n0 + r, p.N - 1) : p.N + min(n0 + r - 8, p.N - 1)) : min(n0 + t * 16 + r, p.N - 1);
-        bp[t] = p.B + (long)z * p.sB + (long)wrow * p.ldb + g * 16;
-    }
+    const bf16_t* Bz = p.B + (long)z * p.sB + g * 16;
     const bf16_t* ap = p.A + (long)z * p.sA + (long)(mok ? r : 0) * p.lda + g * 16;
     const int nchunks = p.K >> 6;
+    constexpr int STEP = 8 * U;
+    const int gpt = (nchunks + STEP - 1) / STEP;                         // groups per tile, the same for every wave
+    const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    const int G = my_tiles * gpt;
+    const int rowb = p.K * 2, rr = mok ? r : 0;
+    const char* xrow = xs + rr * rowb;                                   // this lane's fragment row in LDS (RMS only)
     f32x4 acc[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     SkinnyStage<COLS, U> sa, sb;
+    SkinnyCursor lc = {(int)blockIdx.x, 0}, mc = {(int)blockIdx.x, 0};
+    int parity = 0;
 
-#define SK_LOAD(S, C0)                                                                  \
-    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                     \
-        const int cc = (C0) + 8 * u;                                                    \
-        if (cc < nchunks) {                                                             \
-            _Pragma("unroll") for (int t = 0; t < T; ++t) {                             \
-                S.w0[u][t] = SK_WLOAD((const bf16x8*)(bp[t] + (long)cc * 64));          \
-                S.w1[u][t] = SK_WLOAD((const bf16x8*)(bp[t] + (long)cc * 64 + 8));      \
-            }                                                                           \
-            S.x0[u] = *(const bf16x8*)(ap + (long)cc * 64);                             \
-            S.x1[u] = *(const bf16x8*)(ap + (long)cc * 64 + 8);                         \
-        }                                                                               \
+    auto advance = [&](SkinnyCursor& c) { if (++c.grp == gpt) { c.grp = 0; c.tile += (int)gridDim.x; } };
+#define SK_LOAD(S)                                                                          \
+    {                                                                                       \
+        const int n0 = lc.tile * (SWIGLU ? 8 : COLS), c0 = wave + lc.grp * STEP;            \
+        const bf16_t* bp[T];                                                                \
+        _Pragma("unroll") for (int t = 0; t < T; ++t) {      /* clamped rows: computed, never stored */ \
+            const int wrow = SWIGLU ? (r < 8 ? min(n0 + r, p.N - 1) : p.N + min(n0 + r - 8, p.N - 1)) \
+                                    : min(n0 + t * 16 + r, p.N - 1);                        \
+            bp[t] = Bz + (long)wrow * p.ldb;                                                \
+        }                                                                                   \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) {                                     \
+            const int cc = c0 + 8 * u;                                                      \
+            if (cc < nchunks) {                                                             \
+                _Pragma("unroll") for (int t = 0; t < T; ++t) {                             \
+                    S.w0[u][t] = *(const bf16x8*)(bp[t] + (long)cc * 64);                   \
+                    S.w1[u][t] = *(const bf16x8*)(bp[t] + (long)cc * 64 + 8);               \
+                }                                                                           \
+                if (!RMS) {                                                                 \
+                    S.x0[u] = *(const bf16x8*)(ap + (long)cc * 64);                         \
+                    S.x1[u] = *(const bf16x8*)(ap + (long)cc * 64 + 8);                     \
+                }                                                                           \
+            }                                                                               \
+        }                                                                                   \
+        advance(lc);                                                                        \
     }
-#define SK_MMA(S, C0)                                                                   \
-    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                     \
-        if ((C0) + 8 * u < nchunks) {                                                   \
-            const bf16x8 zero = {};                                                     \
-            const bf16x8 a0 = mok ? S.x0[u] : zero, a1 = mok ? S.x1[u] : zero;          \
-            _Pragma("unroll") for (int t = 0; t < T; ++t) {                             \
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(S.w0[u][t], a0, acc[t], 0, 0, 0); \
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(S.w1[u][t], a1, acc[t], 0, 0, 0); \
-            }                                                                           \
-        }                                                                               \
+#define SK_MMA(S)                                                                           \
+    {                                                                                       \
+        const int c0 = wave + mc.grp * STEP;                                                \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) {                                     \
+            if (c0 + 8 * u < nchunks) {                                                     \
+                const bf16x8 zero = {};                                                     \
+                if (RMS) {                                                                  \
+                    const int slot = (c0 + 8 * u) * 8 + g * 2;                              \
+                    S.x0[u] = *(const bf16x8*)(xrow + ((slot ^ rr) << 4));                  \
+                    S.x1[u] = *(const bf16x8*)(xrow + (((slot + 1) ^ rr) << 4));            \
+                }                                                                           \
+                const bf16x8 a0 = mok ? S.x0[u] : zero, a1 = mok ? S.x1[u] : zero;          \
+                _Pragma("unroll") for (int t = 0; t < T; ++t) {                             \
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(S.w0[u][t], a0, acc[t], 0, 0, 0); \
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(S.w1[u][t], a1, acc[t], 0, 0, 0); \
+                }                                                                           \
+            }                                                                               \
+        }                                                                                   \
+        if (mc.grp == gpt - 1) finish_tile(mc.tile);                                        \
+        advance(mc);                                                                        \
     }
-    constexpr int STEP = 8 * U;
-    SK_LOAD(sa, wave)
-    for (int c = wave; c < nchunks; c += 2 * STEP) {
-        SK_LOAD(sb, c + STEP)
-        SK_MMA(sa, c)
-        SK_LOAD(sa, c + 2 * STEP)
-        SK_MMA(sb, c + STEP)
+    // reduce the 8 waves' partial tiles in fixed order, epilogue, reset; one barrier per tile (red is double buffered:
+    // a wave can run at most one tile ahead of the wave that still reads the other buffer)
+    auto finish_tile = [&](int tile) {
+        f32x4 (*red)[T][64] = (f32x4 (*)[T][64])(smem + parity * RED_BYTES);
+        parity ^= 1;
+#pragma unroll
+        for (int t = 0; t < T; ++t) { red[wave][t][lane] = acc[t]; acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        __syncthreads();
+        if (wave < T) {                                                  // wave t finishes column tile t
+            f32x4 sum = red[0][wave][lane];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) sum += red[w][wave][lane];
+            const int n0 = tile * (SWIGLU ? 8 : COLS);
+            if (SWIGLU) {
+                // lane groups 0,1 hold gate columns n0+4g.., groups 2,3 the matching up columns: fetch up from lane+32
+                u16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float up = __shfl(sum[e], (lane + 32) & 63, 64);
+                    const float gt = bf2f(f2bf(sum[e] * p.alpha)), uu = bf2f(f2bf(up * p.alpha));
+                    o[e] = f2bf(bf2f(f2bf(gt / (1.0f + __expf(-gt)))) * uu);
+                }
+                const int n = n0 + g * 4;
+                if (mok && g < 2 && n < p.N) *(u16x4*)((bf16_t*)p.C + (long)z * p.sC + (long)r * p.ldc + n) = o;
+            } else {
+                const int n = n0 + wave * 16 + g * 4;
+                if (mok && n < p.N) epilogue4(p, z, r, n, sum);
+            }
+        }
+    };
+
+    if (G > 0) SK_LOAD(sa)
+    if (RMS) {
+        for (int m = wave; m < p.M; m += 8) {                            // one wave per row, same summation order as rmsnorm_fwd_k
+            const bf16_t* xr = p.A + (long)z * p.sA + (long)m * p.lda;
+            float q = 0.f;
+#pragma unroll 4
+            for (int c = lane * 8; c < p.K; c += 512) {
+                const u16x8 v = *(const u16x8*)(xr + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float f = bf2f(v[e]); q += f * f; }
+            }
+            const float rstd = rsqrtf(wave_sum(q) / (float)p.K + p.rms_eps);
+#pragma unroll 2
+            for (int c = lane * 8; c < p.K; c += 512) {
+                const u16x8 v = *(const u16x8*)(xr + c);
+                const float4 w0 = *(const float4*)(p.rms_w + c), w1 = *(const float4*)(p.rms_w + c + 4);
+                const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+                u16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = f2bf(wv[e] * bf2f(f2bf(bf2f(v[e]) * rstd)));
+                *(u16x8*)(smem + 2 * RED_BYTES + m * rowb + (((c >> 3) ^ m) << 4)) = o;
+            }
+        }
+        __syncthreads();
+    }
+    for (int gi = 0; gi < G; gi += 2) {
+        if (gi + 1 < G) SK_LOAD(sb)
+        SK_MMA(sa)
+        if (gi + 2 < G) SK_LOAD(sa)
+        if (gi + 1 < G) SK_MMA(sb)
     }
 #undef SK_LOAD
 #undef SK_MMA
-#undef SK_WLOAD
-#pragma unroll
-    for (int t = 0; t < T; ++t) red[wave][t][lane] = acc[t];
-    __syncthreads();
-    if (wave < T) {                                                      // wave t finishes column tile t
-        f32x4 s = red[0][wave][lane];
-#pragma unroll
-        for (int w = 1; w < 8; ++w) s += red[w][wave][lane];
-        if (SWIGLU) {
-            // lane groups 0,1 hold gate columns n0+4g.., groups 2,3 the matching up columns: fetch up from lane+32
-            u16x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float up = __shfl(s[e], (lane + 32) & 63, 64);
-                const float gt = bf2f(f2bf(s[e] * p.alpha)), u = bf2f(f2bf(up * p.alpha));
-                o[e] = f2bf(bf2f(f2bf(gt / (1.0f + __expf(-gt)))) * u);
-            }
-            const int n = n0 + g * 4;
-            if (mok && g < 2 && n < p.N) *(u16x4*)((bf16_t*)p.C + (long)z * p.sC + (long)r * p.ldc + n) = o;
-        } else {
-            const int n = n0 + wave * 16 + g * 4;
-            if (mok && n < p.N) epilogue4(p, z, r, n, s);
-        }
-    }
 }
 
 }  // namespace
@@ -809,7 +878,7 @@ static int g_persistent = 0;      // automatic choice may use the persistent ker
 static int g_stagger = 1;         // automatic choice uses the staggered schedule
 extern "C" int desta_gemm_set_persistent(int on) { g_persistent = on; return DESTA_OK; }
 static int g_skinny = 0;          // 0 auto, else COLS*10 + U of the skinny (M <= 16) kernel (tuning)
-static int g_skinny_nt = 0;       // skinny kernel streams the weights with non-temporal loads
+static int g_skinny_blocks = 512;  // persistent grid of the skinny kernel (2 blocks per CU)
 extern "C" int desta_gemm_set_option(int option, int value) {
     if (option == 0) g_persistent = value;
     else if (option == 1) g_stagger = value;
@@ -820,7 +889,10 @@ extern "C" int desta_gemm_set_option(int option, int value) {
         }
         g_skinny = value;
     }
-    else if (option == 3) g_skinny_nt = value;
+    else if (option == 3) {
+        if (value < 1 || value > 65535) { desta_set_error("gemm_set_option: skinny grid %d out of range", value); return DESTA_EINVAL; }
+        g_skinny_blocks = value;
+    }
     else { desta_set_error("gemm_set_option: unknown option %d", option); return DESTA_EINVAL; }
     return DESTA_OK;
 }
@@ -873,28 +945,32 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
             if (sp >= 2 && (size_t)rem * sp * 256 * 256 * sizeof(float) <= d->workspace_bytes) { split = sp; full = (int)(T - rem); }
         }
     }
-    if (d->act == 4) {
-        DESTA_CHECK_ARG(d->M <= 16 && d->batch >= 1 && !d->out_f32 && !d->bias && !d->residual && !d->preact && d->dropout_p == 0.f,
+    a.rms_w = d->a_rms_weight; a.rms_eps = d->a_rms_eps;
+    if (d->a_rms_weight)
+        DESTA_CHECK_ARG(d->M <= 16 && (size_t)d->M * 2 * (size_t)d->K <= (size_t)SKINNY_XS_BYTES && d->K % 512 == 0 &&
+                        (d->act == 0 || d->act == 4) && g_force_variant == 0,
+                        "gemm: a_rms_weight (fused RMSNorm of A) needs M <= 16, M*2K <= %d bytes of LDS, K %% 512 == 0, act 0 or 4", SKINNY_XS_BYTES);
+    if (d->act == 4 || (d->M <= 16 && g_force_variant == 0)) {          // decode-time projections: weight streaming
+        DESTA_CHECK_ARG(d->act != 4 || (d->M <= 16 && !d->out_f32 && !d->bias && !d->residual && !d->preact && d->dropout_p == 0.f),
                         "gemm: act 4 (SwiGLU over concatenated gate|up rows) is the decode path: M <= 16, bf16 out, no other epilogue");
-        a.tilesM = 1; a.tilesN = (d->N + 7) / 8; a.full_tiles = a.tilesN; a.split = 1; a.ws = nullptr;
-        if (g_skinny_nt) hipLaunchKernelGGL((gemm_bf16_nt_skinny_kernel<16, 2, true, true>), dim3(a.tilesN, d->batch), dim3(512), 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((gemm_bf16_nt_skinny_kernel<16, 2, false, true>), dim3(a.tilesN, d->batch), dim3(512), 0, (hipStream_t)stream, a);
-        DESTA_CHECK_LAUNCH("gemm_bf16_nt_skinny_swiglu");
-        return DESTA_OK;
-    }
-    if (d->M <= 16 && g_force_variant == 0) {                           // decode-time projections: weight streaming
-        // 16 columns x 8 K-slices per block measured fastest on every decode shape (tools/skinny_bench.py);
-        // tuning override: option 2 = COLS*10 + U, option 3 = non-temporal weight loads
+        // 16 columns x 8 K-slices per tile measured fastest on every decode shape (tools/skinny_bench.py; wider
+        // column tiles, deeper stages and non-temporal weight loads all measured slower); option 2 = COLS*10 + U
         int cols = 16, u = 2;
-        if (g_skinny) { cols = g_skinny / 10; u = g_skinny % 10; }
-        a.tilesM = 1; a.tilesN = (d->N + cols - 1) / cols; a.full_tiles = a.tilesN; a.split = 1; a.ws = nullptr;
-        const dim3 grid(a.tilesN, d->batch);
+        if (g_skinny && d->act != 4) { cols = g_skinny / 10; u = g_skinny % 10; }
+        const int ntiles = d->act == 4 ? (d->N + 7) / 8 : (d->N + cols - 1) / cols;
+        a.tilesM = 1; a.tilesN = ntiles; a.full_tiles = ntiles; a.split = 1; a.ws = nullptr;
+        const dim3 grid(ntiles < g_skinny_blocks ? ntiles : g_skinny_blocks, d->batch);
         hipStream_t st = (hipStream_t)stream;
-        if (cols == 64) hipLaunchKernelGGL((gemm_bf16_nt_skinny_kernel<64, 1, false, false>), grid, dim3(512), 0, st, a);
-        else if (cols == 32) hipLaunchKernelGGL((gemm_bf16_nt_skinny_kernel<32, 2, false, false>), grid, dim3(512), 0, st, a);
-        else if (u == 4) hipLaunchKernelGGL((gemm_bf16_nt_skinny_kernel<16, 4, false, false>), grid, dim3(512), 0, st, a);
-        else if (g_skinny_nt) hipLaunchKernelGGL((gemm_bf16_nt_skinny_kernel<16, 2, true, false>), grid, dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((gemm_bf16_nt_skinny_kernel<16, 2, false, false>), grid, dim3(512), 0, st, a);
+        const bool rms = a.rms_w != nullptr;
+#define SK_LAUNCH(C_, U_, SW_) \
+        do { if (rms) hipLaunchKernelGGL((gemm_bf16_nt_skinny_kernel<C_, U_, SW_, true>), grid, dim3(512), 0, st, a, ntiles); \
+             else hipLaunchKernelGGL((gemm_bf16_nt_skinny_kernel<C_, U_, SW_, false>), grid, dim3(512), 0, st, a, ntiles); } while (0)
+        if (d->act == 4) SK_LAUNCH(16, 2, true);
+        else if (cols == 64) SK_LAUNCH(64, 1, false);
+        else if (cols == 32) SK_LAUNCH(32, 2, false);
+        else if (u == 4) SK_LAUNCH(16, 4, false);
+        else SK_LAUNCH(16, 2, false);
+#undef SK_LAUNCH
         DESTA_CHECK_LAUNCH("gemm_bf16_nt_skinny");
         return DESTA_OK;
     }

@@ -33,7 +33,8 @@ class GemmDesc(C.Structure):
                 ("act", i32), ("out_f32", i32),
                 ("preact", vp), ("ldp", i64), ("stride_p", i64), ("alpha", f32),
                 ("aux", vp), ("ld_aux", i64), ("dropout_p", f32), ("dropout_seed", C.c_uint64),
-                ("workspace", vp), ("workspace_bytes", C.c_size_t)]
+                ("workspace", vp), ("workspace_bytes", C.c_size_t),
+                ("a_rms_weight", vp), ("a_rms_eps", f32)]
 
 
 lib.desta_abi_version.restype = i32
@@ -66,8 +67,9 @@ _gemm = _sig("desta_gemm_bf16_nt", C.POINTER(GemmDesc), vp)
 
 def gemm(A, B, out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, residual=None, ldr=None,
          act=0, preact=None, ldp=None, alpha=1.0, batch=1, stride_a=0, stride_b=0, stride_c=0,
-         stride_r=0, stride_p=0, aux=None, ld_aux=0, dropout_p=0.0, dropout_seed=0):
-    """out[M,N] = act(alpha * A[M,K] @ B[N,K]^T + bias) + residual  (bf16 operands, MFMA)."""
+         stride_r=0, stride_p=0, aux=None, ld_aux=0, dropout_p=0.0, dropout_seed=0, a_rms_weight=None, a_rms_eps=0.0):
+    """out[M,N] = act(alpha * A[M,K] @ B[N,K]^T + bias) + residual  (bf16 operands, MFMA).
+    a_rms_weight: decode path, RMSNorm(A; weight, eps) fused into the projection (see `rms_fusable`)."""
     d = GemmDesc()
     d.A, d.B, d.C = p(A), p(B), p(out)
     d.M, d.N, d.K, d.batch = M, N, K, batch
@@ -88,6 +90,7 @@ def gemm(A, B, out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, residua
     d.alpha = alpha
     d.aux, d.ld_aux = p(aux), ld_aux
     d.dropout_p, d.dropout_seed = dropout_p, dropout_seed
+    d.a_rms_weight, d.a_rms_eps = p(a_rms_weight), a_rms_eps
     ws = _gemm_ws.get(A.device)
     if ws is None:
         ws = _gemm_ws[A.device] = torch.empty(GEMM_WS_BYTES // 4, dtype=torch.float32, device=A.device)
@@ -102,6 +105,11 @@ def gemm(A, B, out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, residua
         return out
     check(_gemm(C.byref(d), stream()), "desta_gemm_bf16_nt")
     return out
+
+
+def rms_fusable(M: int, K: int) -> bool:
+    """True when `gemm(..., a_rms_weight=)` can normalise the M rows of A in LDS (decode path)."""
+    return M <= 16 and M * 2 * K <= 8 * 4096 * 2 and K % 512 == 0
 
 
 _gemm_prof = None

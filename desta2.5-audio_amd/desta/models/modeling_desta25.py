@@ -687,9 +687,16 @@ class CausalLMHIP:
         scale = self.hd ** -0.5
         H.embed_gather(self.embed, None, tokens.to(torch.int32), B, h, self.g_x)
         x = self.g_x
+        fuse = H.rms_fusable(B, h)                      # RMSNorm folded into the projection that consumes it
+
+        def proj(xin, nw, w, out, N, **kw):
+            if fuse:
+                H.gemm(xin, w, out, B, N, h, a_rms_weight=nw, a_rms_eps=c.rms_norm_eps, **kw)
+            else:
+                H.rmsnorm_fwd(xin, nw, c.rms_norm_eps, self.g_hb, self.g_r)
+                H.gemm(self.g_hb, w, out, B, N, h, **kw)
         for ly, cache in zip(self.layers, self.kv_cache):
-            H.rmsnorm_fwd(x, ly["n1"], c.rms_norm_eps, self.g_hb, self.g_r)
-            H.gemm(self.g_hb, ly["wqkv"], self.g_qkv, B, self.qkvw, h)
+            proj(x, ly["n1"], ly["wqkv"], self.g_qkv, self.qkvw)
             H.rope_kv_append(self.g_qkv, self.qkvw, B, 1, self.hq, self.hkv, self.hd, self.gen_cos_sin, ly.get("qn"), ly.get("kn"),
                              c.rms_norm_eps, pos_shift, cache, Smax * self.kvw, self.kvw, cur)     # rotate q,k + append K|V at slot cur
             ad = H.attn_desc(self.g_qkv, cache, cache, self.g_att, self.g_lse, batch=B, hq=self.hq, hkv=self.hkv, sq=1, sk=cur + 1,
@@ -698,11 +705,9 @@ class CausalLMHIP:
                              q_bs=self.qkvw, k_bs=Smax * self.kvw, v_bs=Smax * self.kvw, o_bs=self.hq * self.hd)
             H.attention_fwd(ad)
             H.gemm(self.g_att, ly["wo"], self.g_xm, B, h, self.hq * self.hd, residual=x)
-            H.rmsnorm_fwd(self.g_xm, ly["n2"], c.rms_norm_eps, self.g_hb, self.g_r)
-            H.gemm(self.g_hb, ly["wgu"], self.g_act, B, self.I, h, act=4)                       # gate|up projection + SwiGLU in one pass
+            proj(self.g_xm, ly["n2"], ly["wgu"], self.g_act, self.I, act=4)                    # norm + gate|up projection + SwiGLU
             H.gemm(self.g_act, ly["wd"], self.g_x, B, h, self.I, residual=self.g_xm)
-        H.rmsnorm_fwd(self.g_x, self.norm, c.rms_norm_eps, self.g_hb, self.g_r)
-        H.gemm(self.g_hb, self.head, self.g_logits, B, self.V, h, ldc=self.Vp)
+        proj(self.g_x, self.norm, self.head, self.g_logits, self.V, ldc=self.Vp)
         return self.g_logits
 
     def generate_greedy(self, x0_filler, B: int, S: int, kv_start: torch.Tensor, max_new_tokens: int, pad_token_id: int,

@@ -66,6 +66,9 @@ typedef struct desta_gemm_desc {
     uint64_t dropout_seed;             /*   = desta_dropout_mask(seed, m*N + n) (BertSelfOutput/BertOutput, p=0.1) */
     void* workspace;                   /* optional fp32 scratch for the split-K tail (NULL = never split);   */
     size_t workspace_bytes;            /* 64 MiB covers every shape (<= 256 slabs of 256x256 fp32)            */
+    const float* a_rms_weight;         /* decode path (M <= 16, M*2K <= 65536 B, act 0 or 4): A holds the  */
+    float a_rms_eps;                   /*   un-normalised rows; RMSNorm(A; weight, eps) is applied on the fly   */
+                                       /*   (LlamaRMSNorm fused into the projection that consumes it). NULL = off */
 } desta_gemm_desc;
 int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream);
 /* tuning / tests only: 0 = automatic tile choice, 1 = force 128x128, 2 / 3 / 4 = force the 256x256 kernel with the
@@ -73,7 +76,7 @@ int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream);
 int desta_gemm_force_variant(int variant);
 int desta_gemm_set_persistent(int on);   /* 1: the automatic choice uses the persistent kernel when a block owns > 1 item */
 /* A/B switches of the automatic choice: option 0 = persistent, 1 = staggered, 2 = skinny (M <= 16) kernel variant
- * (0 auto, else COLS*10 + U: 162 164 322 641), 3 = non-temporal weight loads in the skinny kernel */
+ * (0 auto, else COLS*10 + U: 162 164 322 641), 3 = persistent grid size of the skinny kernel (default 512 = 2 blocks per CU) */
 int desta_gemm_set_option(int option, int value);
 
 /* ------------------------------------------------------------------------------------------

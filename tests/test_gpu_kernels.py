@@ -127,13 +127,47 @@ def test_gemm_skinny_fused_swiglu(hip, M, I, K):
     out = torch.empty(M, I, dtype=torch.bfloat16, device="cuda")
     hip.gemm(x, w, out, M, I, K, act=4)
     assert torch.equal(out, ref)
-    for nt in (1, 0):                                                   # non-temporal weight loads: same bits
-        hip.gemm_set_option(3, nt)
-        o2 = torch.empty_like(out)
-        hip.gemm(x, w, o2, M, I, K, act=4)
-        g2 = torch.empty_like(gu)
-        hip.gemm(x, w, g2, M, 2 * I, K)
-        assert torch.equal(o2, ref) and torch.equal(g2, gu)
+    try:                                                                # persistent grid: several tiles per block, same bits
+        for blocks in (7, 64):
+            hip.gemm_set_option(3, blocks)
+            o2 = torch.empty_like(out)
+            hip.gemm(x, w, o2, M, I, K, act=4)
+            g2 = torch.empty_like(gu)
+            hip.gemm(x, w, g2, M, 2 * I, K)
+            assert torch.equal(o2, ref) and torch.equal(g2, gu)
+    finally:
+        hip.gemm_set_option(3, 512)
+
+
+@pytest.mark.parametrize("M,N,K", [(8, 4096, 4096), (3, 100, 512), (16, 1028, 2048), (1, 16, 1024), (8, 28672, 4096), (5, 9000, 1536)])
+def test_gemm_skinny_fused_rmsnorm(hip, M, N, K):
+    """a_rms_weight: RMSNorm folded into the skinny GEMM == rmsnorm kernel followed by the GEMM, bit for bit
+    (plain and fused-SwiGLU epilogues); shapes that do not fit the LDS budget are rejected loudly."""
+    g = torch.Generator().manual_seed(M * 5 + N)
+    assert hip.rms_fusable(M, K)
+    x = _bf(torch.randn(M, K, generator=g) * 3).cuda()
+    gamma = (1.0 + 0.1 * torch.randn(K, generator=g)).cuda()
+    w = _bf(torch.randn(2 * N, K, generator=g) / math.sqrt(K) * 2).cuda()
+    res = _bf(torch.randn(M, N, generator=g)).cuda()
+    xn = torch.empty_like(x)
+    hip.rmsnorm_fwd(x, gamma, 1e-5, xn, torch.empty(M, device="cuda"))
+    ref = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    hip.gemm(xn, w, ref, M, N, K, residual=res)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    hip.gemm(x, w, out, M, N, K, residual=res, a_rms_weight=gamma, a_rms_eps=1e-5)
+    assert torch.equal(out, ref)
+    if N % 8 == 0:
+        ref4 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        hip.gemm(xn, w, ref4, M, N, K, act=4)
+        out4 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        hip.gemm(x, w, out4, M, N, K, act=4, a_rms_weight=gamma, a_rms_eps=1e-5)
+        assert torch.equal(out4, ref4)
+    assert not hip.rms_fusable(16, 4096)
+    with pytest.raises(RuntimeError, match="a_rms_weight"):
+        big = _bf(torch.randn(16, 4096, generator=g)).cuda()
+        hip.gemm(big, w[:N, :K].contiguous() if K == 4096 else _bf(torch.randn(N, 4096, generator=g)).cuda(),
+                 torch.empty(16, N, dtype=torch.bfloat16, device="cuda"), 16, N, 4096,
+                 a_rms_weight=torch.ones(4096, device="cuda"), a_rms_eps=1e-5)
 
 
 def test_rope_kv_append(hip):

@@ -12,7 +12,7 @@ import torch  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--m", type=int, default=8)
-    ap.add_argument("--variants", default="0,-1,164,322,641")
+    ap.add_argument("--variants", default="0,-256,-768,-1024,164,322")
     a = ap.parse_args()
     from desta import _hip as H
     M = a.m
@@ -25,7 +25,7 @@ def main():
         ref = (x.float() @ Ws[0].float().T)
         line = [f"N={N:6d} K={K:5d}"]
         for v in [int(t) for t in a.variants.split(",")]:
-            H.gemm_set_option(3, 1 if v < 0 else 0)               # negative code: 16x2 with non-temporal weight loads
+            H.gemm_set_option(3, -v if v < 0 else 512)            # negative code: 16x2 with a persistent grid of -v blocks
             H.gemm_set_option(2, 0 if v < 0 else v)
             H.gemm(x, Ws[0], out, M, N, K)
             err = float((out.float() - ref).abs().max() / ref.abs().max())
@@ -42,7 +42,7 @@ def main():
             us = e0.elapsed_time(e1) * 1e3 / reps
             line.append(f"v{v}: {us:7.1f}us {N * K * 2 / us / 1e6:5.2f}TB/s")
         H.gemm_set_option(2, 0)
-        H.gemm_set_option(3, 0)
+        H.gemm_set_option(3, 512)
         print("  ".join(line), flush=True)
         del Ws
 
