@@ -522,6 +522,103 @@ __global__ __launch_bounds__(64) void argmax_final_k(const unsigned long* __rest
     if (threadIdx.x == 0) out[blockIdx.x] = (long)(unsigned)(~(unsigned)(best & 0xffffffffu));
 }
 
+// ------------------------------------------------------------------------------------ temperature + top-p sampling
+// One 1024-thread block per row.  p_j = softmax(logit_j / T).  TopPLogitsWarper keeps token i iff the mass of all
+// tokens that are not more probable than i exceeds 1 - top_p (ascending cumulative sum, TF:generation/logits_process.py);
+// logits are bf16, so "not more probable" is a comparison of 16-bit keys and the boundary is found by a 16-step binary
+// search over the key space (each step one pass over the row: L2-resident, 256 KiB for a 128k vocabulary).  Tokens that
+// TIE with the boundary logit are all kept (torch.sort leaves their order unspecified).  The sample is drawn by
+// inverting the prefix sum of the kept masses in index order with one counter-based uniform per (seed, step, row).
+__device__ __forceinline__ unsigned bf16_key(bf16_t b) { return (b & 0x8000u) ? (unsigned)(~b & 0xffffu) : (unsigned)(b | 0x8000u); }
+__device__ __forceinline__ float block_sum_1024(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i];
+    return t;
+}
+__global__ __launch_bounds__(1024) void sample_top_p_k(const bf16_t* __restrict__ x, long ld, int cols, float inv_temp, float top_p,
+                                                       unsigned seed_lo, unsigned seed_hi, unsigned step, long* __restrict__ out,
+                                                       unsigned char* __restrict__ keep_mask) {
+    __shared__ float red[16];
+    __shared__ float part[1024];
+    __shared__ int pick;
+    const bf16_t* row = x + (long)blockIdx.x * ld;
+    const int tid = threadIdx.x;
+    float mx = -INFINITY;
+    for (int c = tid; c < cols; c += 1024) mx = fmaxf(mx, bf2f(row[c]));
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = red[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, red[i]);
+    float z = 0.f;
+    for (int c = tid; c < cols; c += 1024) z += __expf((bf2f(row[c]) - mx) * inv_temp);
+    z = block_sum_1024(z, red);
+    unsigned kstar = 0;                                            // keep every token (top_p >= 1)
+    if (top_p < 1.0f) {
+        const float cut = (1.0f - top_p) * z;
+        unsigned lo = 0, hi = 65535;                               // smallest key k with F(k) = sum_{key_j <= k} e_j > cut
+        while (lo < hi) {
+            const unsigned mid = (lo + hi) >> 1;
+            float f = 0.f;
+            for (int c = tid; c < cols; c += 1024) {
+                const bf16_t b = row[c];
+                if (bf16_key(b) <= mid) f += __expf((bf2f(b) - mx) * inv_temp);
+            }
+            f = block_sum_1024(f, red);
+            if (f > cut) hi = mid; else lo = mid + 1;
+        }
+        kstar = lo;
+    }
+    // kept mass per thread over a CONTIGUOUS index chunk (so the prefix sum runs in index order)
+    const int chunk = (cols + 1023) / 1024, c0 = tid * chunk, c1 = min(cols, c0 + chunk);
+    float mine = 0.f;
+    for (int c = c0; c < c1; ++c) {
+        const bf16_t b = row[c];
+        const bool keep = bf16_key(b) >= kstar;
+        if (keep) mine += __expf((bf2f(b) - mx) * inv_temp);
+        if (keep_mask) keep_mask[(long)blockIdx.x * cols + c] = keep ? 1 : 0;
+    }
+    part[tid] = mine;
+    if (tid == 0) pick = -1;
+    __syncthreads();
+    if (tid == 0) {                                                // 1024-entry serial scan by one lane: ~2 us, fixed order
+        float tot = 0.f;
+        for (int i = 0; i < 1024; ++i) tot += part[i];
+        const unsigned r = desta_rng32(seed_lo, seed_hi, ((unsigned long)step << 32) | blockIdx.x);
+        const float target = (float)(r >> 8) * (1.0f / 16777216.0f) * tot;
+        float run = 0.f;
+        int t = 0;
+        for (; t < 1023; ++t) {
+            if (run + part[t] > target) break;
+            run += part[t];
+        }
+        // skip empty tails (rounding may leave target == tot): walk back to the last thread that holds mass
+        while (t > 0 && part[t] == 0.f) --t;
+        pick = t;
+        red[0] = target - run;
+    }
+    __syncthreads();
+    if (tid == pick) {
+        float rem = red[0], run = 0.f;
+        int tok = -1, last = -1;
+        for (int c = c0; c < c1; ++c) {
+            const bf16_t b = row[c];
+            if (bf16_key(b) >= kstar) {
+                last = c;
+                run += __expf((bf2f(b) - mx) * inv_temp);
+                if (run > rem) { tok = c; break; }
+            }
+        }
+        out[blockIdx.x] = tok >= 0 ? tok : last;
+    }
+}
+
 int nblocks(long n, int per = 256, int cap = 8192) {
     long b = (n + per - 1) / per;
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -732,5 +829,15 @@ extern "C" int desta_argmax_bf16(const void* x, int64_t ld, int rows, int cols, 
                        (unsigned long*)workspace);
     hipLaunchKernelGGL(argmax_final_k, dim3(rows), dim3(64), 0, (hipStream_t)stream, (const unsigned long*)workspace, (long*)out);
     DESTA_CHECK_LAUNCH("argmax_bf16");
+    return DESTA_OK;
+}
+
+extern "C" int desta_sample_top_p_bf16(const void* logits, int64_t ld, int rows, int cols, float temperature, float top_p,
+                                       uint64_t seed, uint32_t step, int64_t* out, uint8_t* keep_mask, void* stream) {
+    DESTA_CHECK_ARG(logits && out && rows > 0 && cols > 0, "sample_top_p: bad argument");
+    DESTA_CHECK_ARG(temperature > 0.f && top_p > 0.f && top_p <= 1.f, "sample_top_p: need temperature > 0 and 0 < top_p <= 1");
+    hipLaunchKernelGGL(sample_top_p_k, dim3(rows), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)logits, (long)ld, cols,
+                       1.0f / temperature, top_p, (unsigned)seed, (unsigned)(seed >> 32), step, (long*)out, keep_mask);
+    DESTA_CHECK_LAUNCH("sample_top_p");
     return DESTA_OK;
 }

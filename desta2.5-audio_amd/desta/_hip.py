@@ -447,3 +447,12 @@ def rope_kv_append(buf, ld, rows, seq, n_q, n_kv, hd, cos_sin, q_norm_w, k_norm_
     """Forward rope on a fused q|k|v buffer + append of the rotated K and the V heads to the KV cache slab."""
     check(_rope_kv(p(buf), ld, rows, seq, n_q, n_kv, hd, p(cos_sin), p(q_norm_w), p(k_norm_w), eps, p(pos_shift), p(cache), kv_bs,
                    kv_rs, slot0, stream()), "desta_rope_kv_append")
+
+
+_sample = _sig("desta_sample_top_p_bf16", vp, i64, i32, i32, f32, f32, C.c_uint64, C.c_uint32, vp, vp, vp)
+
+
+def sample_top_p(logits, ld, rows, cols, temperature, top_p, seed, step, out, keep_mask=None):
+    """One temperature / top-p sample per row of bf16 logits (HF `generate(do_sample=True)` step)."""
+    check(_sample(p(logits), ld, rows, cols, temperature, top_p, seed & 0xFFFFFFFFFFFFFFFF, step & 0xFFFFFFFF, p(out), p(keep_mask),
+                  stream()), "desta_sample_top_p_bf16")

@@ -711,8 +711,9 @@ class CausalLMHIP:
         return self.g_logits
 
     def generate_greedy(self, x0_filler, B: int, S: int, kv_start: torch.Tensor, max_new_tokens: int, pad_token_id: int,
-                        eos_token_ids=None, forced_tokens: Optional[torch.Tensor] = None, collect_logits: bool = False):
-        """Prompt pass + KV-cached greedy decode.  Returns new token ids [B, n_new] (int64; finished sequences are
+                        eos_token_ids=None, forced_tokens: Optional[torch.Tensor] = None, collect_logits: bool = False,
+                        do_sample: bool = False, temperature: float = 1.0, top_p: float = 1.0, seed: int = 0):
+        """Prompt pass + KV-cached decode (greedy, or temperature / top-p sampling with the library's counter RNG).  Returns new token ids [B, n_new] (int64; finished sequences are
         filled with pad_token_id, generation stops early once every sequence has produced an EOS), and, with
         collect_logits, the per-step logits [n_new, B, V] (bf16).  `forced_tokens` [B, T] teacher-forces the
         continuation (parity tests compare per-step logits with the oracle on the same prefix)."""
@@ -732,7 +733,10 @@ class CausalLMHIP:
         for t in range(max_new_tokens):
             if collect_logits:
                 steps_logits.append(logits[:, :self.V].clone())
-            H.argmax_bf16(logits, self.Vp, B, self.V, self.g_next)
+            if do_sample:
+                H.sample_top_p(logits, self.Vp, B, self.V, float(temperature), float(top_p), seed, t, self.g_next)
+            else:
+                H.argmax_bf16(logits, self.Vp, B, self.V, self.g_next)
             nxt = self.g_next if forced_tokens is None else forced_tokens[:, t].to(dev, torch.int64)
             nxt = torch.where(finished, torch.full_like(nxt, int(pad_token_id)), nxt)
             out[:, t] = nxt
@@ -973,14 +977,12 @@ class DeSTA25AudioModel:
 
     @torch.no_grad()
     def _generate_step(self, inputs, pad_token_id, temperature=0.7, top_p=0.9, max_new_tokens=512, do_sample=True,
-                       eos_token_id=None, forced_tokens=None, collect_logits=False):
+                       eos_token_id=None, forced_tokens=None, collect_logits=False, seed=0):
         """Reference `_generate_step` (modeling_desta25.py:1358-1431): audio features spliced into the prompt
-        embeddings, then `llm_model.generate(inputs_embeds=…)` — here the KV-cached greedy decoder on the HIP path.
-        Returns ONLY the new tokens, as HF does for inputs_embeds prompts.  Sampling (do_sample=True: temperature /
-        top-p) is not implemented on this path; the trainer's evaluation configs all use do_sample=False."""
-        if do_sample:
-            raise NotImplementedError("do_sample=True (temperature / top-p sampling) is not implemented on the MI355X path; "
-                                      "pass do_sample=False for greedy decoding")
+        embeddings, then `llm_model.generate(inputs_embeds=…)` — here the KV-cached decoder on the HIP path.
+        Returns ONLY the new tokens, as HF does for inputs_embeds prompts.  do_sample=False: greedy (temperature / top_p
+        ignored, as the reference nulls them).  do_sample=True: temperature -> top-p -> one multinomial draw per step
+        with the library's counter RNG (`seed`; same distribution as HF, not torch's random stream)."""
         cfg, dev = self.config, self.device
         input_ids = inputs["context_input_ids"].to(dev)                      # only the context (prompt) part of the batch
         attention_mask = inputs["context_attention_mask"].to(dev)
@@ -1019,7 +1021,9 @@ class DeSTA25AudioModel:
                     eos = [eos]
                 self._fwd = None
                 return self.llm.generate_greedy(fill, B, S, kv_start, int(max_new_tokens), int(pad_token_id), eos,
-                                                forced_tokens=forced_tokens, collect_logits=collect_logits)
+                                                forced_tokens=forced_tokens, collect_logits=collect_logits, do_sample=bool(do_sample),
+                                                temperature=1.0 if temperature is None else float(temperature),
+                                                top_p=1.0 if top_p is None else float(top_p), seed=int(seed))
         finally:
             self.training = was_training
 

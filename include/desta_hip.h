@@ -249,6 +249,15 @@ int desta_dropout_mask_u8(uint64_t seed, int64_t n, float p, uint8_t* out, void*
 size_t desta_argmax_workspace_bytes(int rows);
 int desta_argmax_bf16(const void* x, int64_t ld, int rows, int cols, int64_t* out, void* workspace, void* stream);
 
+/* `do_sample=True` step of `llm_model.generate` (modeling_desta25.py:1419-1427: temperature, top_p):
+ * TemperatureLogitsWarper -> TopPLogitsWarper -> one multinomial draw per row
+ * (TF:generation/logits_process.py, TF:generation/utils.py `_sample`).  Token i is kept iff the softmax mass of all
+ * tokens not more probable than i exceeds 1 - top_p; tokens tying with the boundary logit are all kept.  The draw uses
+ * the library's counter-based RNG (seed, step, row) — same distribution as torch.multinomial, not the same stream.
+ * keep_mask (optional, uint8 [rows, cols]) exports the kept set (tests). */
+int desta_sample_top_p_bf16(const void* logits, int64_t ld, int rows, int cols, float temperature, float top_p,
+                            uint64_t seed, uint32_t step, int64_t* out, uint8_t* keep_mask, void* stream);
+
 /* desta_rope (forward) on a fused q|k|v projection [rows, ld] that ALSO appends the rotated K heads and the V heads of
  * row (b, s) to a KV cache slab: kv_cache + b*kv_batch_stride + (slot0 + s)*kv_row_stride, K heads then V heads.
  * This is what `DynamicCache.update` does inside `llm_model.generate` (modeling_desta25.py:1419) for the prompt

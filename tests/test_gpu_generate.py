@@ -97,7 +97,7 @@ def test_generate_early_stop_and_no_audio():
     ref1, _ = O.greedy_generate(w, d, x, am, 24, 0, eos_token_ids=first, forced_tokens=ref)
     assert out1.cpu().tolist() == ref1.tolist() and out1.shape[1] == 1
     with pytest.raises(NotImplementedError):
-        model._generate_step(inputs, pad_token_id=0, max_new_tokens=4, do_sample=True)
+        model.generate([{"role": "user", "content": "hi"}])
 
 
 def test_argmax_kernel():
@@ -112,3 +112,104 @@ def test_argmax_kernel():
     assert int(out[2]) == 17 and int(out[5]) == 999
     H.argmax_bf16(x, 1000, 7, 900, out)                 # only the first `cols` entries are searched
     assert int(out[5]) != 999 and int(out[2]) == 17
+
+
+@pytest.mark.parametrize("V,temp,top_p", [(1000, 0.7, 0.9), (128256, 0.7, 0.9), (151936, 1.3, 0.5), (512, 1.0, 1.0), (4099, 0.3, 0.999)])
+def test_top_p_kept_set_matches_hf_warpers(V, temp, top_p):
+    """The kept set of desta_sample_top_p_bf16 == TemperatureLogitsWarper -> TopPLogitsWarper of transformers on the same
+    (bf16-valued) logits.  Allowed differences: tokens whose cumulative mass is within 2e-5 of the cut-off (fp32 summation
+    order) and tokens that tie with the boundary logit (torch.sort leaves their order unspecified; we keep all of them)."""
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopPLogitsWarper
+    from desta import _hip as H
+    g = torch.Generator().manual_seed(V)
+    rows = 5
+    logits = (torch.randn(rows, V, generator=g) * 3.0).to(torch.bfloat16)
+    logits[1, :7] = 9.0                                   # a tie group at the top
+    ld = V + 8 - V % 8
+    buf = torch.zeros(rows, ld, dtype=torch.bfloat16, device="cuda")
+    buf[:, :V] = logits.cuda()
+    out = torch.zeros(rows, dtype=torch.int64, device="cuda")
+    mask = torch.zeros(rows, V, dtype=torch.uint8, device="cuda")
+    H.sample_top_p(buf, ld, rows, V, temp, top_p, 1234, 0, out, keep_mask=mask)
+    kept = mask.cpu().bool()
+    scores = TemperatureLogitsWarper(temp)(None, logits.float())
+    if top_p < 1.0:
+        scores = TopPLogitsWarper(top_p)(None, scores)
+    ref = torch.isfinite(scores)
+    probs = torch.softmax(logits.float() / temp, -1)
+    for r in range(rows):
+        diff = (kept[r] != ref[r]).nonzero().flatten()
+        if diff.numel():
+            sp, _ = torch.sort(probs[r])
+            cum = torch.cumsum(sp.double(), 0)
+            for i in diff.tolist():
+                c_i = float(cum[int((sp <= probs[r, i]).sum()) - 1])          # mass of tokens not more probable than i
+                boundary_tie = bool((probs[r][ref[r]].min() == probs[r, i]) or (probs[r][kept[r]].min() == probs[r, i]))
+                assert abs(c_i - (1.0 - top_p)) < 2e-5 or boundary_tie, (r, i, c_i)
+        assert kept[r, int(logits[r].float().argmax())]                      # min_tokens_to_keep = 1
+        assert kept[r, int(out[r])]                                          # the sample is one of the kept tokens
+    # (every differing token was justified above; with 128k bf16 logits the boundary tie group alone holds ~20 tokens)
+    assert int(kept.sum()) > 0 and int((ref & ~kept).sum()) <= rows
+
+
+def test_top_p_sampling_distribution():
+    """Frequencies of 20000 draws (different step counters) match the renormalised kept probabilities."""
+    from desta import _hip as H
+    V, n = 64, 20000
+    g = torch.Generator().manual_seed(2)
+    logits = (torch.randn(1, V, generator=g) * 2).to(torch.bfloat16)
+    probs = torch.softmax(logits.float() / 0.8, -1)[0]
+    rows = 8
+    buf = logits.cuda().repeat(rows, 1).contiguous()
+    mask = torch.zeros(rows, V, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(rows, dtype=torch.int64, device="cuda")
+    counts = torch.zeros(V)
+    outs = []
+    for step in range(n // rows):
+        H.sample_top_p(buf, V, rows, V, 0.8, 0.9, 99, step, out, keep_mask=mask)
+        outs.append(out.clone())
+    toks = torch.cat(outs).cpu()
+    counts = torch.bincount(toks, minlength=V).float()
+    kept = mask[0].cpu().bool()
+    assert counts[~kept].sum() == 0
+    q = torch.where(kept, probs, torch.zeros_like(probs))
+    q = q / q.sum()
+    freq = counts / counts.sum()
+    # 5-sigma binomial bound per token
+    sigma = torch.sqrt(q * (1 - q) / n)
+    assert bool(((freq - q).abs() <= 5 * sigma + 1e-4).all()), (freq - q).abs().max()
+    # reproducible: same (seed, step, row) -> same token; another seed -> another sequence
+    o1, o2, o3 = (torch.zeros(rows, dtype=torch.int64, device="cuda") for _ in range(3))
+    H.sample_top_p(buf, V, rows, V, 0.8, 0.9, 99, 5, o1)
+    H.sample_top_p(buf, V, rows, V, 0.8, 0.9, 99, 5, o2)
+    assert torch.equal(o1, o2) and torch.equal(o1, outs[5])
+    assert len(set(toks[:64].tolist())) > 4
+
+
+def test_generate_step_sampling_end_to_end(golden_dir):
+    """do_sample=True through _generate_step: reproducible per seed, every sampled token inside the top-p set of the fp32
+    oracle logits for the product's own prefix (up to bf16 noise at the set boundary), top_p -> 0 degenerates to greedy."""
+    d = O.tiny_dims(False)
+    g, batch = golden_batch(golden_dir, "llama")
+    model, w = _model(d)
+    inputs = _gen_inputs(g, batch)
+    a = model._generate_step(inputs, pad_token_id=0, max_new_tokens=10, do_sample=True, temperature=0.7, top_p=0.9, seed=3).cpu()
+    b = model._generate_step(inputs, pad_token_id=0, max_new_tokens=10, do_sample=True, temperature=0.7, top_p=0.9, seed=3).cpu()
+    c = model._generate_step(inputs, pad_token_id=0, max_new_tokens=10, do_sample=True, temperature=0.7, top_p=0.9, seed=4).cpu()
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    lo = _oracle_logits(w, d, g, batch, a)                                   # [T, B, V] fp32 logits on the sampled prefix
+    p = torch.softmax(lo / 0.7, -1)
+    sp, _ = torch.sort(p, dim=-1)
+    cum = torch.cumsum(sp, -1)
+    for t in range(a.shape[1]):
+        for r in range(a.shape[0]):
+            pi = p[t, r, a[r, t]]
+            c_i = float(cum[t, r, int((sp[t, r] <= pi).sum()) - 1])
+            assert c_i > (1.0 - 0.9) - 2e-2, (t, r, c_i)                      # inside the nucleus (bf16 logits move the edge slightly)
+    # top_p -> 0 keeps only the most probable logit value: every sampled token attains the row maximum of the step's
+    # logits (bf16 logits can TIE — then greedy takes the first index, sampling any member of the tie group)
+    nearly, lg = model._generate_step(inputs, pad_token_id=0, max_new_tokens=6, do_sample=True, temperature=0.7, top_p=1e-6, seed=1,
+                                      collect_logits=True)
+    lg = lg.float()
+    picked = lg.gather(-1, nearly.t().unsqueeze(-1)).squeeze(-1)
+    assert torch.equal(picked, lg.max(-1).values)
