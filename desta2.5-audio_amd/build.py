@@ -21,6 +21,7 @@ LIB = os.path.join(OUT_DIR, "libdesta_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast",
          "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-Wno-unused-result"]
+FLAGS += os.environ.get("DESTA_EXTRA_HIPCC_FLAGS", "").split()      # kernel A/B experiments (-DNAME=value)
 
 
 def _digest(paths):

@@ -114,8 +114,14 @@ __device__ __forceinline__ bf16x8 acc_frag(const f32x16& x, int s) {
 __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 // ------------------------------------------------------------------------------------------ forward
+// Occupancy beats prefetch depth here (measured, tools/attn_bench.py): with K/V register-staged ONE tile ahead the
+// kernel fits 256 VGPRs at D=128 (160 at D=64) -> 2 (3) blocks per CU, whose MFMA / softmax / staging phases overlap
+// each other: LLM shape 104 -> 69 us, Whisper shape 190 -> 157 us vs two tiles ahead at one block per CU.
+#ifndef ATTN_FWD_PF
+#define ATTN_FWD_PF 1
+#endif
 template <int D, bool DROP>
-__global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_k(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char lds[2 * 64 * D * 2];
     char* kimg = lds;
     char* vimg = lds + 64 * D * 2;
@@ -148,9 +154,8 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
         for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
     float m = -INFINITY, l = 0.f;
 
-    // K/V tiles are register-staged TWO tiles ahead (two register sets, loop unrolled by two through the
-    // `step` lambda): under load an L2/HBM round trip outlasts one tile of MFMA work.
-    constexpr int PF = 2;                                  // prefetch distance in tiles (1 or 2)
+    // K/V tiles are register-staged PF tiles ahead (PF = 2: two register sets, loop unrolled by two)
+    constexpr int PF = ATTN_FWD_PF;                        // prefetch distance in tiles (1 or 2)
     stage_t<D, 64> kr0 = {}, vr0 = {}, kr1 = {}, vr1 = {};
     if (t_lo < t_hi) {
         kr0 = tile_load<D, 64>(kbase, p.k_rs, t_lo * 64, p.Sk - 1);
@@ -293,8 +298,16 @@ __global__ __launch_bounds__(256) void attn_delta_k(AttnArgs p, float* __restric
 }
 
 // ------------------------------------------------------------------------------------------ backward: dQ
+// same trade as the forward: one tile ahead + two blocks per CU (131 -> 103 us on the LLM shape; two tiles ahead
+// squeezed into 256 registers spills and is slower than either)
+#ifndef ATTN_DQ_PF
+#define ATTN_DQ_PF 1
+#endif
+#ifndef ATTN_DQ_BLOCKS
+#define ATTN_DQ_BLOCKS 2
+#endif
 template <int D, bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dq_k(AttnArgs p) {
+__global__ __launch_bounds__(256, ATTN_DQ_BLOCKS) void attn_bwd_dq_k(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char lds[2 * 64 * D * 2];
     char* kimg = lds;
     char* vimg = lds + 64 * D * 2;
@@ -332,9 +345,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
 
-    // K/V tiles are register-staged TWO tiles ahead (two register sets, loop unrolled by two through the
-    // `step` lambda): under load an L2/HBM round trip outlasts one tile of MFMA work.
-    constexpr int PF = 2;                                  // prefetch distance in tiles (1 or 2)
+    // K/V tiles are register-staged PF tiles ahead (PF = 2: two register sets, loop unrolled by two)
+    constexpr int PF = ATTN_DQ_PF;                         // prefetch distance in tiles (1 or 2)
     stage_t<D, 64> kr0 = {}, vr0 = {}, kr1 = {}, vr1 = {};
     if (t_lo < t_hi) {
         kr0 = tile_load<D, 64>(kbase, p.k_rs, t_lo * 64, p.Sk - 1);

@@ -1,0 +1,39 @@
+"""Time the flash-attention kernels on the two shapes of the training step (events around repeated launches).
+  python tools/attn_bench.py"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "desta2.5-audio_amd"))
+import torch
+from desta import _hip as hip
+
+
+def t_us(fn, reps=20):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+for name, (B, Hq, Hkv, S, D, causal) in {"llm S=640 D=128 causal GQA": (8, 32, 8, 640, 128, True),
+                                         "whisper S=1500 D=64": (8, 20, 20, 1500, 64, False),
+                                         "qformer self S=64 D=64": (32, 20, 20, 64, 64, False)}.items():
+    g = torch.Generator(device="cuda").manual_seed(1)
+    wq, wkv = Hq * D, Hkv * D
+    qkv = torch.randn(B * S, wq + 2 * wkv, generator=g, device="cuda").to(torch.bfloat16)
+    o = torch.zeros(B * S, wq, dtype=torch.bfloat16, device="cuda")
+    do = torch.randn(B * S, wq, generator=g, device="cuda").to(torch.bfloat16)
+    lse = torch.zeros(B, Hq, S, device="cuda")
+    dqkv = torch.zeros_like(qkv)
+    d = hip.attn_desc(qkv, qkv, qkv, o, lse, batch=B, hq=Hq, hkv=Hkv, sq=S, sk=S, hd=D, scale=D ** -0.5, causal=causal,
+                      kv_start=None, q_off=0, k_off=wq, v_off=wq + wkv)
+    f = t_us(lambda: hip.attention_fwd(d))
+    bw = t_us(lambda: hip.attention_bwd(d, do, dqkv, dqkv, dqkv, dq_off=0, dk_off=wq, dv_off=wq + wkv))
+    fl = 4.0 * B * Hq * S * S * D * (0.5 if causal else 1.0)
+    print(f"{name:30s} fwd {f:7.1f} us ({fl / f / 1e6:6.0f} TF/s)   bwd {bw:7.1f} us ({2.5 * fl / bw / 1e6:6.0f} TF/s)", flush=True)
