@@ -161,6 +161,28 @@ __device__ __forceinline__ void epilogue_pair_bf16(const GemmArgs& p, int z, int
     if (row_ok) *(uint4*)((bf16_t*)p.C + (long)z * p.sC + (long)m * p.ldc + col) = make_uint4(lo[0], hi[0], lo[1], hi[1]);
 }
 
+// TA / TB: the operand is stored TRANSPOSED, i.e. as [K, M] (resp. [K, N]) row-major with the reduction index as
+// the slow dimension — what autograd's dW = dY^T X and dX = dY W need without materialising a transpose.  Its LDS
+// tile image is [64 k][128 out] (256-B rows); the 16-B chunk c of row k sits at slot c ^ f(k), f(k) = (k & 3) |
+// ((k >> 3) & 3) << 2, so that the 16 (k-group, k) rows a `ds_read_b64_tr_b16` fragment read touches fall on 16
+// distinct chunk slots (2 wave-cycles for 512 B: conflict-free).  A fragment = two transpose reads: each gives a
+// lane 4 consecutive k of ONE output index, exactly the 16x16x32 operand layout (lane = out index, k = 8g..8g+7).
+__device__ __forceinline__ int tr_swz(int k) { return (k & 3) | (((k >> 3) & 3) << 2); }
+__device__ __forceinline__ bf16x8 frag_trans(const char* img, int out0, int kk, int fr, int fq) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+    const int col = out0 + 4 * (fr & 3);                                 // this lane's 4-column piece of the 16-column block
+    bf16x8 o;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const int k = kk * 32 + 8 * fq + 4 * s2 + (fr >> 2);
+        const int off = k * 256 + (((col >> 3) ^ tr_swz(k)) << 4) + ((col & 4) << 1);
+        const bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)(img + off));
+        o[4 * s2 + 0] = v[0]; o[4 * s2 + 1] = v[1]; o[4 * s2 + 2] = v[2]; o[4 * s2 + 3] = v[3];
+    }
+    return o;
+}
+
+template <bool TA, bool TB>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) char lds[2 * 2 * TILE_BYTES];   // [buf][A|B]
 
@@ -188,20 +210,30 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int idx = i * 256 + tid;                  // chunk index in the tile image
-        const int r = idx >> 3, pc = idx & 7;
-        const int c = pc ^ (r & 7);                     // logical chunk stored at physical slot pc
-        const int ra = min(brow + r, p.M - 1), rb = min(bcol + r, p.N - 1);
-        srcA[i] = A + (long)ra * p.lda + c * 8;
-        srcB[i] = B + (long)rb * p.ldb + c * 8;
+        if (TA) {                                       // image [64 k][16 chunks of 8 outputs]
+            const int k = idx >> 4, c = (idx & 15) ^ tr_swz(k);
+            srcA[i] = A + (long)k * p.lda + min(brow + c * 8, p.M - 8);      // clamped chunks feed rows >= M only
+        } else {
+            const int r = idx >> 3, c = (idx & 7) ^ (r & 7);                 // logical chunk stored at physical slot idx & 7
+            srcA[i] = A + (long)min(brow + r, p.M - 1) * p.lda + c * 8;
+        }
+        if (TB) {
+            const int k = idx >> 4, c = (idx & 15) ^ tr_swz(k);
+            srcB[i] = B + (long)k * p.ldb + min(bcol + c * 8, p.N - 8);
+        } else {
+            const int r = idx >> 3, c = (idx & 7) ^ (r & 7);
+            srcB[i] = B + (long)min(bcol + r, p.N - 1) * p.ldb + c * 8;
+        }
     }
+    const long stepA = TA ? (long)BK * p.lda : BK, stepB = TB ? (long)BK * p.ldb : BK;
     auto stage = [&](int buf, int kt) {
         char* la = lds + buf * 2 * TILE_BYTES;
         char* lb = la + TILE_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int wbase = (i * 256 + wave * 64) * 16;           // wave-uniform LDS base
-            glds16(srcA[i] + (long)kt * BK, la + wbase);
-            glds16(srcB[i] + (long)kt * BK, lb + wbase);
+            glds16(srcA[i] + kt * stepA, la + wbase);
+            glds16(srcB[i] + kt * stepB, lb + wbase);
         }
     };
 
@@ -236,8 +268,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 // logical chunk = kk*4 + fq  ->  physical = (kk*4 + fq) ^ (row&7) = offX ^ (kk<<6)
-                af[i] = *(const bf16x8*)(la + (offA[i] ^ (kk << 6)));
-                bfr[i] = *(const bf16x8*)(lb + (offB[i] ^ (kk << 6)));
+                if (TA) af[i] = frag_trans(la, wr * 64 + i * 16, kk, fr, fq);
+                else af[i] = *(const bf16x8*)(la + (offA[i] ^ (kk << 6)));
+                if (TB) bfr[i] = frag_trans(lb, wc * 64 + i * 16, kk, fr, fq);
+                else bfr[i] = *(const bf16x8*)(lb + (offB[i] ^ (kk << 6)));
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -908,6 +942,9 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
     DESTA_CHECK_ARG(d->batch >= 1 && d->batch <= 65535, "gemm: bad batch %d", d->batch);
     DESTA_CHECK_ARG(!d->residual || d->ldr % 4 == 0, "gemm: ldr must be a multiple of 4");
     DESTA_CHECK_ARG(!d->preact || d->ldp % 4 == 0, "gemm: ldp must be a multiple of 4");
+    DESTA_CHECK_ARG(!d->trans_a || (d->M % 8 == 0 && d->M >= 8), "gemm: trans_a needs M to be a multiple of 8");
+    DESTA_CHECK_ARG(!d->trans_b || (d->N % 8 == 0 && d->N >= 8), "gemm: trans_b needs N to be a multiple of 8");
+    DESTA_CHECK_ARG(!(d->trans_a || d->trans_b) || (d->act != 4 && !d->a_rms_weight), "gemm: trans_a / trans_b not available on the decode path");
     GemmArgs a;
     a.A = (const bf16_t*)d->A; a.B = (const bf16_t*)d->B; a.C = d->C;
     a.M = d->M; a.N = d->N; a.K = d->K;
@@ -950,7 +987,7 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
         DESTA_CHECK_ARG(d->M <= 16 && (size_t)d->M * 2 * (size_t)d->K <= (size_t)SKINNY_XS_BYTES && d->K % 512 == 0 &&
                         (d->act == 0 || d->act == 4) && g_force_variant == 0,
                         "gemm: a_rms_weight (fused RMSNorm of A) needs M <= 16, M*2K <= %d bytes of LDS, K %% 512 == 0, act 0 or 4", SKINNY_XS_BYTES);
-    if (d->act == 4 || (d->M <= 16 && g_force_variant == 0)) {          // decode-time projections: weight streaming
+    if (d->act == 4 || (d->M <= 16 && g_force_variant == 0 && !d->trans_a && !d->trans_b)) {          // decode-time projections: weight streaming
         DESTA_CHECK_ARG(d->act != 4 || (d->M <= 16 && !d->out_f32 && !d->bias && !d->residual && !d->preact && d->dropout_p == 0.f),
                         "gemm: act 4 (SwiGLU over concatenated gate|up rows) is the decode path: M <= 16, bf16 out, no other epilogue");
         // 16 columns x 8 K-slices per tile measured fastest on every decode shape (tools/skinny_bench.py; wider
@@ -983,6 +1020,7 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
     }
     if (g_force_variant == 1) big = false;
     if (g_force_variant >= 2) big = true;
+    if (d->trans_a || d->trans_b) big = false;                          // transposed-storage operands: 128x128 kernel only
     if (big) {
         a.tilesM = tM; a.tilesN = tN;
         a.full_tiles = full; a.split = split; a.ws = (float*)d->workspace;
@@ -999,7 +1037,10 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
         a.tilesM = (d->M + BM - 1) / BM; a.tilesN = (d->N + BN - 1) / BN;
         a.full_tiles = a.tilesM * a.tilesN; a.split = 1; a.ws = nullptr;
         dim3 grid(a.tilesM * a.tilesN, d->batch);
-        hipLaunchKernelGGL(gemm_bf16_nt_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+        if (d->trans_a && d->trans_b) hipLaunchKernelGGL((gemm_bf16_nt_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        else if (d->trans_b) hipLaunchKernelGGL((gemm_bf16_nt_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        else if (d->trans_a) hipLaunchKernelGGL((gemm_bf16_nt_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((gemm_bf16_nt_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
     }
     DESTA_CHECK_LAUNCH("gemm_bf16_nt");
     return DESTA_OK;

@@ -34,7 +34,7 @@ class GemmDesc(C.Structure):
                 ("preact", vp), ("ldp", i64), ("stride_p", i64), ("alpha", f32),
                 ("aux", vp), ("ld_aux", i64), ("dropout_p", f32), ("dropout_seed", C.c_uint64),
                 ("workspace", vp), ("workspace_bytes", C.c_size_t),
-                ("a_rms_weight", vp), ("a_rms_eps", f32)]
+                ("trans_a", i32), ("trans_b", i32), ("a_rms_weight", vp), ("a_rms_eps", f32)]
 
 
 lib.desta_abi_version.restype = i32
@@ -67,14 +67,16 @@ _gemm = _sig("desta_gemm_bf16_nt", C.POINTER(GemmDesc), vp)
 
 def gemm(A, B, out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, residual=None, ldr=None,
          act=0, preact=None, ldp=None, alpha=1.0, batch=1, stride_a=0, stride_b=0, stride_c=0,
-         stride_r=0, stride_p=0, aux=None, ld_aux=0, dropout_p=0.0, dropout_seed=0, a_rms_weight=None, a_rms_eps=0.0):
+         stride_r=0, stride_p=0, aux=None, ld_aux=0, dropout_p=0.0, dropout_seed=0, a_rms_weight=None, a_rms_eps=0.0,
+         trans_a=False, trans_b=False):
     """out[M,N] = act(alpha * A[M,K] @ B[N,K]^T + bias) + residual  (bf16 operands, MFMA).
     a_rms_weight: decode path, RMSNorm(A; weight, eps) fused into the projection (see `rms_fusable`)."""
     d = GemmDesc()
     d.A, d.B, d.C = p(A), p(B), p(out)
     d.M, d.N, d.K, d.batch = M, N, K, batch
-    d.lda = K if lda is None else lda
-    d.ldb = K if ldb is None else ldb
+    d.lda = (M if trans_a else K) if lda is None else lda       # transposed storage: A is [K, M], B is [K, N]
+    d.ldb = (N if trans_b else K) if ldb is None else ldb
+    d.trans_a, d.trans_b = int(trans_a), int(trans_b)
     d.ldc = N if ldc is None else ldc
     d.stride_a, d.stride_b, d.stride_c = stride_a, stride_b, stride_c
     d.bias = p(bias)

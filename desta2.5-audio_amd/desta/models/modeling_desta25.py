@@ -344,7 +344,8 @@ class QformerConnectorHIP:
         self.B = 0
         self.p_drop = 0.0                      # set per forward by the model (cfg.qformer_dropout in training mode)
         self.seed_base = 0
-        # transposed bf16 weights for the dX GEMMs: name -> [in, out]
+        # transposed bf16 weights for the dX GEMMs: name -> [in, out] (refreshed on the optimizer's side stream; reading W
+        # itself as a transposed-storage operand measured 25-45 % slower per dX GEMM, tools/tn_bench.py)
         self.wT: Dict[str, torch.Tensor] = {}
 
     # -- views
@@ -475,14 +476,20 @@ class QformerConnectorHIP:
     # -- backward helpers
     def _dW(self, dY, X, M, N, Kin, wname, bname, Mp, x_is_T=None):
         """grad(wname)[N,Kin] = dY[M,N]^T @ X[M,Kin];  grad(bname)[N] = colsum(dY).  bf16 operands."""
-        tA = self.tA[: N * Mp].view(N, Mp)
-        H.transpose_to_bf16(dY, M, N, tA, Mp, ld_in=dY.shape[-1])
-        if x_is_T is None:
-            tB = self.tB[: Kin * Mp].view(Kin, Mp)
-            H.transpose_to_bf16(X, M, Kin, tB, Mp, ld_in=X.shape[-1])
+        gw = self.G(wname) if N == self.arena.shapes[wname][0] else self._gwide(wname, N)
+        if M % 64 == 0 and x_is_T is None:
+            # both operands in transposed storage ([M, N] and [M, Kin], reduction index slow): no transposes
+            # (44 vs 59 us per dW at N=3840, Kin=1280, M=2048: tools/tn_bench.py)
+            H.gemm(dY, X, gw, N, Kin, M, trans_a=True, trans_b=True, lda=dY.shape[-1], ldb=X.shape[-1])
         else:
-            tB = x_is_T
-        H.gemm(tA, tB, self.G(wname) if N == self.arena.shapes[wname][0] else self._gwide(wname, N), N, Kin, Mp)
+            tA = self.tA[: N * Mp].view(N, Mp)
+            H.transpose_to_bf16(dY, M, N, tA, Mp, ld_in=dY.shape[-1])
+            if x_is_T is None:
+                tB = self.tB[: Kin * Mp].view(Kin, Mp)
+                H.transpose_to_bf16(X, M, Kin, tB, Mp, ld_in=X.shape[-1])
+            else:
+                tB = x_is_T
+            H.gemm(tA, tB, gw, N, Kin, Mp)
         if bname is not None:
             H.colsum(dY, M, N, dY.shape[-1], self.G32(bname, N))
 

@@ -66,6 +66,9 @@ typedef struct desta_gemm_desc {
     uint64_t dropout_seed;             /*   = desta_dropout_mask(seed, m*N + n) (BertSelfOutput/BertOutput, p=0.1) */
     void* workspace;                   /* optional fp32 scratch for the split-K tail (NULL = never split);   */
     size_t workspace_bytes;            /* 64 MiB covers every shape (<= 256 slabs of 256x256 fp32)            */
+    int trans_a, trans_b;              /* != 0: the operand is stored transposed, A as [K,M] (lda = row stride), B as   */
+                                       /*   [K,N]: autograd's dW = dY^T X (both) and dX = dY W (trans_b) without a        */
+                                       /*   materialised transpose; M resp. N must be a multiple of 8                     */
     const float* a_rms_weight;         /* decode path (M <= 16, M*2K <= 65536 B, act 0 or 4): A holds the  */
     float a_rms_eps;                   /*   un-normalised rows; RMSNorm(A; weight, eps) is applied on the fly   */
                                        /*   (LlamaRMSNorm fused into the projection that consumes it). NULL = off */

@@ -199,6 +199,29 @@ def test_rope_kv_append(hip):
         assert bool((cache[:, 8] == 0).all()) and torch.equal(cache[:, :S], ref.view(B, S, ld)[:, :, hq * hd:])
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (3840, 1280, 2048), (1280, 3072, 2048), (200, 136, 192), (2048, 1280, 3840), (8, 8, 64)])
+def test_gemm_transposed_operands(hip, M, N, K):
+    """trans_a / trans_b: operands stored [K,M] / [K,N] (autograd's dW = dY^T X, dX = dY W) == the NT kernel on
+    materialised transposes, bit for bit (same products, same order), incl. ragged tile edges and padded leading dims."""
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    At = _bf(torch.randn(K, M + 8, generator=g)).cuda()                # [K, M] view with lda = M + 8
+    Bt = _bf(torch.randn(K, N, generator=g)).cuda()
+    A = At[:, :M].t().contiguous()
+    B = Bt.t().contiguous()
+    bias = torch.randn(N, generator=g).cuda()
+    try:
+        hip.gemm_force_variant(1)
+        ref = torch.empty(M, N, dtype=torch.float32, device="cuda")
+        hip.gemm(A, B, ref, M, N, K, bias=bias)
+    finally:
+        hip.gemm_force_variant(0)
+    torch.testing.assert_close(ref, A.float() @ B.float().T + bias, rtol=1e-4, atol=2e-3)
+    for ta, tb in ((True, True), (False, True), (True, False)):
+        out = torch.empty(M, N, dtype=torch.float32, device="cuda")
+        hip.gemm(At if ta else A, Bt if tb else B, out, M, N, K, bias=bias, trans_a=ta, trans_b=tb, lda=(M + 8) if ta else K)
+        assert torch.equal(out, ref), (ta, tb)
+
+
 def test_gemm_256_identity_and_k64(hip):
     K = 64                                        # a single K-tile: the whole loop is prologue + dummy tail loads
     A = _bf(torch.eye(256)[:, :K]).cuda()
