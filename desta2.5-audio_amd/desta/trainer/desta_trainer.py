@@ -35,6 +35,7 @@ class TrainingArguments:
     max_steps: int = -1
     num_train_epochs: float = 1.0
     per_device_train_batch_size: int = 8
+    per_device_eval_batch_size: int = 8
     gradient_accumulation_steps: int = 1
     max_grad_norm: float = 1.0
     logging_steps: int = 10
@@ -170,6 +171,69 @@ class DeSTA25Trainer:
         torch.cuda.synchronize(self.model.device)
         self._flush_logs()
         return [float(x) for x in losses]
+
+    # -- evaluation (desta_trainer.py:104-189): eval loss / perplexity + generation through `_generate_step` ----------
+    def evaluate(self, eval_batches: Optional[Iterable[Dict[str, Any]]] = None, metric_key_prefix: str = "eval",
+                 generation_kwargs: Optional[Dict[str, Any]] = None) -> Dict[str, float]:
+        """Eval-mode forward (no Q-Former dropout) for loss / ppl on every batch, then `_predict_step`.  Metrics keep the
+        reference's names (`eval_loss`, `eval_ppl`); accuracy scoring needs the reference's text metrics and a tokenizer
+        (`processing_class`) and is reported only when predictions could be decoded (`prediction_step_outputs`)."""
+        if eval_batches is None:
+            if self.eval_dataset is None or self.data_collator is None:
+                raise ValueError("evaluate() needs `eval_batches` or eval_dataset + data_collator")
+            bs = self.args.per_device_eval_batch_size
+            n = len(self.eval_dataset)
+            eval_batches = (self.data_collator([self.eval_dataset[i] for i in range(s, min(s + bs, n))]) for s in range(0, n, bs))
+        self.wait_update()
+        was_training = self.model.training
+        self.model.eval()
+        losses: List[torch.Tensor] = []
+        self.prediction_step_outputs: List[Dict[str, Any]] = []
+        try:
+            for batch in eval_batches:
+                if self._is_empty_batch(batch):
+                    logging.warning("Skipping empty batch during evaluation")
+                    continue
+                fwd = {k: batch[k] for k in ("input_ids", "attention_mask", "batch_features", "batch_transcription_ids",
+                                             "batch_start_positions", "labels") if k in batch}
+                losses.append(self.model(**fwd).loss.detach().clone())
+                if "context_input_ids" in batch:
+                    self._predict_step(batch, generation_kwargs)
+        finally:
+            self.model.train(was_training)
+        ls = torch.stack(losses).double() if losses else torch.zeros(1, dtype=torch.float64, device=self.model.device)
+        metrics = {f"{metric_key_prefix}_loss": float(ls.mean()), f"{metric_key_prefix}_ppl": float(torch.exp(ls).mean())}
+        self.log_history.append(dict(metrics))
+        return metrics
+
+    def _predict_step(self, batch: Dict[str, Any], generation_kwargs: Optional[Dict[str, Any]] = None) -> torch.Tensor:
+        """desta_trainer.py:160-189: generate from the context part of the batch; decode when a tokenizer is attached."""
+        gk = dict(temperature=0.7, top_p=0.9, max_new_tokens=128, do_sample=False)
+        cfg_gk = getattr(getattr(self.cfg, "model", None), "generation_kwargs", None) if self.cfg is not None else None
+        for src in (cfg_gk, generation_kwargs):
+            if src:
+                gk.update({k: (src[k] if isinstance(src, dict) else getattr(src, k)) for k in gk if (k in src if isinstance(src, dict) else hasattr(src, k))})
+        tok = self.processing_class
+        eos_id = getattr(tok, "eos_token_id", None)
+        pad_id = eos_id if eos_id is not None else 0
+        ids = self.model._generate_step(batch, pad_token_id=pad_id, temperature=gk["temperature"], top_p=gk["top_p"],
+                                        max_new_tokens=gk["max_new_tokens"], do_sample=gk["do_sample"],
+                                        seed=self.global_step)
+        metas = batch.get("metadata") or [{} for _ in range(ids.shape[0])]
+        if tok is not None:
+            ctx = batch["context_input_ids"].clone()
+            ctx[ctx == -100] = pad_id
+            lab = batch["labels"].clone()
+            lab[lab == -100] = pad_id
+            contexts = tok.batch_decode(ctx, skip_special_tokens=False)
+            labels = tok.batch_decode(lab, skip_special_tokens=True)
+            preds = tok.batch_decode(ids, skip_special_tokens=True)
+            for c, l, pr, m in zip(contexts, labels, preds, metas):
+                self.prediction_step_outputs.append({**m, "context": c, "prediction": pr, "label": l})
+        else:
+            for row, m in zip(ids.cpu().tolist(), metas):
+                self.prediction_step_outputs.append({**m, "prediction_ids": row})
+        return ids
 
     # -- HF `checkpoint-<step>/` layout (TF:trainer.py:3079-3130): model.safetensors (trainable-only), config.json,
     #    optimizer.pt (Adafactor state_dict wire format), scheduler.pt (LambdaLR state), trainer_state.json

@@ -3,6 +3,8 @@
   (2) the cache-free oracle (oracle.greedy_generate) step by step under teacher forcing.
 The product computes in bf16, the reference in fp32: per-step logits must agree to 3e-2 relative L2, and every
 greedy choice of the product must be (near-)optimal under the fp32 logits (argmax flips only between near-ties)."""
+import math
+
 import pytest
 import torch
 
@@ -213,3 +215,36 @@ def test_generate_step_sampling_end_to_end(golden_dir):
     lg = lg.float()
     picked = lg.gather(-1, nearly.t().unsqueeze(-1)).squeeze(-1)
     assert torch.equal(picked, lg.max(-1).values)
+
+
+def test_trainer_evaluate_loss_ppl_and_predictions(golden_dir):
+    """DeSTA25Trainer.evaluate (reference desta_trainer.py:104-189): eval-mode loss / ppl == the oracle's forward loss
+    (no dropout even with qformer_dropout configured), predictions == _generate_step on the batch's context part;
+    with a tokenizer-like `processing_class` the decoded strings are recorded under the reference's keys."""
+    from desta.models.modeling_desta25 import DeSTA25AudioModel
+    from desta.trainer.desta_trainer import DeSTA25Trainer, TrainingArguments
+    d = O.tiny_dims(False)
+    g, batch = golden_batch(golden_dir, "llama")
+    w = O.init_weights(d, seed=7)
+    model = DeSTA25AudioModel(cfg_from_dims(d, dropout=0.1), weights=w)
+    full = dict(batch)
+    full.update(_gen_inputs(g, batch))
+    full["metadata"] = [{"id": "a"}, {"id": "b"}]
+    tr = DeSTA25Trainer(model, args=TrainingArguments(max_steps=10))
+    m = tr.evaluate([full, {"_empty_batch": True}, full], generation_kwargs=dict(max_new_tokens=10, do_sample=False))
+    assert abs(m["eval_loss"] - float(g["loss"])) < 2e-2 and abs(m["eval_ppl"] - math.exp(float(g["loss"]))) < 2e-2 * math.exp(float(g["loss"]))
+    assert model.training                                        # mode restored
+    ids = model.eval()._generate_step(full, pad_token_id=0, max_new_tokens=10, do_sample=False).cpu().tolist()
+    model.train()
+    assert len(tr.prediction_step_outputs) == 4
+    assert [o["prediction_ids"] for o in tr.prediction_step_outputs[:2]] == ids and tr.prediction_step_outputs[0]["id"] == "a"
+
+    class Tok:                                                   # minimal tokenizer surface used by _predict_step
+        eos_token_id = 2
+
+        def batch_decode(self, x, skip_special_tokens=False):
+            return [" ".join(str(int(t)) for t in row) for row in x]
+    tr2 = DeSTA25Trainer(model, args=TrainingArguments(max_steps=10), processing_class=Tok())
+    tr2.evaluate([full], generation_kwargs=dict(max_new_tokens=4, do_sample=False))
+    o = tr2.prediction_step_outputs[0]
+    assert set(o) >= {"context", "prediction", "label", "id"} and len(o["prediction"].split()) == 4
