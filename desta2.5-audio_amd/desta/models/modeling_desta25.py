@@ -473,6 +473,19 @@ class QformerConnectorHIP:
         H.gemm(self.pb, self.W16(CON + "proj.1.weight"), self.af, B * K, self.h, d, bias=self.P32(CON + "proj.1.bias"))
         return self.af
 
+    def __call__(self, encoder_hidden_states) -> torch.Tensor:
+        """The reference's `QformerConnector.forward(encoder_hidden_states)` (modeling_desta25.py:178-205): a list with
+        one [B, T, d] state per encoder layer (the target layers are picked here) -> [B, prompt_size, llm_hidden] bf16."""
+        states = [encoder_hidden_states[i] for i in self.cfg.target_layer_ids]
+        B, T, d = states[0].shape
+        assert d == self.d, f"encoder width {d} != {self.d}"
+        if T != self.T:                                   # the connector is agnostic to the number of encoder frames
+            self.T, self.B = T, 0
+        with torch.cuda.device(self.dev):
+            enc_all = torch.stack([s.to(self.dev, BF16).reshape(B * T, d) for s in states]).contiguous()
+            self.refresh_weights()
+            return self.forward(enc_all, B).view(B, self.K, self.h)
+
     # -- backward helpers
     def _dW(self, dY, X, M, N, Kin, wname, bname, Mp, x_is_T=None):
         """grad(wname)[N,Kin] = dY[M,N]^T @ X[M,Kin];  grad(bname)[N] = colsum(dY).  bf16 operands."""

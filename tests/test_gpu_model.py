@@ -263,3 +263,46 @@ def test_hf_checkpoint_wire_format_and_resume(tmp_path):
     t_d.optimizer.step(lr)
     for n in names:
         torch.testing.assert_close(m_d.arena.param(n).cpu(), params[n].detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_connector_standalone_vs_reference_golden(golden_dir):
+    """`connector(list_of_encoder_states)` like the reference's own unit test (tests/test_modeling.py:21-36), but
+    with numbers: the golden holds the reference QformerConnector's output on seeded random states."""
+    d = O.tiny_dims(False)
+    g, _ = golden_batch(golden_dir, "llama")
+    model, w = _model(d)
+    states = list(g["conn_states"].unbind(0))
+    out = model.connector(states)
+    assert out.shape == g["conn_out"].shape == (2, d.prompt_size, d.llm_h)
+    assert rel_err(out.float(), g["conn_out"]) < 2e-2
+
+
+def test_connector_reference_unit_test_shapes_fwd_bwd():
+    """The shapes of the reference's connector unit test (whisper-tiny width 384 / 6 heads, prompt_size 4, 100 frames,
+    2 Q-Former layers, BertConfig-default intermediate 3072): ragged everything (Sq = 4, Sk = 100, R = 32 rows).
+    Forward and all gradients against the oracle's autograd."""
+    import dataclasses
+    d = dataclasses.replace(O.tiny_dims(False), enc_d=384, enc_heads=6, enc_ffn=1536, enc_T=100, qf_inter=3072, prompt_size=4)
+    model, w = _model(d, seed=3)
+    gen = torch.Generator().manual_seed(5)
+    B = 2
+    states = [torch.randn(B, d.enc_T, d.enc_d, generator=gen).to(torch.bfloat16).float() for _ in range(d.enc_layers)]
+    names = [n for n in O.trainable_names(d)]
+    for n in names:
+        w[n].requires_grad_(True)
+    ref = O.mix_proj(w, d, [O.qformer(w, d, j, states[t]) for j, t in enumerate(d.taps)])
+    out = model.connector(states)
+    assert out.shape == (B, 4, d.llm_h)
+    assert rel_err(out.float(), ref) < 2e-2
+    d_af = torch.randn(B * 4, d.llm_h, generator=gen).to(torch.bfloat16)
+    ref.backward(d_af.float().view(B, 4, d.llm_h))
+    model.connector.backward(d_af.cuda())
+    gn = sorted(float(w[n].grad.double().norm()) for n in names)
+    floor = gn[len(gn) // 2] * 1e-2
+    worst = 0.0
+    for n in names:
+        r = w[n].grad.double()
+        e = float((model.arena.grad(n).double().cpu() - r).norm() / max(float(r.norm()), floor))
+        worst = max(worst, e)
+        assert e < 8e-2, (n, e)
+    print("worst connector grad err", worst)
