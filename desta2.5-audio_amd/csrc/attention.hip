@@ -612,6 +612,28 @@ extern "C" size_t desta_attention_bwd_workspace_floats(int batch, int n_q_heads,
     return (size_t)batch * n_q_heads * seq_q;
 }
 
+// dQ and dK/dV are independent given delta.  The dK/dV grid is makespan-bound under the causal mask (320 blocks of very
+// different length on 256 CUs, one block per CU: ~25 % of the CU-time idles behind the heaviest blocks), so the dQ kernel
+// is launched on a side stream (fork after delta, join before returning to the caller's stream) and its blocks fill
+// the CUs that dK/dV leaves idle.  Results are unchanged (no shared outputs, no atomics).
+namespace {
+struct BwdFork { hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+BwdFork g_bwd_fork[16];
+int g_bwd_concurrent = 1;
+BwdFork* bwd_fork() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    BwdFork& f = g_bwd_fork[dev];
+    if (!f.side) {
+        if (hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) != hipSuccess) { f.side = nullptr; return nullptr; }
+        if (hipEventCreateWithFlags(&f.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&f.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
+    return &f;
+}
+}  // namespace
+extern "C" int desta_attention_set_concurrent_bwd(int on) { g_bwd_concurrent = on; return DESTA_OK; }
+
 extern "C" int desta_attention_bwd(const desta_attn_desc* d, float* workspace, void* stream) {
     AttnArgs a;
     if (int rc = fill_args(d, a)) return rc;
@@ -628,8 +650,16 @@ extern "C" int desta_attention_bwd(const desta_attn_desc* d, float* workspace, v
     dim3 gk((unsigned)((a.Sk + 127) / 128) * a.Hkv * a.B);
     if (d->head_dim == 128) {
         hipLaunchKernelGGL(attn_delta_k<128>, gd, dim3(256), 0, st, a, workspace);
-        hipLaunchKernelGGL((attn_bwd_dq_k<128, false>), gq, dim3(256), 0, st, a);
-        if (d->dK) hipLaunchKernelGGL((attn_bwd_dkdv_k<128, false>), gk, dim3(256), 0, st, a);
+        BwdFork* f = (g_bwd_concurrent && d->dK) ? bwd_fork() : nullptr;
+        if (f && hipEventRecord(f->fork, st) == hipSuccess && hipStreamWaitEvent(f->side, f->fork, 0) == hipSuccess) {
+            hipLaunchKernelGGL((attn_bwd_dkdv_k<128, false>), gk, dim3(256), 0, st, a);          // the long one first
+            hipLaunchKernelGGL((attn_bwd_dq_k<128, false>), gq, dim3(256), 0, f->side, a);
+            DESTA_CHECK_ARG(hipEventRecord(f->join, f->side) == hipSuccess && hipStreamWaitEvent(st, f->join, 0) == hipSuccess,
+                            "attention_bwd: could not join the side stream");
+        } else {
+            hipLaunchKernelGGL((attn_bwd_dq_k<128, false>), gq, dim3(256), 0, st, a);
+            if (d->dK) hipLaunchKernelGGL((attn_bwd_dkdv_k<128, false>), gk, dim3(256), 0, st, a);
+        }
     } else {
         hipLaunchKernelGGL(attn_delta_k<64>, gd, dim3(256), 0, st, a, workspace);
         if (a.drop_thresh) {

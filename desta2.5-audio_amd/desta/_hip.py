@@ -458,3 +458,8 @@ def sample_top_p(logits, ld, rows, cols, temperature, top_p, seed, step, out, ke
     """One temperature / top-p sample per row of bf16 logits (HF `generate(do_sample=True)` step)."""
     check(_sample(p(logits), ld, rows, cols, temperature, top_p, seed & 0xFFFFFFFFFFFFFFFF, step & 0xFFFFFFFF, p(out), p(keep_mask),
                   stream()), "desta_sample_top_p_bf16")
+
+
+def attention_set_concurrent_bwd(on: bool) -> None:
+    lib.desta_attention_set_concurrent_bwd.argtypes = [i32]
+    check(lib.desta_attention_set_concurrent_bwd(int(on)), "desta_attention_set_concurrent_bwd")

@@ -229,6 +229,9 @@ typedef struct desta_attn_desc {
 int desta_attention_fwd(const desta_attn_desc* d, void* stream);
 size_t desta_attention_bwd_workspace_floats(int batch, int n_q_heads, int seq_q);
 int desta_attention_bwd(const desta_attn_desc* d, float* workspace, void* stream);
+/* D = 128 backward: run the dQ kernel on an internal side stream next to dK/dV (fork after delta, join on `stream`);
+ * 1 = on (default), 0 = everything on `stream`.  Results are identical either way. */
+int desta_attention_set_concurrent_bwd(int on);
 
 /* layer_prompts[j].expand(B,-1,-1) for all taps at once (modeling_desta25.py:589): prompts fp32
  * [taps][n], n = prompt_size*d -> rows [(taps*batch)][n] in fp32 and bf16; prompt_grad sums the

@@ -35,5 +35,8 @@ for name, (B, Hq, Hkv, S, D, causal) in {"llm S=640 D=128 causal GQA": (8, 32, 8
                       kv_start=None, q_off=0, k_off=wq, v_off=wq + wkv)
     f = t_us(lambda: hip.attention_fwd(d))
     bw = t_us(lambda: hip.attention_bwd(d, do, dqkv, dqkv, dqkv, dq_off=0, dk_off=wq, dv_off=wq + wkv))
+    hip.attention_set_concurrent_bwd(False)
+    bw_serial = t_us(lambda: hip.attention_bwd(d, do, dqkv, dqkv, dqkv, dq_off=0, dk_off=wq, dv_off=wq + wkv))
+    hip.attention_set_concurrent_bwd(True)
     fl = 4.0 * B * Hq * S * S * D * (0.5 if causal else 1.0)
-    print(f"{name:30s} fwd {f:7.1f} us ({fl / f / 1e6:6.0f} TF/s)   bwd {bw:7.1f} us ({2.5 * fl / bw / 1e6:6.0f} TF/s)", flush=True)
+    print(f"{name:30s} fwd {f:7.1f} us ({fl / f / 1e6:6.0f} TF/s)   bwd {bw:7.1f} us ({2.5 * fl / bw / 1e6:6.0f} TF/s; dQ after dK/dV on one stream: {bw_serial:7.1f} us)", flush=True)
