@@ -39,6 +39,10 @@ class GemmDesc(C.Structure):
 
 lib.desta_abi_version.restype = i32
 lib.desta_last_error.restype = C.c_char_p
+ABI_VERSION = 2
+if lib.desta_abi_version() != ABI_VERSION:
+    raise ImportError(f"libdesta_hip.so has ABI version {lib.desta_abi_version()}, this binding needs {ABI_VERSION}: "
+                      "rebuild with `python desta2.5-audio_amd/build.py`")
 
 
 def _sig(name, *argtypes):
@@ -463,3 +467,14 @@ def sample_top_p(logits, ld, rows, cols, temperature, top_p, seed, step, out, ke
 def attention_set_concurrent_bwd(on: bool) -> None:
     lib.desta_attention_set_concurrent_bwd.argtypes = [i32]
     check(lib.desta_attention_set_concurrent_bwd(int(on)), "desta_attention_set_concurrent_bwd")
+
+
+def _check_struct_layouts() -> None:
+    lib.desta_sizeof_desc.restype = C.c_size_t
+    lib.desta_sizeof_desc.argtypes = [i32]
+    for which, cls in ((0, GemmDesc), (1, AttnDesc), (2, OptPlan)):
+        if lib.desta_sizeof_desc(which) != C.sizeof(cls):
+            raise ImportError(f"struct layout mismatch for {cls.__name__}: library {lib.desta_sizeof_desc(which)} B, binding {C.sizeof(cls)} B")
+
+
+_check_struct_layouts()

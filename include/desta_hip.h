@@ -26,9 +26,12 @@
 extern "C" {
 #endif
 
-#define DESTA_ABI_VERSION 1
+#define DESTA_ABI_VERSION 2
 
 int desta_abi_version(void);
+/* sizeof of the descriptor structs as this library was compiled (0 = desta_gemm_desc, 1 = desta_attn_desc,
+ * 2 = desta_opt_plan): a binding checks its own struct layouts against these before the first call. */
+size_t desta_sizeof_desc(int which);
 const char* desta_last_error(void);
 
 /* ------------------------------------------------------------------------------------------

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/desta_hip.h but not exported"
     lib.desta_abi_version.restype = ctypes.c_int
-    assert lib.desta_abi_version() == 1
+    assert lib.desta_abi_version() == 2
 
 
 def test_host_side_table_helper_runs_without_gpu():
@@ -43,3 +43,12 @@ def test_host_side_table_helper_runs_without_gpu():
         fb = host[1200:].view(201, n_mels).numpy()
         np.testing.assert_allclose(fb, O.mel_filter_bank(n_mels), rtol=2e-6, atol=1e-9)
         np.testing.assert_allclose(host[:400].numpy(), torch.hann_window(400, dtype=torch.float64).numpy(), atol=1e-7)
+
+
+def test_binding_struct_layouts_match_the_library():
+    """The ctypes descriptors of desta/_hip.py have the sizes the compiled library reports (checked at import too)."""
+    import ctypes as C
+    from desta import _hip
+    for which, cls in ((0, _hip.GemmDesc), (1, _hip.AttnDesc), (2, _hip.OptPlan)):
+        assert _hip.lib.desta_sizeof_desc(which) == C.sizeof(cls)
+    assert _hip.lib.desta_sizeof_desc(99) == 0
