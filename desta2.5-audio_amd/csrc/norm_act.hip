@@ -154,31 +154,63 @@ __global__ __launch_bounds__(256) void layernorm_bwd_k(const void* __restrict__ 
     }
 }
 
-// out[which][c] (+)= sum_b part[b][which][c];  also used for column sums (bias gradients)
+// out[which][c] (+)= sum_b part[b][which][c];  also used for column sums (bias gradients).  64 columns per block, the
+// partial rows are split over the block's 4 waves (4 independent accumulators each) and combined in fixed order.
 __global__ __launch_bounds__(256) void reduce_partials_k(const float* __restrict__ part, int nblk, int width,
                                                          float* __restrict__ out0, float* __restrict__ out1, int cols,
                                                          int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= width) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[(long)b * width + c];
-    float* o = (c < cols) ? out0 + c : out1 + (c - cols);
-    *o = accumulate ? *o + s : s;
+    __shared__ float comb[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < width) {
+        int b = grp;
+        for (; b + 12 < nblk; b += 16) {
+            a0 += part[(long)b * width + c];
+            a1 += part[(long)(b + 4) * width + c];
+            a2 += part[(long)(b + 8) * width + c];
+            a3 += part[(long)(b + 12) * width + c];
+        }
+        for (; b < nblk; b += 4) a0 += part[(long)b * width + c];
+    }
+    comb[grp][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (grp == 0 && c < width) {
+        const float s = (comb[0][lane] + comb[1][lane]) + (comb[2][lane] + comb[3][lane]);
+        float* o = (c < cols) ? out0 + c : out1 + (c - cols);
+        *o = accumulate ? *o + s : s;
+    }
 }
 
-// column sums of a bf16 [rows, cols] matrix -> per-block partials [gridDim.y][cols]
+// column sums of a bf16 [rows, cols] matrix -> per-block partials [gridDim.y][cols]; V columns per thread (8 = 16-B loads)
+template <int V>
 __global__ __launch_bounds__(256) void colsum_partial_k(const bf16_t* __restrict__ x, int rows, int cols, long ld,
                                                         float* __restrict__ part) {
-    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+    typedef __attribute__((ext_vector_type(V))) unsigned short vec_t;
+    const int c = (blockIdx.x * 256 + threadIdx.x) * V;
     if (c >= cols) return;
     const int r0 = blockIdx.y, nr = gridDim.y;
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int r = r0; r < rows; r += nr) {
-        const u16x4 v = *(const u16x4*)(x + (long)r * ld + c);
+    float s[V];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s[e] += bf2f(v[e]);
+    for (int e = 0; e < V; ++e) s[e] = 0.f;
+#pragma unroll 4
+    for (int r = r0; r < rows; r += nr) {
+        const vec_t v = *(const vec_t*)(x + (long)r * ld + c);
+#pragma unroll
+        for (int e = 0; e < V; ++e) s[e] += bf2f(v[e]);
     }
-    *(float4*)(part + (long)r0 * cols + c) = make_float4(s[0], s[1], s[2], s[3]);
+#pragma unroll
+    for (int e = 0; e < V; ++e) part[(long)r0 * cols + c + e] = s[e];
+}
+// row splits: enough blocks to fill the chip on tall matrices (the [48000, 2560] d(K|V) of the cross-attention ran at
+// 1.5 TB/s with 64 splits x 3 column blocks), at least ~32 rows per split
+static int colsum_splits(int rows, int cols) {
+    const int xb = (cols / 4 + 255) / 256;
+    int nr = (2048 + xb - 1) / xb;
+    if (nr > rows / 32) nr = rows / 32;
+    if (nr > 512) nr = 512;
+    if (nr < 1) nr = 1;
+    return nr;
 }
 
 // ------------------------------------------------------------------------------------ RMSNorm
@@ -665,25 +697,26 @@ extern "C" int desta_layernorm_bwd(const void* dy, int dy_f32, const void* x, in
     else if (cols <= 1024) hipLaunchKernelGGL((layernorm_bwd_k<2>), dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, dy_f32, x, x_f32, gamma, stats, rows, cols, dx_f32, (bf16_t*)dx_bf16, part);
     else hipLaunchKernelGGL((layernorm_bwd_k<4>), dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, dy_f32, x, x_f32, gamma, stats, rows, cols, dx_f32, (bf16_t*)dx_bf16, part);
     if (dgamma)
-        hipLaunchKernelGGL(reduce_partials_k, dim3((2 * cols + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(reduce_partials_k, dim3((2 * cols + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                            (const float*)part, nb, 2 * cols, dgamma, dbeta, cols, accumulate);
     DESTA_CHECK_LAUNCH("layernorm_bwd");
     return DESTA_OK;
 }
 
-extern "C" size_t desta_colsum_workspace_floats(int rows, int cols) {
-    int nr = rows < 64 ? rows : 64;
-    return (size_t)nr * cols;
-}
+extern "C" size_t desta_colsum_workspace_floats(int rows, int cols) { return (size_t)colsum_splits(rows, cols) * cols; }
 
 extern "C" int desta_colsum_bf16(const void* x, int rows, int cols, int64_t ld, float* out, int accumulate,
                                  float* workspace, void* stream) {
     DESTA_CHECK_ARG(x && out && workspace, "colsum: null argument");
     DESTA_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0 && ld % 4 == 0, "colsum: cols/ld must be multiples of 4");
-    const int nr = rows < 64 ? rows : 64;
-    hipLaunchKernelGGL(colsum_partial_k, dim3((cols / 4 + 255) / 256, nr), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)x, rows, cols, (long)ld, workspace);
-    hipLaunchKernelGGL(reduce_partials_k, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+    const int nr = colsum_splits(rows, cols);
+    if (cols % 8 == 0 && ld % 8 == 0 && ((uintptr_t)x % 16) == 0)
+        hipLaunchKernelGGL(colsum_partial_k<8>, dim3((cols / 8 + 255) / 256, nr), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)x, rows, cols, (long)ld, workspace);
+    else
+        hipLaunchKernelGGL(colsum_partial_k<4>, dim3((cols / 4 + 255) / 256, nr), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)x, rows, cols, (long)ld, workspace);
+    hipLaunchKernelGGL(reduce_partials_k, dim3((cols + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, nr, cols, out, out, cols, accumulate);
     DESTA_CHECK_LAUNCH("colsum");
     return DESTA_OK;

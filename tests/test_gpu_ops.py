@@ -86,6 +86,15 @@ def test_colsum_transpose_cast_add(hip):
     torch.testing.assert_close(out.cpu(), x.float().sum(0), rtol=1e-4, atol=1e-3)
     hip.colsum(x.cuda(), 1000, 136, 136, out, accumulate=True)
     torch.testing.assert_close(out.cpu(), 2 * x.float().sum(0), rtol=1e-4, atol=2e-3)
+    # tall matrix (many row splits), a strided view (ld > cols), cols not a multiple of 8, tiny row counts; run-to-run identical
+    for rows, cols, ld in ((48000, 2560, 2560), (2048, 3840, 3840), (4097, 132, 140), (5, 8, 8), (33, 1280, 2560)):
+        xs = bf(torch.randn(rows, ld, generator=g)).cuda()
+        o1, o2 = torch.zeros(cols, device="cuda"), torch.zeros(cols, device="cuda")
+        hip.colsum(xs, rows, cols, ld, o1)
+        hip.colsum(xs, rows, cols, ld, o2)
+        ref = xs[:, :cols].double().sum(0).float()
+        torch.testing.assert_close(o1, ref, rtol=2e-4, atol=2e-3 * math.sqrt(rows / 1000))
+        assert torch.equal(o1, o2)
     # transpose with zero-padded K tail, bf16 and fp32 inputs
     t = torch.full((136, 1024), 9.0, dtype=torch.bfloat16, device="cuda")
     hip.transpose_to_bf16(x.cuda(), 1000, 136, t, 1024)
