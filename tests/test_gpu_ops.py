@@ -104,6 +104,14 @@ def test_colsum_transpose_cast_add(hip):
     t2 = torch.empty(200, 128, dtype=torch.bfloat16, device="cuda")
     hip.transpose_to_bf16(xf.cuda(), 70, 200, t2, 128)
     assert torch.equal(t2[:, :70].cpu(), bf(xf).T.contiguous())
+    # 16-byte path (cols, ld_in, ld_out multiples of 8): ragged rows, zero-padded tail, strided input, fp32 input
+    for rows, cols, ld_in, ld_out, f32 in ((1000, 136, 136, 1024, False), (48000, 256, 512, 48000, False), (70, 200, 200, 128, True), (2048, 1280, 3840, 2048, False)):
+        src = torch.randn(rows, ld_in, generator=g)
+        src = src if f32 else bf(src)
+        tv = torch.full((cols, ld_out), 9.0, dtype=torch.bfloat16, device="cuda")
+        hip.transpose_to_bf16(src.cuda(), rows, cols, tv, ld_out, ld_in=ld_in)
+        assert torch.equal(tv[:, :rows].cpu(), bf(src[:, :cols].float()).T.contiguous())
+        assert ld_out == rows or float(tv[:, rows:].abs().max()) == 0.0
     y = torch.empty(70 * 200, dtype=torch.bfloat16, device="cuda")
     hip.cast_bf16(xf.cuda().reshape(-1), y)
     assert torch.equal(y.cpu(), bf(xf).reshape(-1))

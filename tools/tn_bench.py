@@ -48,3 +48,10 @@ for (N, Kin) in ((3840, 1280), (1280, 1280), (3072, 1280), (1280, 3072), (4096, 
     only = t_us(lambda: H.gemm(tA, tB, gw, N, Kin, M))
     print(f"N={N} Kin={Kin} M={M}: dW transposes+NT {t_us(dw_nt):6.1f} us (NT gemm alone {only:6.1f})  TN {t_us(dw_tn):6.1f} us | "
           f"dX NT {t_us(dx_nt):6.1f} us  trans_b {t_us(dx_tb):6.1f} us", flush=True)
+
+# transposes of the Q-Former backward (bf16): the tall d(K|V) one and a small dY
+for rows, cols in ((48000, 2560), (2048, 3840), (2048, 1280)):
+    x = torch.randn(rows, cols, device="cuda").to(torch.bfloat16)
+    o = torch.empty(cols, rows, dtype=torch.bfloat16, device="cuda")
+    us = t_us(lambda: H.transpose_to_bf16(x, rows, cols, o, rows))
+    print(f"transpose [{rows}, {cols}] bf16: {us:6.1f} us = {2 * rows * cols * 2 / us / 1e6:5.2f} TB/s (read + write)", flush=True)
