@@ -207,7 +207,7 @@ def test_embed_gather_and_rows(hip):
     assert torch.equal(o2.cpu(), ref[[6, 0, 2]])
 
 
-@pytest.mark.parametrize("V", [512, 1000, 128256])
+@pytest.mark.parametrize("V", [512, 1000, 24000, 128256, 151936])
 def test_causal_lm_loss(hip, V):
     g = torch.Generator().manual_seed(V)
     B, S = 2, 7
