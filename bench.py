@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--persistent-gemm", action="store_true", help="A/B: enable the persistent GEMM kernel")
     ap.add_argument("--no-stagger", action="store_true", help="A/B: lockstep GEMM schedule")
     ap.add_argument("--repeat", type=int, default=1, help="repeat the timed region (reports the best), for A/B runs")
+    ap.add_argument("--no-dw-overlap", action="store_true", help="A/B: Q-Former weight gradients on the main stream")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,6 +134,8 @@ def main():
     args = TrainingArguments(learning_rate=1e-4, weight_decay=0.01, warmup_steps=5000, max_steps=10 ** 6, logging_steps=10 ** 9,
                              overlap_comm=not a.no_overlap)
     trainer = DeSTA25Trainer(model, args=args)
+    if a.no_dw_overlap:
+        model.connector.overlap_dw = False
     B, S = a.batch, a.ctx + cfg.prompt_size + a.tgt
     n_mels = cfg.encoder_config.num_mel_bins
     # two alternating synthetic batches per rank, resident in HBM (seed 1234 + rank)

@@ -245,8 +245,8 @@ def rmsnorm_bwd(dy, x, weight, rstd, dx, dres=None):
     check(_rms_bwd(p(dy), p(x), p(weight), p(rstd), p(dres), rows, cols, p(dx), stream()), "desta_rmsnorm_bwd")
 
 
-def colsum(x, rows, cols, ld, out, accumulate=False):
-    ws = scratch(lib.desta_colsum_workspace_floats(rows, cols), x.device)
+def colsum(x, rows, cols, ld, out, accumulate=False, tag="ws"):
+    ws = scratch(lib.desta_colsum_workspace_floats(rows, cols), x.device, tag)     # one scratch tag per stream
     check(_colsum(p(x), rows, cols, ld, p(out), int(accumulate), p(ws), stream()), "desta_colsum_bf16")
 
 

@@ -343,6 +343,8 @@ class QformerConnectorHIP:
         self.w16 = torch.empty(arena.numel, dtype=BF16, device=device)          # bf16 image of the arena (autocast copy)
         self.B = 0
         self.p_drop = 0.0                      # set per forward by the model (cfg.qformer_dropout in training mode)
+        self.overlap_dw = True                 # weight gradients on a side stream beside the dX chain
+        self._dw_stream, self._dw_pending = None, False
         self.seed_base = 0
         # transposed bf16 weights for the dX GEMMs: name -> [in, out] (refreshed on the optimizer's side stream; reading W
         # itself as a transposed-storage operand measured 25-45 % slower per dX GEMM, tools/tn_bench.py)
@@ -492,7 +494,18 @@ class QformerConnectorHIP:
         gw = self.G(wname) if N == self.arena.shapes[wname][0] else self._gwide(wname, N)
         if M % 64 == 0 and x_is_T is None:
             # both operands in transposed storage ([M, N] and [M, Kin], reduction index slow): no transposes
-            # (44 vs 59 us per dW at N=3840, Kin=1280, M=2048: tools/tn_bench.py)
+            # (44 vs 59 us per dW at N=3840, Kin=1280, M=2048: tools/tn_bench.py).  Weight / bias gradients are leaves of
+            # the backward graph: they run on a side stream next to the dX chain (small GEMMs that fill a fraction of
+            # the chip each); `_join_dw` re-joins before any dY buffer is overwritten (every LayerNorm backward).
+            side = self._dw_side()
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream(self.dev))
+                with torch.cuda.stream(side):
+                    H.gemm(dY, X, gw, N, Kin, M, trans_a=True, trans_b=True, lda=dY.shape[-1], ldb=X.shape[-1])
+                    if bname is not None:
+                        H.colsum(dY, M, N, dY.shape[-1], self.G32(bname, N), tag="ws_dw_side")
+                self._dw_pending = True
+                return
             H.gemm(dY, X, gw, N, Kin, M, trans_a=True, trans_b=True, lda=dY.shape[-1], ldb=X.shape[-1])
         else:
             tA = self.tA[: N * Mp].view(N, Mp)
@@ -505,6 +518,19 @@ class QformerConnectorHIP:
             H.gemm(tA, tB, gw, N, Kin, Mp)
         if bname is not None:
             H.colsum(dY, M, N, dY.shape[-1], self.G32(bname, N))
+
+    def _dw_side(self):
+        if not self.overlap_dw:
+            return None
+        if self._dw_stream is None:
+            self._dw_stream = torch.cuda.Stream(device=self.dev)
+        return self._dw_stream
+
+    def _join_dw(self):
+        """Main stream waits for the weight-gradient kernels issued so far (before their dY inputs are overwritten)."""
+        if self._dw_pending:
+            torch.cuda.current_stream(self.dev).wait_stream(self._dw_stream)
+            self._dw_pending = False
 
     def _drop_grad(self, dpre16, s, site):
         """Gradient w.r.t. a dense output that went through epilogue dropout: same mask, same 1/(1-p)."""
@@ -535,6 +561,7 @@ class QformerConnectorHIP:
             p, s = f"{CON}qformer.layer.{i}.", self.sv[i]
             # --- FFN block: x3 = LN(pre3), pre3 = hact@Wo^T + b + x2
             dpre, dpre16, dh, da, dq, dqkv = other, self.dpre16, self.dh, self.da, self.dq, self.dqkv
+            self._join_dw()
             H.layernorm_bwd(dx, s["pre3"], self.P32(p + "output.LayerNorm.weight"), s["st3"], dx32=dpre, dx16=dpre16,
                             dgamma=self.G32(p + "output.LayerNorm.weight"), dbeta=self.G32(p + "output.LayerNorm.bias"))
             dm = self._drop_grad(dpre16, s, 4)                                                   # grad of the dense output (through its dropout)
@@ -544,6 +571,7 @@ class QformerConnectorHIP:
             self._dW(dh, s["x2_16"], R, inter, d, p + "intermediate.dense.weight", p + "intermediate.dense.bias", self.Rp)
             H.gemm(dh, self.wT[f"{i}.i"], dx, R, d, inter, residual=dpre)                      # dx := d x2_32
             # --- cross-attention block: x2 = LN(pre2), pre2 = a_c@Wo^T + b + x1
+            self._join_dw()
             H.layernorm_bwd(dx, s["pre2"], self.P32(p + "crossattention.output.LayerNorm.weight"), s["st2"], dx32=dpre, dx16=dpre16,
                             dgamma=self.G32(p + "crossattention.output.LayerNorm.weight"), dbeta=self.G32(p + "crossattention.output.LayerNorm.bias"))
             dm = self._drop_grad(dpre16, s, 3)
@@ -557,6 +585,7 @@ class QformerConnectorHIP:
             H.colsum(self.dkv, E, 2 * d, 2 * d, self.G32(p + "crossattention.self.key.bias", 2 * d))
             H.gemm(dq, self.wT[f"{i}.c.q"], dx, R, d, d, residual=dpre)                         # dx := d x1_32
             # --- self-attention block: x1 = LN(pre1), pre1 = a_s@Wo^T + b + x_in
+            self._join_dw()
             H.layernorm_bwd(dx, s["pre1"], self.P32(p + "attention.output.LayerNorm.weight"), s["st1"], dx32=dpre, dx16=dpre16,
                             dgamma=self.G32(p + "attention.output.LayerNorm.weight"), dbeta=self.G32(p + "attention.output.LayerNorm.bias"))
             dm = self._drop_grad(dpre16, s, 1)
@@ -566,6 +595,7 @@ class QformerConnectorHIP:
             self._dW(dqkv, s["x_in16"], R, 3 * d, d, p + "attention.self.query.weight", p + "attention.self.query.bias", self.Rp)
             H.gemm(dqkv, self.wT[f"{i}.s.qkv"], dx, R, d, 3 * d, residual=dpre)                # dx := d x_in32
         H.prompt_grad(dx, nt, B, K * d, self.G32(f"{CON}layer_prompts.0", nt * K * d))
+        self._join_dw()
 
 
 # =========================================================================================== causal LM
