@@ -125,6 +125,41 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& p, int z, int m, int n
 // (half the store instructions of the epilogue, which is issue-bound with one block per CU).
 __device__ __forceinline__ void epilogue_pair_bf16(const GemmArgs& p, int z, int m, bool row_ok, int ncol0, int fq,
                                                    const f32x4& a0, const f32x4& a1) {
+    if (p.res && !p.res_f32 && (p.ldr & 7) == 0 && (p.sR & 7) == 0) {
+        // bf16 residual: swap the fp32 values first, so the lane's 8 contiguous outputs take ONE 16-byte residual load
+        // (instead of two 8-byte loads before the swap); same arithmetic: add in fp32, round once.
+        float v[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f32x4& a = t ? a1 : a0;
+            const int n0 = ncol0 + t * 16 + fq * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[t][e] = a[e] * p.alpha;
+            if (p.bias) {
+                const float4 b = *(const float4*)(p.bias + n0);
+                v[t][0] += b.x; v[t][1] += b.y; v[t][2] += b.z; v[t][3] += b.w;
+            }
+            if (p.act == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[t][e] = gelu_erf_fast(v[t][e]);
+            }
+        }
+        const int col = ncol0 + (fq & 1) * 16 + (fq >> 1) * 8;
+        const u16x8 r = *(const u16x8*)((const bf16_t*)p.res + (long)z * p.sR + (long)m * p.ldr + col);
+        float w[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[0][e]), __float_as_uint(v[1][e]), false, false);
+            // after the swap: first result = columns col + e (e < 4: from tile 0/1 half), second = col + 4 + e
+            w[e] = __uint_as_float(sw[0]);
+            w[4 + e] = __uint_as_float(sw[1]);
+        }
+        u16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(w[e] + bf2f(r[e]));
+        if (row_ok) *(u16x8*)((bf16_t*)p.C + (long)z * p.sC + (long)m * p.ldc + col) = o;
+        return;
+    }
     unsigned pk[2][2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
