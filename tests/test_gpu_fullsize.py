@@ -115,3 +115,54 @@ def test_full_size_step_properties(hip, full_model):
     losses = tr.train([batch] * 6)
     assert losses[-1] < losses[0] - 0.05, losses
     assert all(math.isfinite(x) for x in losses)
+
+
+def test_full_size_generate_cache_consistency(hip, full_model):
+    """KV-cached decoding at the true model size, checked by a size-independent property: the logits of decode step t
+    (weight-streaming GEMMs with fused RMSNorm / SwiGLU, Sq = 1 attention over the cache, rope + append kernel) must
+    equal the last-row logits of a fresh PROMPT pass (tile GEMMs, full causal attention) over prompt + the first t
+    generated tokens — same bf16 weights, two completely different kernel paths.  Also: greedy rerun is bit-identical,
+    left padding does not change a row's continuation, finished rows emit the pad token."""
+    from desta.synthetic import synthetic_inputs, synthetic_waveform
+    model = full_model
+    cfg = model.config
+    model.eval()
+    model.mark_weights_updated()
+    B, n_new = 4, 6
+    t = synthetic_inputs(cfg, B, 40, 8, "cuda:0", seed=9)
+    mel = hip.logmel(synthetic_waveform(B, "cuda:0", seed=9), 128)
+    inputs = {"context_input_ids": t["input_ids"], "context_attention_mask": t["attention_mask"],
+              "context_batch_start_positions": t["batch_start_positions"], "batch_features": mel,
+              "batch_transcription_ids": t["batch_transcription_ids"]}
+    ids, logits = model._generate_step(inputs, pad_token_id=0, max_new_tokens=n_new, do_sample=False, eos_token_id=[], collect_logits=True)
+    ids2 = model._generate_step(inputs, pad_token_id=0, max_new_tokens=n_new, do_sample=False, eos_token_id=[])
+    assert ids.shape == (B, n_new) and torch.equal(ids, ids2)
+    V = cfg.llm_config.vocab_size
+    assert torch.equal(logits[0].float().argmax(-1), ids[:, 0])
+    # no-cache reference for step k: prompt pass over prompt + k generated tokens (one more text token per step)
+    for k in (1, n_new - 1):
+        ext = {**inputs,
+               "context_input_ids": torch.cat([t["input_ids"], ids[:, :k]], 1),
+               "context_attention_mask": torch.cat([t["attention_mask"], torch.ones(B, k, dtype=torch.long, device="cuda:0")], 1)}
+        _, lg = model._generate_step(ext, pad_token_id=0, max_new_tokens=1, do_sample=False, eos_token_id=[], collect_logits=True)
+        a, b = logits[k].float(), lg[0].float()
+        rel = float((a - b).norm() / b.norm())
+        assert rel < 2e-2, (k, rel)
+        assert float((a.argmax(-1) == b.argmax(-1)).float().mean()) >= 0.75
+    # left padding: rows shifted right by 5 pad positions continue identically (positions and masks follow the mask)
+    pad = 5
+    S = t["input_ids"].shape[1]
+    ids_p = torch.zeros(B, S + pad, dtype=torch.long, device="cuda:0")
+    ids_p[:, pad:] = t["input_ids"]
+    am_p = torch.zeros(B, S + pad, dtype=torch.long, device="cuda:0")
+    am_p[:, pad:] = 1
+    padded = {**inputs, "context_input_ids": ids_p, "context_attention_mask": am_p,
+              "context_batch_start_positions": [(b, s + pad) for b, s in t["batch_start_positions"]]}
+    ids_pad, lg_pad = model._generate_step(padded, pad_token_id=0, max_new_tokens=2, do_sample=False, eos_token_id=[], collect_logits=True)
+    rel = float((lg_pad[0].float() - logits[0].float()).norm() / logits[0].float().norm())
+    assert rel < 2e-2, rel
+    # EOS = the first token every row produced -> a single column comes back
+    first = [int(x) for x in ids[:, 0].tolist()]
+    one = model._generate_step(inputs, pad_token_id=0, max_new_tokens=n_new, do_sample=False, eos_token_id=first)
+    assert one.shape == (B, 1) and torch.equal(one[:, 0], ids[:, 0])
+    model.train()
