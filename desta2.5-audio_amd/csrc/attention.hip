@@ -433,14 +433,20 @@ __global__ __launch_bounds__(256, ATTN_DQ_BLOCKS) void attn_bwd_dq_k(AttnArgs p)
 }
 
 // ------------------------------------------------------------------------------------------ backward: dK, dV
-// block = 128 keys of one (batch, kv head); wave w owns keys [k0 + 32w, k0 + 32w + 32)
+// block = 128 keys of one (batch, kv head); wave w owns keys [k0 + 32w, k0 + 32w + 32).  QR query rows (32 or 64) are
+// staged per iteration: QR = 64 halves the barriers / staging round trips per unit of MFMA work.
+#ifndef ATTN_DKDV_QR
+#define ATTN_DKDV_QR 32
+#endif
+
 template <int D, bool DROP>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_k(AttnArgs p) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * 32 * D * 2 + 2 * 32 * 4];
+    constexpr int QR = (D == 128) ? ATTN_DKDV_QR : 32;
+    __shared__ __attribute__((aligned(16))) char lds[2 * QR * D * 2 + 2 * QR * 4];
     char* qimg = lds;
-    char* gimg = lds + 32 * D * 2;
-    float* lse_s = (float*)(lds + 2 * 32 * D * 2);
-    float* dlt_s = lse_s + 32;
+    char* gimg = lds + QR * D * 2;
+    float* lse_s = (float*)(lds + 2 * QR * D * 2);
+    float* dlt_s = lse_s + QR;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h2 = lane >> 5;
     // 1-D grid with the key block as the SLOWEST index: under the causal mask low key blocks sweep the
     // most query tiles, so the heaviest work items are dispatched first (longest-processing-time order)
@@ -469,76 +475,102 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_k(AttnArgs p) {
 
     // first query row that can see any key of this block
     const int q_first = p.causal ? max(0, kb0 - coff) : 0;
-    const int qt_lo = q_first / 32, qt_hi = (p.Sq + 31) / 32;
-    // (query head of the GQA group, 32-row query slice) flattened into one iteration space; the Q / dO
+    const int qt_lo = q_first / QR, qt_hi = (p.Sq + QR - 1) / QR;
+    // (query head of the GQA group, QR-row query slice) flattened into one iteration space; the Q / dO
     // tiles and their lse / delta rows are register-staged TWO iterations ahead.
     const int nq = qt_hi - qt_lo, n_it = group * nq;
-    stage_t<D, 32> qr0 = {}, gr0 = {}, qr1 = {}, gr1 = {};
+    stage_t<D, QR> qr0 = {}, gr0 = {}, qr1 = {}, gr1 = {};
     float ls0 = 0.f, dl0 = 0.f, ls1 = 0.f, dl1 = 0.f;
-#define DESTA_Q_FETCH(IT, QR, GR, LS, DL)                                                                       \
+#define DESTA_Q_FETCH(IT, QR_, GR, LS, DL)                                                                      \
     {                                                                                                          \
         const int h_ = hk * group + (IT) / nq, qt_ = qt_lo + (IT) % nq;                                        \
-        QR = tile_load<D, 32>(p.Q + (long)b * p.q_bs + (long)h_ * D, p.q_rs, qt_ * 32, p.Sq - 1);             \
-        GR = tile_load<D, 32>(p.dO + (long)b * p.do_bs + (long)h_ * D, p.do_rs, qt_ * 32, p.Sq - 1);          \
-        if (threadIdx.x < 32) {                                                                                \
-            const long st_ = ((long)b * p.Hq + h_) * p.Sq + min(qt_ * 32 + (int)threadIdx.x, p.Sq - 1);       \
+        QR_ = tile_load<D, QR>(p.Q + (long)b * p.q_bs + (long)h_ * D, p.q_rs, qt_ * QR, p.Sq - 1);            \
+        GR = tile_load<D, QR>(p.dO + (long)b * p.do_bs + (long)h_ * D, p.do_rs, qt_ * QR, p.Sq - 1);          \
+        if (threadIdx.x < QR) {                                                                                \
+            const long st_ = ((long)b * p.Hq + h_) * p.Sq + min(qt_ * QR + (int)threadIdx.x, p.Sq - 1);       \
             LS = p.lse[st_];                                                                                   \
             DL = p.delta[st_];                                                                                 \
         }                                                                                                      \
     }
-#define DESTA_Q_STAGE(IT, QR, GR, LS, DL)                                                                       \
+#define DESTA_Q_STAGE(IT, QR_, GR, LS, DL)                                                                      \
     __syncthreads();                                                                                           \
-    asm volatile("; stage " #QR ::: "memory");                                                                 \
-    tile_store<D, 32>(qimg, QR);                                                                               \
-    tile_store<D, 32>(gimg, GR);                                                                               \
-    if (threadIdx.x < 32) { lse_s[threadIdx.x] = LS; dlt_s[threadIdx.x] = DL; }                                \
+    asm volatile("; stage " #QR_ ::: "memory");                                                                \
+    tile_store<D, QR>(qimg, QR_);                                                                              \
+    tile_store<D, QR>(gimg, GR);                                                                               \
+    if (threadIdx.x < QR) { lse_s[threadIdx.x] = LS; dlt_s[threadIdx.x] = DL; }                                \
     __syncthreads();                                                                                           \
-    if ((IT) + 2 < n_it) DESTA_Q_FETCH((IT) + 2, QR, GR, LS, DL)
+    if ((IT) + 2 < n_it) DESTA_Q_FETCH((IT) + 2, QR_, GR, LS, DL)
     if (n_it > 0) DESTA_Q_FETCH(0, qr0, gr0, ls0, dl0)
     if (n_it > 1) DESTA_Q_FETCH(1, qr1, gr1, ls1, dl1)
     auto compute = [&](const int it) __attribute__((always_inline)) {
         const int qt = qt_lo + it % nq;
-            // wave-uniform skip: under the causal mask this wave's keys are all in the future of this q tile
-            if (p.causal && k0 > qt * 32 + 31 + coff) return;
-            f32x16 st, dp;
+        constexpr int NS = QR / 32;
+        f32x16 stv[NS], dpv[NS];
+        bool act[NS];
+        // phase A for every 32-row slice first: with QR = 64 the S / dP MFMAs of slice 1 are in flight while the
+        // VALU softmax of slice 0 runs, and slice 0's dV / dK MFMAs overlap the softmax of slice 1
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+        for (int sub = 0; sub < NS; ++sub) {
+            const int qb = qt * QR + sub * 32;                                // first query row of this 32-row slice
+            // wave-uniform skips: slice past the end, or (causal) all of this wave's keys in the slice's future
+            act[sub] = qb < p.Sq && !(p.causal && k0 > qb + 31 + coff);
+            if (!act[sub]) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { stv[sub][r] = 0.f; dpv[sub][r] = 0.f; }
 #pragma unroll
             for (int ds = 0; ds < D / 16; ++ds) {
-                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(qimg, 0, ds, lane), kf[ds], st, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(gimg, 0, ds, lane), vf[ds], dp, 0, 0, 0);
+                stv[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(qimg, sub * 32, ds, lane), kf[ds], stv[sub], 0, 0, 0);
+                dpv[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(gimg, sub * 32, ds, lane), vf[ds], dpv[sub], 0, 0, 0);
             }
-            // st[r]: S[q = qt*32 + acc_row(r)][key = kcol]
+        }
+#pragma unroll
+        for (int sub = 0; sub < NS; ++sub) {
+            if (!act[sub]) continue;
+            const int qb = qt * QR + sub * 32;
+            f32x16& st = stv[sub];
+            f32x16& dp = dpv[sub];
+            // st[r]: S[q = qb + acc_row(r)][key = kcol]
             // masks only on boundary tiles (wave-uniform): ragged Sq/Sk, left padding, causal diagonal
-            const bool need_mask = (qt * 32 + 31 >= p.Sq) || (k0 + 31 >= p.Sk) || (k0 < kv_lo) ||
-                                   (p.causal && k0 + 31 > qt * 32 + coff);
+            const bool need_mask = (qb + 31 >= p.Sq) || (k0 + 31 >= p.Sk) || (k0 < kv_lo) ||
+                                   (p.causal && k0 + 31 > qb + coff);
+            // this lane's 16 accumulator rows are 4 runs of 4 consecutive query rows (acc_row): fetch lse / delta as
+            // 4 + 4 ds_read_b128 instead of 32 scalar LDS reads inside the dependent exp chain
+            float lsv[16], dlv[16];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const float4 a4 = *(const float4*)(lse_s + sub * 32 + 8 * q4 + 4 * h2);
+                const float4 b4 = *(const float4*)(dlt_s + sub * 32 + 8 * q4 + 4 * h2);
+                lsv[4 * q4 + 0] = a4.x; lsv[4 * q4 + 1] = a4.y; lsv[4 * q4 + 2] = a4.z; lsv[4 * q4 + 3] = a4.w;
+                dlv[4 * q4 + 0] = b4.x; dlv[4 * q4 + 1] = b4.y; dlv[4 * q4 + 2] = b4.z; dlv[4 * q4 + 3] = b4.w;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ql = acc_row(r, lane);
-                float pv = __builtin_amdgcn_exp2f(fmaf(st[r], p.scale_log2, -lse_s[ql]));
+                float pv = __builtin_amdgcn_exp2f(fmaf(st[r], p.scale_log2, -lsv[r]));
                 if (need_mask) {
-                    const int q = qt * 32 + ql;
+                    const int q = qb + ql;
                     const bool ok = key_ok && q < p.Sq && (!p.causal || kcol <= q + coff);
                     pv = ok ? pv : 0.f;
                 }
                 float ms = 1.0f;
                 if constexpr (DROP) {
                     const int hq = hk * group + it / nq;
-                    const unsigned long idx = (((unsigned long)b * p.Hq + hq) * p.Sq + min(qt * 32 + ql, p.Sq - 1)) * p.Sk + kc;
+                    const unsigned long idx = (((unsigned long)b * p.Hq + hq) * p.Sq + min(qb + ql, p.Sq - 1)) * p.Sk + kc;
                     ms = desta_rng32(p.seed_lo, p.seed_hi, idx) >= p.drop_thresh ? p.drop_scale : 0.f;
                 }
                 st[r] = pv * ms;                                             // (dropped) P for dV
-                dp[r] = pv * (ms * dp[r] - dlt_s[ql]) * p.scale;             // dS
+                dp[r] = pv * (ms * dp[r] - dlv[r]) * p.scale;                // dS
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const bf16x8 pf = acc_frag(st, s), dsf = acc_frag(dp, s);
 #pragma unroll
                 for (int i = 0; i < D / 32; ++i) {
-                    dv[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, frag_tr<D>(gimg, 16 * s, i * 32, lane), dv[i], 0, 0, 0);
-                    dk[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf, frag_tr<D>(qimg, 16 * s, i * 32, lane), dk[i], 0, 0, 0);
+                    dv[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, frag_tr<D>(gimg, sub * 32 + 16 * s, i * 32, lane), dv[i], 0, 0, 0);
+                    dk[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf, frag_tr<D>(qimg, sub * 32 + 16 * s, i * 32, lane), dk[i], 0, 0, 0);
                 }
             }
+        }
     };
     for (int it = 0; it < n_it; it += 2) {
         DESTA_Q_STAGE(it, qr0, gr0, ls0, dl0)
