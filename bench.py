@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--no-stagger", action="store_true", help="A/B: lockstep GEMM schedule")
     ap.add_argument("--repeat", type=int, default=1, help="repeat the timed region (reports the best), for A/B runs")
     ap.add_argument("--no-dw-overlap", action="store_true", help="A/B: Q-Former weight gradients on the main stream")
+    ap.add_argument("--gemm-4phase", action="store_true", help="A/B: the 4-phase (16 MFMAs per phase) GEMM schedule")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,6 +129,8 @@ def main():
         H.gemm_set_option(0, 1)
     if a.no_stagger:
         H.gemm_set_option(1, 0)
+    if a.gemm_4phase:
+        H.gemm_set_option(4, 0)
     cfg = DeSTA25Config(**FULL_CONFIGS[a.config])
     t0 = time.time()
     model = DeSTA25AudioModel(cfg, weights=RandomWeights(cfg, dev, seed=0), device=dev)

@@ -345,7 +345,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs p) {
 //   slots so the count stays constant.
 constexpr int HT = 128 * BK * 2;                         // half-tile bytes (128 rows x 128 B)
 
-template <bool STAGGER>
+// PHASES = 4: the schedule described above.  PHASES = 2: the same half-tile stream and slots, but a K-tile is multiplied
+// in TWO phases of 32 MFMAs per wave (P1 reads A0,B0,B1 -> Q00,Q01; P2 reads A1 -> Q11,Q10 with B in registers): half the
+// workgroup barriers per K-tile (rocprofv3 PMC: the waves of the 4-phase kernel are parked at s_waitcnt / s_barrier 37 %
+// of their cycles).  P1 stages A1(t+1) into the slot P2(t-1) vacated, P2 stages A0,B0,B1(t+2) into the slots P1
+// vacated; every barrier is preceded by vmcnt(8): all but the 4 youngest half-tiles have landed.
+template <bool STAGGER, int PHASES>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) char lds[2 * 4 * HT];            // [buf][A0,A1,B0,B1]
 
@@ -425,7 +430,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
 
 #pragma unroll
     for (int j = 0; j < 7; ++j) stage(j);
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    if (PHASES == 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     bf16x8 a[4][2], b0[2][2], b1[2][2];
@@ -434,8 +439,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
     // slot and an MFMA slot with a barrier after each; group B enters the loop one barrier late and group A
     // leaves it one barrier late.  Every slot ends with lgkmcnt(0) (its ds_reads have returned before any
     // other wave may re-stage the slot) and the counted vmcnt (the shares this wave issued have landed).
-#define SLOT_END()                                        \
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");     \
+#define SLOT_END()                                                                                                  \
+    if (PHASES == 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); \
     __builtin_amdgcn_s_barrier();
 #define MFMA_SLOT(ACC_I0, ACC_J0, BF)                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
@@ -452,6 +457,40 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
         const char* base = lds + (t & 1) * 4 * HT;
         const char* A0 = base, *A1 = base + HT, *B0 = base + 2 * HT, *B1 = base + 3 * HT;
         const int g = 4 * t;
+        if constexpr (PHASES == 2) {
+            // ---------------- P1: A0, B0, B1 -> Q00, Q01
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    b0[i][kk] = *(const bf16x8*)(B0 + (offB[i] ^ (kk << 6)));
+                    b1[i][kk] = *(const bf16x8*)(B1 + (offB[i] ^ (kk << 6)));
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) a[i][kk] = *(const bf16x8*)(A0 + (offA[i] ^ (kk << 6)));
+            stage(g + 7);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (STAGGER) { SLOT_END() }
+            MFMA_SLOT(0, 0, b0)
+            MFMA_SLOT(0, 2, b1)
+            SLOT_END()
+            // ---------------- P2: A1 (B in registers) -> Q11, Q10
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) a[i][kk] = *(const bf16x8*)(A1 + (offA[i] ^ (kk << 6)));
+            stage(g + 8);
+            stage(g + 9);
+            stage(g + 10);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (STAGGER) { SLOT_END() }
+            MFMA_SLOT(4, 2, b1)
+            MFMA_SLOT(4, 0, b0)
+            SLOT_END()
+            continue;
+        }
         // ---------------- P1: A0, B0 -> Q00
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -945,6 +984,7 @@ static int g_force_variant = 0;   // 0 auto, 1 = 128x128, 2 = 256x256 lockstep, 
 extern "C" int desta_gemm_force_variant(int v) { g_force_variant = v; return DESTA_OK; }
 static int g_persistent = 0;      // automatic choice may use the persistent kernel (in-situ A/B: no gain)
 static int g_stagger = 1;         // automatic choice uses the staggered schedule
+static int g_phases2 = 1;         // automatic choice uses the 2-phase (32 MFMAs per phase) staggered schedule (+5-16 % on every shape)
 extern "C" int desta_gemm_set_persistent(int on) { g_persistent = on; return DESTA_OK; }
 static int g_skinny = 0;          // 0 auto, else COLS*10 + U of the skinny (M <= 16) kernel (tuning)
 static int g_skinny_blocks = 512;  // persistent grid of the skinny kernel (2 blocks per CU)
@@ -958,6 +998,7 @@ extern "C" int desta_gemm_set_option(int option, int value) {
         }
         g_skinny = value;
     }
+    else if (option == 4) g_phases2 = value;
     else if (option == 3) {
         if (value < 1 || value > 65535) { desta_set_error("gemm_set_option: skinny grid %d out of range", value); return DESTA_EINVAL; }
         g_skinny_blocks = value;
@@ -1063,9 +1104,11 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
         // variants: 2 = lockstep, 3 = staggered (+4-7 %), 4 = staggered + persistent cross-tile streaming
         //           (default when a block gets more than one item; +3-7 % on the LLM shapes)
         const bool persistent = g_force_variant == 4 || (g_force_variant == 0 && g_persistent && items > NCU);
-        if (g_force_variant == 2 || (g_force_variant == 0 && !g_stagger)) hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<false>, dim3(items, d->batch), dim3(512), 0, (hipStream_t)stream, a);
+        if (g_force_variant == 2 || (g_force_variant == 0 && !g_stagger)) hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<false, 4>), dim3(items, d->batch), dim3(512), 0, (hipStream_t)stream, a);
         else if (persistent) hipLaunchKernelGGL(gemm_bf16_nt_256p_kernel<true>, dim3(items < NCU ? items : NCU, d->batch), dim3(512), 0, (hipStream_t)stream, a, items);
-        else hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<true>, dim3(items, d->batch), dim3(512), 0, (hipStream_t)stream, a);
+        else if (g_force_variant == 6 || (g_force_variant == 0 && g_phases2)) hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<true, 2>), dim3(items, d->batch), dim3(512), 0, (hipStream_t)stream, a);
+        else if (g_force_variant == 7) hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<false, 2>), dim3(items, d->batch), dim3(512), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<true, 4>), dim3(items, d->batch), dim3(512), 0, (hipStream_t)stream, a);
         if (split > 1)
             hipLaunchKernelGGL(gemm_splitk_fixup_kernel, dim3((unsigned)(T - full) * 64, d->batch), dim3(256), 0, (hipStream_t)stream, a);
     } else {
