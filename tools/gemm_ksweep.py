@@ -33,7 +33,7 @@ def main():
                 C = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
                 bias = torch.randn(N, device=dev) if epi == "bias+gelu" else None
                 res = torch.randn(M, N, device=dev).to(torch.bfloat16) if epi == "residual" else None
-                H.gemm_force_variant(3)
+                H.gemm_force_variant(6)
                 us = t_us(lambda: H.gemm(A, B, C, M, N, K, bias=bias, residual=res, act=1 if bias is not None else 0))
                 H.gemm_force_variant(0)
                 pts.append((K // 64, us / rounds))
