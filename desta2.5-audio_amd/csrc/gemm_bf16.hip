@@ -18,6 +18,10 @@
 #include "desta_hip.h"
 #include <math.h>
 
+#ifndef GEMM_GROUP_M
+#define GEMM_GROUP_M 8        // tile-group height of the 256x256 kernel (8 vs 4: gate_up +2-3 %, others equal; tools/gemm_bench.py)
+#endif
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
         L = p.full_tiles + j / p.split;
         slice = j % p.split;
     }
-    constexpr int GROUP_M = 4;
+    constexpr int GROUP_M = GEMM_GROUP_M;
     const int gspan = GROUP_M * p.tilesN;
     const int first_m = (L / gspan) * GROUP_M;
     const int gsz = min(p.tilesM - first_m, GROUP_M);
