@@ -599,7 +599,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256p_kernel(GemmArgs p, i
     const bf16_t* A = p.A + (long)z * p.sA;
     const bf16_t* B = p.B + (long)z * p.sB;
     const int nk_all = p.K / BK;
-    constexpr int GROUP_M = 4;
+    constexpr int GROUP_M = GEMM_GROUP_M;              // the fix-up / persistent kernels must map L -> tile like the main kernel
 
     // item id -> tile origin + K range
     auto item_geom = [&](int s, int& brow, int& bcol, int& kt0, int& nk, bool& partial, int& slab) {
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_fixup_kernel(GemmArgs p) {
     const int ti = blockIdx.x / 64, part = blockIdx.x % 64;          // 64 blocks per tile: 4 rows x 256 cols each
     const int z = blockIdx.y;
     const int L = p.full_tiles + ti;
-    constexpr int GROUP_M = 4;
+    constexpr int GROUP_M = GEMM_GROUP_M;              // the fix-up / persistent kernels must map L -> tile like the main kernel
     const int gspan = GROUP_M * p.tilesN;
     const int first_m = (L / gspan) * GROUP_M;
     const int gsz = min(p.tilesM - first_m, GROUP_M);
