@@ -332,3 +332,26 @@ def test_loss_curve_tracks_oracle_over_many_steps():
     assert ref[-1] < ref[0] - 0.3                                # the pool is being fitted
     assert sum(diff) / len(diff) < 5e-3 and max(diff) < 3e-2
     assert abs(sum(hip[-10:]) - sum(ref[-10:])) / 10 < 5e-3
+
+
+def test_training_entry_point_debug_config(tmp_path):
+    """The reference's integration test is its run recipe (`train_desta.py --config-name desta25_debug +dataset=debug`):
+    same command line here, synthetic data, 12 steps; checks the experiment directory layout the reference produces."""
+    import importlib.util
+    import json
+    import os
+    from safetensors.torch import load_file
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("train_desta", os.path.join(root, "examples", "train", "train_desta.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    exp = str(tmp_path / "exp")
+    m.main(["--config-name", "desta25_debug", "+dataset=debug", f"exp_dir={exp}", "trainer.max_steps=12"])
+    assert os.path.isfile(os.path.join(exp, "config.yaml"))
+    init = load_file(os.path.join(exp, "checkpoint-initial", "model.safetensors"))
+    last = load_file(os.path.join(exp, "checkpoint-12", "model.safetensors"))
+    assert sorted(init) == sorted(last) and all(k.startswith("perception.connector.") for k in init)   # trainable-only, reference keys
+    assert any(not torch.equal(init[k], last[k]) for k in init)                                          # parameters moved
+    cfgj = json.load(open(os.path.join(exp, "checkpoint-12", "config.json")))
+    assert cfgj["model_type"] == "desta25" and cfgj["connector_mode"] == "qformer_1"
+    assert os.path.isfile(os.path.join(exp, "checkpoint-12", "optimizer.pt"))
