@@ -176,7 +176,11 @@ def main():
     loss = run(a.steps, a.warmup)
     fence()
     elapsed = time.perf_counter() - t0
-    n_launch, flops, gemm_ms = H.gemm_profile_stop()
+    prof = H.gemm_profile_stop(by_kernel=True)
+    n_launch, flops, gemm_ms = prof.get(2, (0, 0.0, 0.0))                 # the dominant kernel: gemm_bf16_nt_256_kernel
+    n_other = sum(v[0] for k, v in prof.items() if k != 2)
+    ms_other = sum(v[2] for k, v in prof.items() if k != 2)
+    flops_other = sum(v[1] for k, v in prof.items() if k != 2)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -188,7 +192,7 @@ def main():
         # HBM bytes per launch of the dominant kernel: from the separate rocprofv3 --pmc passes of this same
         # command (profiles/, FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes); null if absent
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_b_gemm_hbm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_c_gemm_hbm_traffic.json")
         if a.config == "desta25_llama31-8B_Qformer6L" and os.path.isfile(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
@@ -205,10 +209,13 @@ def main():
                        "step_definition": "one pass of the hot path over one per-GPU batch; value = per-GPU batch-steps per second "
                                           "summed over the node (N x K / max-over-ranks time), weak scaling"},
             "final_loss": final_loss,
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_256_kernel (+ gemm_bf16_nt_kernel on small shapes)", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_256_kernel", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
                          "launches_per_step": n_launch / a.steps, "avg_launch_us": 1e3 * gemm_ms / max(n_launch, 1),
-                         "flop_per_launch": flops / max(n_launch, 1), "gemm_ms_per_step": gemm_ms / a.steps},
+                         "flop_per_launch": flops / max(n_launch, 1), "gemm_ms_per_step": gemm_ms / a.steps,
+                         "other_gemm_kernels": {"launches_per_step": n_other / a.steps, "ms_per_step": ms_other / a.steps,
+                                                "tflops": (flops_other / (ms_other * 1e-3) / 1e12) if ms_other > 0 else 0.0,
+                                                "note": "gemm_bf16_nt_kernel (128x128, incl. transposed-storage dW on a side stream)"}},
         }
         if not a.no_cpu_baseline and world == 1:
             try:

@@ -984,6 +984,8 @@ __global__ __launch_bounds__(512, (COLS == 16 && U == 2) ? 2 : 1) void gemm_bf16
 
 }  // namespace
 
+static int g_last_kernel = 0;      // kernel family of the most recent launch: 1 = 128x128, 2 = 256x256 (+ split-K fix-up), 3 = skinny
+extern "C" int desta_gemm_last_kernel(void) { return g_last_kernel; }
 static int g_force_variant = 0;   // 0 auto, 1 = 128x128, 2 = 256x256 lockstep, 3 = staggered, 4 = staggered persistent (tuning / tests)
 extern "C" int desta_gemm_force_variant(int v) { g_force_variant = v; return DESTA_OK; }
 static int g_persistent = 0;      // automatic choice may use the persistent kernel (in-situ A/B: no gain)
@@ -1089,6 +1091,7 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
         else SK_LAUNCH(16, 2, false);
 #undef SK_LAUNCH
         DESTA_CHECK_LAUNCH("gemm_bf16_nt_skinny");
+        g_last_kernel = 3;
         return DESTA_OK;
     }
     bool big = false;
@@ -1125,5 +1128,6 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
         else hipLaunchKernelGGL((gemm_bf16_nt_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
     }
     DESTA_CHECK_LAUNCH("gemm_bf16_nt");
+    g_last_kernel = big ? 2 : 1;
     return DESTA_OK;
 }

@@ -107,7 +107,7 @@ def gemm(A, B, out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, residua
         e0.record()
         check(_gemm(C.byref(d), stream()), "desta_gemm_bf16_nt")
         e1.record()
-        _gemm_prof.append((e0, e1, 2.0 * M * N * K * batch))
+        _gemm_prof.append((e0, e1, 2.0 * M * N * K * batch, lib.desta_gemm_last_kernel()))
         return out
     check(_gemm(C.byref(d), stream()), "desta_gemm_bf16_nt")
     return out
@@ -128,13 +128,20 @@ def gemm_profile_start():
     _gemm_prof = []
 
 
-def gemm_profile_stop():
-    """-> (n_launches, total_flops, total_ms) of the GEMM launches since gemm_profile_start()."""
+def gemm_profile_stop(by_kernel: bool = False):
+    """-> (n_launches, total_flops, total_ms) of the GEMM launches since gemm_profile_start(); with by_kernel a dict
+    {kernel family (1 = 128x128, 2 = 256x256, 3 = skinny): (n, flops, ms)} instead."""
     global _gemm_prof
     rec, _gemm_prof = _gemm_prof, None
     torch.cuda.synchronize()
-    ms = sum(a.elapsed_time(b) for a, b, _ in rec)
-    return len(rec), sum(f for _, _, f in rec), ms
+    if by_kernel:
+        out = {}
+        for a, b, f, k in rec:
+            n0, f0, m0 = out.get(k, (0, 0.0, 0.0))
+            out[k] = (n0 + 1, f0 + f, m0 + a.elapsed_time(b))
+        return out
+    ms = sum(a.elapsed_time(b) for a, b, _, _ in rec)
+    return len(rec), sum(f for _, _, f, _ in rec), ms
 
 
 # ----------------------------------------------------------------------------- log-mel

@@ -80,6 +80,9 @@ int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream);
 /* tuning / tests only: 0 = automatic tile choice, 1 = force 128x128, 2 / 3 / 4 = force the 256x256 kernel with the
  * lockstep / staggered / staggered-persistent four-phase schedule, 6 / 7 = staggered / lockstep two-phase schedule */
 int desta_gemm_force_variant(int variant);
+/* kernel family the most recent desta_gemm_bf16_nt call launched: 1 = 128x128, 2 = 256x256 (+ split-K fix-up), 3 = skinny
+ * (bench.py attributes its HIP-event timings to the dominant kernel with this) */
+int desta_gemm_last_kernel(void);
 int desta_gemm_set_persistent(int on);   /* 1: the automatic choice uses the persistent kernel when a block owns > 1 item */
 /* A/B switches of the automatic choice: option 0 = persistent, 1 = staggered, 2 = skinny (M <= 16) kernel variant
  * (0 auto, else COLS*10 + U: 162 164 322 641), 3 = persistent grid size of the skinny kernel (default 512 = 2 blocks per CU),
