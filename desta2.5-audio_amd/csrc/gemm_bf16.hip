@@ -588,7 +588,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
 // stores of item s drain behind the main loop of item s+1 (with one block per CU nothing else would hide
 // them).  With the staggered schedule the two wave groups run their epilogues half a phase apart, each
 // beside the other group's MFMA slot.  Same phase structure, LDS slot rule and counted vmcnt(10) as above.
-template <bool STAGGER>
+template <bool STAGGER, int PHASES>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256p_kernel(GemmArgs p, int n_items) {
     __shared__ __attribute__((aligned(16))) char lds[2 * 4 * HT];
 
@@ -675,12 +675,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256p_kernel(GemmArgs p, i
 
     setup_issue(0);
     STAGE_NEXT(0) STAGE_NEXT(1) STAGE_NEXT(2) STAGE_NEXT(3) STAGE_NEXT(0) STAGE_NEXT(1) STAGE_NEXT(2)
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    if (PHASES == 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     bf16x8 a[4][2], b0[2][2], b1[2][2];
-#define SLOT_END()                                        \
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");     \
+#define SLOT_END()                                                                                                  \
+    if (PHASES == 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); \
     __builtin_amdgcn_s_barrier();
 #define MFMA_SLOT(ACC_I0, ACC_J0, BF)                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
@@ -704,6 +704,40 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256p_kernel(GemmArgs p, i
         for (int t = 0; t < nk; ++t, ++Tc) {
             const char* base = lds + (Tc & 1) * 4 * HT;
             const char* A0 = base, *A1 = base + HT, *B0 = base + 2 * HT, *B1 = base + 3 * HT;
+            if constexpr (PHASES == 2) {
+                // P1: A0, B0, B1 -> Q00, Q01
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        b0[i][kk] = *(const bf16x8*)(B0 + (offB[i] ^ (kk << 6)));
+                        b1[i][kk] = *(const bf16x8*)(B1 + (offB[i] ^ (kk << 6)));
+                    }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) a[i][kk] = *(const bf16x8*)(A0 + (offA[i] ^ (kk << 6)));
+                STAGE_NEXT(3)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (STAGGER) { SLOT_END() }
+                MFMA_SLOT(0, 0, b0)
+                MFMA_SLOT(0, 2, b1)
+                SLOT_END()
+                // P2: A1 (B in registers) -> Q11, Q10
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) a[i][kk] = *(const bf16x8*)(A1 + (offA[i] ^ (kk << 6)));
+                STAGE_NEXT(0)
+                STAGE_NEXT(1)
+                STAGE_NEXT(2)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (STAGGER) { SLOT_END() }
+                MFMA_SLOT(4, 2, b1)
+                MFMA_SLOT(4, 0, b0)
+                SLOT_END()
+                continue;
+            }
             // P1: A0, B0 -> Q00            (stream position g+7 : A1 of the K-tile after next)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -1112,7 +1146,8 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
         //           (default when a block gets more than one item; +3-7 % on the LLM shapes)
         const bool persistent = g_force_variant == 4 || (g_force_variant == 0 && g_persistent && items > NCU);
         if (g_force_variant == 2 || (g_force_variant == 0 && !g_stagger)) hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<false, 4>), dim3(items, d->batch), dim3(512), 0, (hipStream_t)stream, a);
-        else if (persistent) hipLaunchKernelGGL(gemm_bf16_nt_256p_kernel<true>, dim3(items < NCU ? items : NCU, d->batch), dim3(512), 0, (hipStream_t)stream, a, items);
+        else if (g_force_variant == 8) hipLaunchKernelGGL((gemm_bf16_nt_256p_kernel<true, 2>), dim3(items < NCU ? items : NCU, d->batch), dim3(512), 0, (hipStream_t)stream, a, items);
+        else if (persistent) hipLaunchKernelGGL((gemm_bf16_nt_256p_kernel<true, 4>), dim3(items < NCU ? items : NCU, d->batch), dim3(512), 0, (hipStream_t)stream, a, items);
         else if (g_force_variant == 6 || (g_force_variant == 0 && g_phases2)) hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<true, 2>), dim3(items, d->batch), dim3(512), 0, (hipStream_t)stream, a);
         else if (g_force_variant == 7) hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<false, 2>), dim3(items, d->batch), dim3(512), 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<true, 4>), dim3(items, d->batch), dim3(512), 0, (hipStream_t)stream, a);

@@ -78,7 +78,8 @@ typedef struct desta_gemm_desc {
 } desta_gemm_desc;
 int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream);
 /* tuning / tests only: 0 = automatic tile choice, 1 = force 128x128, 2 / 3 / 4 = force the 256x256 kernel with the
- * lockstep / staggered / staggered-persistent four-phase schedule, 6 / 7 = staggered / lockstep two-phase schedule */
+ * lockstep / staggered / staggered-persistent four-phase schedule, 6 / 7 = staggered / lockstep two-phase schedule,
+ * 8 = two-phase schedule in the persistent tile walk */
 int desta_gemm_force_variant(int variant);
 /* kernel family the most recent desta_gemm_bf16_nt call launched: 1 = 128x128, 2 = 256x256 (+ split-K fix-up), 3 = skinny
  * (bench.py attributes its HIP-event timings to the dominant kernel with this) */

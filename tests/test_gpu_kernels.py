@@ -71,7 +71,7 @@ def test_gemm_256_staggered_variant(hip, M, N, K):
     B = _bf(torch.randn(N, K, generator=g)).cuda()
     outs = []
     try:
-        for v in (2, 3, 4, 6, 7):
+        for v in (2, 3, 4, 6, 7, 8):
             hip.gemm_force_variant(v)
             o = torch.empty(M, N, dtype=torch.float32, device="cuda")
             for _ in range(3):                      # repeat: a schedule race would show up as run-to-run differences
@@ -81,6 +81,7 @@ def test_gemm_256_staggered_variant(hip, M, N, K):
         hip.gemm_force_variant(0)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     assert torch.equal(outs[0], outs[3]) and torch.equal(outs[0], outs[4])      # 6 / 7: two-phase schedules (staggered / lockstep)
+    assert torch.equal(outs[0], outs[5])                                        # 8: two-phase, persistent tile walk
     torch.testing.assert_close(outs[1], A.float() @ B.float().T, rtol=1e-4, atol=2e-3)
 
 
