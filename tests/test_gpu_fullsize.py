@@ -148,7 +148,10 @@ def test_full_size_generate_cache_consistency(hip, full_model):
         a, b = logits[k].float(), lg[0].float()
         rel = float((a - b).norm() / b.norm())
         assert rel < 2e-2, (k, rel)
-        assert float((a.argmax(-1) == b.argmax(-1)).float().mean()) >= 0.75
+        # the no-cache pass's greedy token is (near-)optimal under the cached logits too (random-init logits are flat:
+        # compare by margin, not by identity of the argmax)
+        gap = a.max(-1).values - a.gather(-1, b.argmax(-1, keepdim=True)).squeeze(-1)
+        assert float((gap / a.std(-1)).max()) < 0.1, gap
     # left padding: rows shifted right by 5 pad positions continue identically (positions and masks follow the mask)
     pad = 5
     S = t["input_ids"].shape[1]
