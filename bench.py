@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--repeat", type=int, default=1, help="repeat the timed region (reports the best), for A/B runs")
     ap.add_argument("--no-dw-overlap", action="store_true", help="A/B: Q-Former weight gradients on the main stream")
     ap.add_argument("--gemm-4phase", action="store_true", help="A/B: the 4-phase (16 MFMAs per phase) GEMM schedule")
+    ap.add_argument("--full-lm-head", action="store_true", help="A/B: lm_head / CE over the whole token grid, not only the target rows")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -139,6 +140,8 @@ def main():
     trainer = DeSTA25Trainer(model, args=args)
     if a.no_dw_overlap:
         model.connector.overlap_dw = False
+    if a.full_lm_head:
+        model.compact_lm_head = False
     B, S = a.batch, a.ctx + cfg.prompt_size + a.tgt
     n_mels = cfg.encoder_config.num_mel_bins
     # two alternating synthetic batches per rank, resident in HBM (seed 1234 + rank)

@@ -29,6 +29,45 @@ __global__ __launch_bounds__(256) void gather_rows_k(const bf16_t* __restrict__ 
     for (int c = lane * 8; c < h; c += 512) *(u16x8*)(out + (long)row * h + c) = *(const u16x8*)(src + c);
 }
 
+// out[idx[i]] = in[i]: rows of a compact [rows, h] matrix back into their places (the inverse of gather_rows)
+__global__ __launch_bounds__(256) void scatter_rows_k(const bf16_t* __restrict__ in, const int* __restrict__ idx, int rows,
+                                                      int h, bf16_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    bf16_t* dst = out + (long)idx[row] * h;
+    for (int c = lane * 8; c < h; c += 512) *(u16x8*)(dst + c) = *(const u16x8*)(in + (long)row * h + c);
+}
+
+// Rows of the [B*S] token grid whose SHIFTED label is a real target (ForCausalLMLoss: row (b,s) predicts labels[b,s+1]):
+// idx[0..n) = those rows in order, lab[0] = -100, lab[1 + i] = target of compact row i, lab[1 + n] = -100, count = n.
+// One block; fixed-order scan (deterministic).  lab is laid out so that `desta_causal_lm_loss(batch = 1, seq = n + 1)`
+// on a compact [n + 1, V] logits buffer reproduces the full-grid loss and gradients of exactly these rows.
+__global__ __launch_bounds__(1024) void target_rows_k(const long* __restrict__ labels, int B, int S, int* __restrict__ idx,
+                                                      long* __restrict__ lab, int* __restrict__ count) {
+    __shared__ int part[1024];
+    const int M = B * S, tid = threadIdx.x;
+    const int per = (M + 1023) / 1024, m0 = tid * per, m1 = min(M, m0 + per);
+    int n = 0;
+    for (int m = m0; m < m1; ++m) n += ((m % S) + 1 < S && labels[m + 1] != -100) ? 1 : 0;
+    part[tid] = n;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < 1024; ++i) { const int v = part[i]; part[i] = run; run += v; }
+        *count = run;
+        lab[0] = -100;
+        lab[1 + run] = -100;
+    }
+    __syncthreads();
+    int pos = part[tid];
+    for (int m = m0; m < m1; ++m)
+        if ((m % S) + 1 < S && labels[m + 1] != -100) {
+            idx[pos] = m;
+            lab[1 + pos] = labels[m + 1];
+            ++pos;
+        }
+}
+
 // scal[0] = number of valid (shifted) targets, scal[1] = 1/scal[0]
 __global__ __launch_bounds__(256) void ce_count_k(const long* __restrict__ labels, int B, int S, float* __restrict__ scal) {
     __shared__ float red[4];
@@ -294,6 +333,23 @@ extern "C" int desta_gather_rows_bf16(const void* in, const int32_t* idx, int ro
     hipLaunchKernelGGL(gather_rows_k, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, idx, rows,
                        hidden, (bf16_t*)out);
     DESTA_CHECK_LAUNCH("gather_rows");
+    return DESTA_OK;
+}
+
+extern "C" int desta_scatter_rows_bf16(const void* in, const int32_t* idx, int rows, int hidden, void* out, void* stream) {
+    DESTA_CHECK_ARG(in && idx && out && rows > 0 && hidden % 8 == 0, "scatter_rows: bad argument");
+    hipLaunchKernelGGL(scatter_rows_k, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, idx, rows,
+                       hidden, (bf16_t*)out);
+    DESTA_CHECK_LAUNCH("scatter_rows");
+    return DESTA_OK;
+}
+
+extern "C" int desta_target_rows(const int64_t* labels, int batch, int seq, int32_t* idx, int64_t* compact_labels, int32_t* count,
+                                 void* stream) {
+    DESTA_CHECK_ARG(labels && idx && compact_labels && count && batch > 0 && seq > 0, "target_rows: bad argument");
+    hipLaunchKernelGGL(target_rows_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const long*)labels, batch, seq, idx,
+                       (long*)compact_labels, count);
+    DESTA_CHECK_LAUNCH("target_rows");
     return DESTA_OK;
 }
 

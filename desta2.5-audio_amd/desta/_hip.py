@@ -485,3 +485,16 @@ def _check_struct_layouts() -> None:
 
 
 _check_struct_layouts()
+
+
+_scatter = _sig("desta_scatter_rows_bf16", vp, vp, i32, i32, vp, vp)
+_target_rows = _sig("desta_target_rows", vp, i32, i32, vp, vp, vp, vp)
+
+
+def scatter_rows(src, idx, rows, hidden, out):
+    check(_scatter(p(src), p(idx), rows, hidden, p(out), stream()), "desta_scatter_rows_bf16")
+
+
+def target_rows(labels, batch, seq, idx, compact_labels, count):
+    """Rows with a real shifted target -> idx / compact label layout / device count (see include/desta_hip.h)."""
+    check(_target_rows(p(labels), batch, seq, p(idx), p(compact_labels), p(count), stream()), "desta_target_rows")

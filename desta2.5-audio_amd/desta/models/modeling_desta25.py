@@ -658,6 +658,7 @@ class CausalLMHIP:
             self.sv.append(s)
         self.rf = torch.empty(M, dtype=F32, device=dev)
         self.hb = b16(M, h)
+        self.hbc = b16(M, h)                                                                 # compact target rows (lm_head in / dX out)
         self.act = b16(M, self.I)
         self.logits = torch.zeros(M, self.Vp, dtype=BF16, device=dev)                        # pad columns stay 0
         self.loss = torch.zeros(1, dtype=F32, device=dev)
@@ -669,7 +670,7 @@ class CausalLMHIP:
 
     def forward(self, x0_filler, B: int, S: int, kv_start: Optional[torch.Tensor], labels: Optional[torch.Tensor], need_grad: bool,
                 pos_shift: Optional[torch.Tensor] = None, cos_sin: Optional[torch.Tensor] = None, last_logits: Optional[torch.Tensor] = None,
-                kv_cache: Optional[List[torch.Tensor]] = None):
+                kv_cache: Optional[List[torch.Tensor]] = None, target_rows=None):
         """`x0_filler(buf)` writes inputs_embeds [B*S, h] bf16 into buf.  Returns the logits buffer [B*S, Vp].
         Training uses position_ids = arange(S) (H7); generate() passes pos_shift (= -left_pad per sequence, with a
         `cos_sin` table that also covers the new tokens), `last_logits` [B, Vp] to project only the last row, and the
@@ -705,6 +706,19 @@ class CausalLMHIP:
         if last_logits is not None:                      # rows b*S + S-1 only: A is a strided view of hb
             H.gemm(self.hb[S - 1:], self.head, last_logits, B, self.V, h, lda=S * h, ldc=self.Vp)
             return last_logits
+        self.compact = None
+        if target_rows is not None:
+            # training without returned logits: lm_head / CE / lm_head backward only on the rows that carry a target
+            # (ForCausalLMLoss ignores the others; their gradient is exactly zero).  The row count comes from a side stream
+            # that only depends on `labels`, so waiting for it here does not drain the main stream.
+            idx, lab_c, count_host, ev = target_rows
+            ev.synchronize()
+            Mc = int(count_host[0])
+            if 0 < Mc < M:
+                H.gather_rows(self.hb, idx, Mc, h, self.hbc)
+                H.gemm(self.hbc, self.head, self.logits, Mc, self.V, h, ldc=self.Vp)        # compact logits in rows [0, Mc)
+                self.compact = (idx, lab_c, Mc)
+                return self.logits
         H.gemm(self.hb, self.head, self.logits, M, self.V, h, ldc=self.Vp)
         return self.logits
 
@@ -810,6 +824,10 @@ class CausalLMHIP:
 
     def loss_and_grad(self, labels: torch.Tensor, write_grad: bool) -> torch.Tensor:
         """ForCausalLMLoss on the logits of the last forward; with write_grad the logits buffer becomes dlogits."""
+        if getattr(self, "compact", None) is not None:
+            idx, lab_c, Mc = self.compact
+            H.causal_lm_loss(self.logits, self.Vp, lab_c, 1, Mc + 1, self.V, self.loss, write_grad=write_grad)
+            return self.loss
         H.causal_lm_loss(self.logits, self.Vp, labels, self.B, self.S, self.V, self.loss, write_grad=write_grad)
         return self.loss
 
@@ -817,7 +835,13 @@ class CausalLMHIP:
         """dlogits (in self.logits) -> dL/d inputs_embeds [B*S, h] bf16."""
         c, h, M, S = self.c, self.h, self.M, self.S
         dhb = self.hb
-        H.gemm(self.logits, self.headT, dhb, M, h, self.Vp, ldb=self.Vp)
+        if getattr(self, "compact", None) is not None:
+            idx, _, Mc = self.compact
+            H.gemm(self.logits, self.headT, self.hbc, Mc, h, self.Vp, ldb=self.Vp)       # d(final norm out) of the target rows
+            dhb.zero_()                                                                   # the other rows have zero gradient
+            H.scatter_rows(self.hbc, idx, Mc, h, dhb)
+        else:
+            H.gemm(self.logits, self.headT, dhb, M, h, self.Vp, ldb=self.Vp)
         dx, other = self.dxa, self.dxb
         H.rmsnorm_bwd(dhb, self.xs[self.L], self.norm, self.rf, dx)
         for i in reversed(range(self.L)):
@@ -863,6 +887,8 @@ class DeSTA25AudioModel:
         self._fwd = None
         self._enc_prefetched = None
         self.dropout_seed = 0                  # per-rank stream id of the Q-Former dropout RNG (trainer sets rank)
+        self.compact_lm_head = True            # training: lm_head / CE / its backward on target rows only
+        self._tr_stream = self._tr_idx = self._tr_lab = self._tr_count = self._tr_count_host = None
         self._fwd_count = 0
 
     # -- weights -------------------------------------------------------------------------------
@@ -1003,7 +1029,11 @@ class DeSTA25AudioModel:
 
             def fill(buf):
                 H.embed_gather(self.llm.embed, af, src, B * S, h, buf)
-            logits = self.llm.forward(fill, B, S, kv_start, labels, self.training)
+            target_rows = None
+            if (labels is not None and self.training and N_audio > 0 and not kwargs.get("keep_logits", False)
+                    and self.compact_lm_head):
+                target_rows = self._target_rows(labels, B, S)
+            logits = self.llm.forward(fill, B, S, kv_start, labels, self.training, target_rows=target_rows)
             V = cfg.llm_config.vocab_size
             out_logits = logits.view(B, S, self.llm.Vp)[:, :, :V]
             loss = None
@@ -1083,6 +1113,31 @@ class DeSTA25AudioModel:
         Build the batch with the reference's processor/collate code and call `_generate_step(batch, …)`."""
         raise NotImplementedError("chat-level generate() (tokenizer + audio-file front end) is out of scope of the MI355X hot path; "
                                   "use _generate_step(inputs, pad_token_id, do_sample=False, max_new_tokens=…) on a collated batch")
+
+    def _target_rows(self, labels, B: int, S: int):
+        """Index list / compact labels / host-visible count of the rows that carry a target, on a side stream: it waits for
+        the main stream's current position (the producer of `labels`), runs one tiny kernel and copies the count to pinned
+        memory; the main stream's later work is not involved, so synchronising on the event at lm_head time does not drain it."""
+        dev = self.device
+        if self._tr_stream is None:
+            self._tr_stream = torch.cuda.Stream(device=dev)
+            self._tr_count_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        M = B * S
+        if self._tr_idx is None or self._tr_idx.numel() < M:
+            self._tr_idx = torch.empty(M, dtype=torch.int32, device=dev)
+            self._tr_lab = torch.empty(M + 2, dtype=torch.int64, device=dev)
+            self._tr_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        main = torch.cuda.current_stream(dev)
+        lab_dev = labels.to(dev).contiguous()
+        self._tr_labels_keep = lab_dev                                           # alive until the side stream has read it
+        self._tr_stream.wait_stream(main)
+        with torch.cuda.stream(self._tr_stream):
+            H.target_rows(lab_dev, B, S, self._tr_idx, self._tr_lab, self._tr_count)
+            self._tr_count_host.copy_(self._tr_count, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._tr_stream)
+        main.wait_stream(self._tr_stream)                                        # idx / compact labels are read on the main stream
+        return self._tr_idx, self._tr_lab, self._tr_count_host, ev
 
     def prefetch_encoder(self, batch_features: torch.Tensor) -> None:
         """Run the FROZEN Whisper encoder for the next batch now (it does not depend on the connector

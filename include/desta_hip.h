@@ -257,6 +257,17 @@ int desta_prompt_grad(const float* dx, int taps, int batch, int64_t n, float* dp
 int desta_dropout_bf16(const void* x, void* y, int rows, int cols, int64_t ld, float p, uint64_t seed, void* stream);
 int desta_dropout_mask_u8(uint64_t seed, int64_t n, float p, uint8_t* out, void* stream);
 
+/* lm_head on target rows only.  `ForCausalLMLoss` (TF:loss/loss_utils.py:49-71) ignores every row whose shifted label is
+ * -100, so the logits of those rows (context, audio span, last position: 20 % of the synthetic batch, more on real data)
+ * and their zero gradients need not be computed.  desta_target_rows lists the rows of the [batch*seq] grid that carry a
+ * target (idx, in order; *count = n) and lays their targets out as compact_labels[0] = -100, [1 + i] = target of compact
+ * row i, [1 + n] = -100 (room for batch*seq + 2 entries): desta_causal_lm_loss(batch = 1, seq = n + 1) on a compact
+ * [n + 1, vocab] logits buffer then gives the same loss / gradients as the full grid.  desta_scatter_rows_bf16 is the
+ * inverse of desta_gather_rows_bf16 (out[idx[i]] = in[i]). */
+int desta_target_rows(const int64_t* labels, int batch, int seq, int32_t* idx, int64_t* compact_labels, int32_t* count,
+                      void* stream);
+int desta_scatter_rows_bf16(const void* in, const int32_t* idx, int rows, int hidden, void* out, void* stream);
+
 /* Greedy decoding helper: out[r] = argmax over the first `cols` entries of bf16 row r (first maximum, two-stage
  * reduction; `workspace` holds desta_argmax_workspace_bytes(rows) bytes).
  * Replaces the argmax of `llm_model.generate(do_sample=False)` (modeling_desta25.py:1419). */

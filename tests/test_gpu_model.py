@@ -355,3 +355,29 @@ def test_training_entry_point_debug_config(tmp_path):
     cfgj = json.load(open(os.path.join(exp, "checkpoint-12", "config.json")))
     assert cfgj["model_type"] == "desta25" and cfgj["connector_mode"] == "qformer_1"
     assert os.path.isfile(os.path.join(exp, "checkpoint-12", "optimizer.pt"))
+
+
+@pytest.mark.parametrize("name", ["llama", "qwen3"])
+def test_compact_lm_head_equals_full_grid(golden_dir, name):
+    """Training forward / backward with lm_head + CE restricted to the target rows == the full-grid path: same loss, same
+    connector gradients (only the fp32 summation order of split-K tail tiles may differ)."""
+    d = O.tiny_dims(name == "qwen3")
+    g, batch = golden_batch(golden_dir, name)
+    model, w = _model(d)
+    res = {}
+    for compact in (True, False):
+        model.compact_lm_head = compact
+        model.mark_weights_updated()
+        out = model(**batch)
+        assert out.logits is None
+        assert (model.llm.compact is not None) == compact
+        model.backward()
+        res[compact] = (float(out.loss), model.arena.grads.clone())
+    assert abs(res[True][0] - res[False][0]) < 1e-6 * max(1.0, abs(res[False][0]))
+    a, b = res[True][1].double(), res[False][1].double()
+    assert float((a - b).norm() / b.norm()) < 2e-3
+    assert abs(res[True][0] - float(g["loss"])) < 2e-2
+    # keep_logits / eval still take the full grid
+    model.compact_lm_head = True
+    out = model(**batch, keep_logits=True)
+    assert out.logits is not None and model.llm.compact is None

@@ -456,3 +456,38 @@ def test_attention_dropout_fwd_bwd(hip, Sq, Sk):
     hip.attention_fwd(d0)
     ref0 = (p @ v.permute(0, 2, 1, 3)).permute(0, 2, 1, 3)
     assert rel_err(o.float().cpu().view(B, Sq, H, D), ref0.detach()) < 8e-3
+
+
+def test_target_rows_and_scatter(hip):
+    """desta_target_rows: rows whose SHIFTED label is a target, their labels in the layout the CE entry point consumes with
+    (batch = 1, seq = n + 1), and the count; desta_scatter_rows_bf16 inverts desta_gather_rows_bf16."""
+    g = torch.Generator().manual_seed(12)
+    B, S = 5, 37
+    labels = torch.randint(0, 1000, (B, S), generator=g)
+    labels[:, :9] = -100
+    labels[2, 20:25] = -100
+    labels[4] = -100
+    idx = torch.full((B * S,), -1, dtype=torch.int32, device="cuda")
+    lab = torch.full((B * S + 2,), 7, dtype=torch.int64, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    hip.target_rows(labels.cuda(), B, S, idx, lab, cnt)
+    ref = [(b * S + s, int(labels[b, s + 1])) for b in range(B) for s in range(S - 1) if labels[b, s + 1] != -100]
+    n = int(cnt)
+    assert n == len(ref) and idx[:n].cpu().tolist() == [r for r, _ in ref]
+    assert lab[:n + 2].cpu().tolist() == [-100] + [t for _, t in ref] + [-100]
+    # CE on compact logits == CE on the full grid (loss and the gradient rows)
+    V = 1000
+    logits = bf(torch.randn(B * S, V, generator=g) * 2).cuda()
+    full = logits.clone()
+    loss_f, loss_c = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+    hip.causal_lm_loss(full, V, labels.cuda(), B, S, V, loss_f, write_grad=True)
+    comp = torch.zeros(n + 1, V, dtype=torch.bfloat16, device="cuda")
+    hip.gather_rows(logits, idx, n, V, comp)
+    hip.causal_lm_loss(comp, V, lab, 1, n + 1, V, loss_c, write_grad=True)
+    assert abs(float(loss_f) - float(loss_c)) < 1e-6 * max(1.0, float(loss_f))
+    back = torch.zeros_like(full)
+    hip.scatter_rows(comp, idx, n, V, back)
+    assert torch.equal(back, full)                                  # non-target rows of the full gradient are exactly zero
+    # no targets at all -> count 0
+    hip.target_rows(torch.full((B, S), -100).cuda(), B, S, idx, lab, cnt)
+    assert int(cnt) == 0 and lab[:2].cpu().tolist() == [-100, -100]
