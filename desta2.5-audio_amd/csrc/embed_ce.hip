@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void scatter_rows_k(const bf16_t* __restrict__
 // One block; fixed-order scan (deterministic).  lab is laid out so that `desta_causal_lm_loss(batch = 1, seq = n + 1)`
 // on a compact [n + 1, V] logits buffer reproduces the full-grid loss and gradients of exactly these rows.
 __global__ __launch_bounds__(1024) void target_rows_k(const long* __restrict__ labels, int B, int S, int* __restrict__ idx,
-                                                      long* __restrict__ lab, int* __restrict__ count) {
+                                                      long* __restrict__ lab, int* __restrict__ count, int s_major) {
     __shared__ int part[1024];
     const int M = B * S, tid = threadIdx.x;
     const int per = (M + 1023) / 1024, m0 = tid * per, m1 = min(M, m0 + per);
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(1024) void target_rows_k(const long* __restrict__ l
     int pos = part[tid];
     for (int m = m0; m < m1; ++m)
         if ((m % S) + 1 < S && labels[m + 1] != -100) {
-            idx[pos] = m;
+            idx[pos] = s_major ? (m % S) * B + m / S : m;          // row id in the position-major / batch-major token grid
             lab[1 + pos] = labels[m + 1];
             ++pos;
         }
@@ -345,10 +345,10 @@ extern "C" int desta_scatter_rows_bf16(const void* in, const int32_t* idx, int r
 }
 
 extern "C" int desta_target_rows(const int64_t* labels, int batch, int seq, int32_t* idx, int64_t* compact_labels, int32_t* count,
-                                 void* stream) {
+                                 int s_major, void* stream) {
     DESTA_CHECK_ARG(labels && idx && compact_labels && count && batch > 0 && seq > 0, "target_rows: bad argument");
     hipLaunchKernelGGL(target_rows_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const long*)labels, batch, seq, idx,
-                       (long*)compact_labels, count);
+                       (long*)compact_labels, count, s_major);
     DESTA_CHECK_LAUNCH("target_rows");
     return DESTA_OK;
 }

@@ -303,7 +303,7 @@ template <int HD, int NORM, bool BWD>
 __global__ __launch_bounds__(256) void rope_k(bf16_t* __restrict__ buf, long ld, int rows, int S, int n_heads, int n_q,
                                               const float* __restrict__ cs, const float* __restrict__ wq,
                                               const float* __restrict__ wk, float eps, const bf16_t* __restrict__ pre,
-                                              long ld_pre, const int* __restrict__ pos_shift, RopeKV kv) {
+                                              long ld_pre, const int* __restrict__ pos_shift, RopeKV kv, int sm_batch) {
     constexpr int G = HD / 16, H2 = HD / 2;
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     const long grp = gid / G;
@@ -320,7 +320,9 @@ __global__ __launch_bounds__(256) void rope_k(bf16_t* __restrict__ buf, long ld,
     }
     // position_ids: arange(S) for every row in training (H7); generate() passes a per-sequence shift
     // (-left_pad for the prompt, cache_length - left_pad for a decode step) as HF derives them from the mask
-    const int pos = pos_shift ? max(0, row % S + pos_shift[row / S]) : row % S;
+    // sm_batch > 0: the token grid is stored position-major (row = s * batch + b), else batch-major (row = b * S + s)
+    const int spos = sm_batch ? row / sm_batch : row % S, bidx = sm_batch ? row % sm_batch : row / S;
+    const int pos = pos_shift ? max(0, spos + pos_shift[bidx]) : spos;
     bf16_t* p = buf + (long)row * ld + (long)head * HD;
     float a[8], b[8], c[8], s[8];
     load8(p, 8 * j, 0, a);
@@ -782,7 +784,7 @@ extern "C" int desta_rmsnorm_bwd(const void* dy, const void* x, const float* wei
 
 static int rope_launch(void* buf, int64_t ld, int rows, int seq, int n_q_heads, int n_kv_heads, int head_dim,
                        const float* cos_sin, const float* q_norm_w, const float* k_norm_w, float eps,
-                       const void* pre_norm, int64_t ld_pre, int backward, const int32_t* pos_shift, RopeKV kv, void* stream) {
+                       const void* pre_norm, int64_t ld_pre, int backward, const int32_t* pos_shift, RopeKV kv, int sm_batch, void* stream) {
     DESTA_CHECK_ARG(buf && cos_sin, "rope: null argument");
     DESTA_CHECK_ARG(head_dim == 64 || head_dim == 128, "rope: head_dim %d unsupported (64 or 128)", head_dim);
     DESTA_CHECK_ARG(ld % 8 == 0 && rows > 0 && seq > 0, "rope: bad shape");
@@ -793,7 +795,7 @@ static int rope_launch(void* buf, int64_t ld, int rows, int seq, int n_q_heads, 
     const long nthreads = (long)rows * (nh + kv.n_v) * (head_dim / 16);
     dim3 grid((unsigned)((nthreads + 255) / 256));
     hipStream_t st = (hipStream_t)stream;
-#define ROPE_ARGS grid, dim3(256), 0, st, (bf16_t*)buf, (long)ld, rows, seq, nh, n_q_heads, cos_sin, q_norm_w, k_norm_w, eps, (const bf16_t*)pre_norm, (long)ld_pre, pos_shift, kv
+#define ROPE_ARGS grid, dim3(256), 0, st, (bf16_t*)buf, (long)ld, rows, seq, nh, n_q_heads, cos_sin, q_norm_w, k_norm_w, eps, (const bf16_t*)pre_norm, (long)ld_pre, pos_shift, kv, sm_batch
     if (head_dim == 128) {
         if (!backward) { if (norm) hipLaunchKernelGGL((rope_k<128, 1, false>), ROPE_ARGS); else hipLaunchKernelGGL((rope_k<128, 0, false>), ROPE_ARGS); }
         else { if (norm) hipLaunchKernelGGL((rope_k<128, 2, true>), ROPE_ARGS); else hipLaunchKernelGGL((rope_k<128, 0, true>), ROPE_ARGS); }
@@ -808,10 +810,12 @@ static int rope_launch(void* buf, int64_t ld, int rows, int seq, int n_q_heads, 
 
 extern "C" int desta_rope(void* buf, int64_t ld, int rows, int seq, int n_q_heads, int n_kv_heads, int head_dim,
                           const float* cos_sin, const float* q_norm_w, const float* k_norm_w, float eps,
-                          const void* pre_norm, int64_t ld_pre, int backward, const int32_t* pos_shift, void* stream) {
+                          const void* pre_norm, int64_t ld_pre, int backward, const int32_t* pos_shift, int s_major_batch,
+                          void* stream) {
+    DESTA_CHECK_ARG(s_major_batch >= 0 && (s_major_batch == 0 || rows % s_major_batch == 0), "rope: rows must be a multiple of s_major_batch");
     const RopeKV kv = {nullptr, 0, 0, 0, 0};
     return rope_launch(buf, ld, rows, seq, n_q_heads, n_kv_heads, head_dim, cos_sin, q_norm_w, k_norm_w, eps, pre_norm, ld_pre, backward,
-                       pos_shift, kv, stream);
+                       pos_shift, kv, s_major_batch, stream);
 }
 
 extern "C" int desta_rope_kv_append(void* qkv, int64_t ld, int rows, int seq, int n_q_heads, int n_kv_heads, int head_dim,
@@ -821,7 +825,7 @@ extern "C" int desta_rope_kv_append(void* qkv, int64_t ld, int rows, int seq, in
     DESTA_CHECK_ARG(kv_cache && kv_row_stride % 8 == 0 && kv_batch_stride % 8 == 0 && slot0 >= 0, "rope_kv_append: bad cache argument");
     DESTA_CHECK_ARG((uintptr_t)kv_cache % 16 == 0 && (uintptr_t)qkv % 16 == 0, "rope_kv_append: buffers must be 16-byte aligned");
     const RopeKV kv = {(bf16_t*)kv_cache, (long)kv_batch_stride, (long)kv_row_stride, slot0, n_kv_heads};
-    return rope_launch(qkv, ld, rows, seq, n_q_heads, n_kv_heads, head_dim, cos_sin, q_norm_w, k_norm_w, eps, nullptr, 0, 0, pos_shift, kv, stream);
+    return rope_launch(qkv, ld, rows, seq, n_q_heads, n_kv_heads, head_dim, cos_sin, q_norm_w, k_norm_w, eps, nullptr, 0, 0, pos_shift, kv, 0, stream);
 }
 
 extern "C" int desta_swiglu_fwd(const void* gate_up, void* act, int64_t rows, int inter, void* stream) {

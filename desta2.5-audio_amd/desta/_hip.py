@@ -207,7 +207,7 @@ _rms_bwd = _sig("desta_rmsnorm_bwd", vp, vp, vp, vp, vp, i32, i32, vp, vp)
 lib.desta_colsum_workspace_floats.restype = c_size_t
 lib.desta_colsum_workspace_floats.argtypes = [i32, i32]
 _colsum = _sig("desta_colsum_bf16", vp, i32, i32, i64, vp, i32, vp, vp)
-_rope = _sig("desta_rope", vp, i64, i32, i32, i32, i32, i32, vp, vp, vp, f32, vp, i64, i32, vp, vp)
+_rope = _sig("desta_rope", vp, i64, i32, i32, i32, i32, i32, vp, vp, vp, f32, vp, i64, i32, vp, i32, vp)
 _swiglu_fwd = _sig("desta_swiglu_fwd", vp, vp, i64, i32, vp)
 _swiglu_bwd = _sig("desta_swiglu_bwd", vp, vp, vp, i64, i32, vp)
 _gelu_bwd = _sig("desta_gelu_bwd", vp, vp, vp, i64, vp)
@@ -258,9 +258,9 @@ def colsum(x, rows, cols, ld, out, accumulate=False, tag="ws"):
 
 
 def rope(buf, ld, rows, seq, n_q, n_kv, hd, cos_sin, q_norm_w=None, k_norm_w=None, eps=1e-6, pre_norm=None,
-         ld_pre=0, backward=False, pos_shift=None):
+         ld_pre=0, backward=False, pos_shift=None, s_major_batch=0):
     check(_rope(p(buf), ld, rows, seq, n_q, n_kv, hd, p(cos_sin), p(q_norm_w), p(k_norm_w), eps, p(pre_norm), ld_pre,
-                int(backward), p(pos_shift), stream()), "desta_rope")
+                int(backward), p(pos_shift), s_major_batch, stream()), "desta_rope")
 
 
 def swiglu_fwd(gate_up, act, rows, inter):
@@ -378,17 +378,18 @@ def attention_fwd(d: AttnDesc):
 
 
 def attention_bwd(d: AttnDesc, do, dq, dk=None, dv=None, *, do_rs=None, dq_off=0, dk_off=0, dv_off=0, dq_rs=None,
-                  dk_rs=None, dv_rs=None):
-    """Backward of the attention described by `d` (O and lse filled by forward)."""
+                  dk_rs=None, dv_rs=None, do_bs=None, dq_bs=None, dk_bs=None, dv_bs=None):
+    """Backward of the attention described by `d` (O and lse filled by forward); *_bs override the batch strides
+    (position-major token grids: row stride = batch * width, batch stride = width)."""
     do_rs = do.shape[-1] if do_rs is None else do_rs
     dq_rs = dq.shape[-1] if dq_rs is None else dq_rs
-    d.dO, d.do_row_stride, d.do_batch_stride = p(do), do_rs, d.seq_q * do_rs
-    d.dQ, d.dq_row_stride, d.dq_batch_stride = _elem_ptr(dq, dq_off), dq_rs, d.seq_q * dq_rs
+    d.dO, d.do_row_stride, d.do_batch_stride = p(do), do_rs, (d.seq_q * do_rs if do_bs is None else do_bs)
+    d.dQ, d.dq_row_stride, d.dq_batch_stride = _elem_ptr(dq, dq_off), dq_rs, (d.seq_q * dq_rs if dq_bs is None else dq_bs)
     if dk is not None:
         dk_rs = dk.shape[-1] if dk_rs is None else dk_rs
         dv_rs = dv.shape[-1] if dv_rs is None else dv_rs
-        d.dK, d.dk_row_stride, d.dk_batch_stride = _elem_ptr(dk, dk_off), dk_rs, d.seq_k * dk_rs
-        d.dV, d.dv_row_stride, d.dv_batch_stride = _elem_ptr(dv, dv_off), dv_rs, d.seq_k * dv_rs
+        d.dK, d.dk_row_stride, d.dk_batch_stride = _elem_ptr(dk, dk_off), dk_rs, (d.seq_k * dk_rs if dk_bs is None else dk_bs)
+        d.dV, d.dv_row_stride, d.dv_batch_stride = _elem_ptr(dv, dv_off), dv_rs, (d.seq_k * dv_rs if dv_bs is None else dv_bs)
     else:
         d.dK = d.dV = 0
     ws = scratch(lib.desta_attention_bwd_workspace_floats(d.batch, d.n_q_heads, d.seq_q), do.device, "attn")
@@ -488,13 +489,13 @@ _check_struct_layouts()
 
 
 _scatter = _sig("desta_scatter_rows_bf16", vp, vp, i32, i32, vp, vp)
-_target_rows = _sig("desta_target_rows", vp, i32, i32, vp, vp, vp, vp)
+_target_rows = _sig("desta_target_rows", vp, i32, i32, vp, vp, vp, i32, vp)
 
 
 def scatter_rows(src, idx, rows, hidden, out):
     check(_scatter(p(src), p(idx), rows, hidden, p(out), stream()), "desta_scatter_rows_bf16")
 
 
-def target_rows(labels, batch, seq, idx, compact_labels, count):
+def target_rows(labels, batch, seq, idx, compact_labels, count, s_major=False):
     """Rows with a real shifted target -> idx / compact label layout / device count (see include/desta_hip.h)."""
-    check(_target_rows(p(labels), batch, seq, p(idx), p(compact_labels), p(count), stream()), "desta_target_rows")
+    check(_target_rows(p(labels), batch, seq, p(idx), p(compact_labels), p(count), int(s_major), stream()), "desta_target_rows")

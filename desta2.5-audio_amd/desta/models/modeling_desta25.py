@@ -666,11 +666,11 @@ class CausalLMHIP:
         self.dxa, self.dxb = b16(M, h), b16(M, h)
         self.dgu = b16(M, 2 * self.I)
         self.dqkv = b16(M, self.qkvw)
-        self.datt = b16(M, self.hq * self.hd)
+        self.datt = torch.zeros(M, self.hq * self.hd, dtype=BF16, device=dev)                # rows in front of the first audio span stay 0
 
     def forward(self, x0_filler, B: int, S: int, kv_start: Optional[torch.Tensor], labels: Optional[torch.Tensor], need_grad: bool,
                 pos_shift: Optional[torch.Tensor] = None, cos_sin: Optional[torch.Tensor] = None, last_logits: Optional[torch.Tensor] = None,
-                kv_cache: Optional[List[torch.Tensor]] = None, target_rows=None):
+                kv_cache: Optional[List[torch.Tensor]] = None, target_rows=None, s_major: bool = False):
         """`x0_filler(buf)` writes inputs_embeds [B*S, h] bf16 into buf.  Returns the logits buffer [B*S, Vp].
         Training uses position_ids = arange(S) (H7); generate() passes pos_shift (= -left_pad per sequence, with a
         `cos_sin` table that also covers the new tokens), `last_logits` [B, Vp] to project only the last row, and the
@@ -682,17 +682,27 @@ class CausalLMHIP:
         self.kv_start = kv_start
         scale = self.hd ** -0.5
         cs = self.cos_sin if cos_sin is None else cos_sin
+        # s_major (training): row = s * B + b, so "all positions >= s0" is ONE contiguous row range and the backward can
+        # skip the rows in front of the first audio span; per-sequence kernels then see row stride B*width, batch stride width
+        self.s_major = bool(s_major)
+        smb = B if s_major else 0
+        rsm = B if s_major else 1
         for i, (ly, s) in enumerate(zip(self.layers, self.sv)):
             x = self.xs[i]
             H.rmsnorm_fwd(x, ly["n1"], c.rms_norm_eps, self.hb, s["r1"])
             H.gemm(self.hb, ly["wqkv"], s["qkv"], M, self.qkvw, h, preact=s.get("pre"))
             if kv_cache is None:
-                H.rope(s["qkv"], self.qkvw, M, S, self.hq, self.hkv, self.hd, cs, ly.get("qn"), ly.get("kn"), c.rms_norm_eps, pos_shift=pos_shift)
+                H.rope(s["qkv"], self.qkvw, M, S, self.hq, self.hkv, self.hd, cs, ly.get("qn"), ly.get("kn"), c.rms_norm_eps, pos_shift=pos_shift,
+                       s_major_batch=smb)
             else:
                 H.rope_kv_append(s["qkv"], self.qkvw, M, S, self.hq, self.hkv, self.hd, cs, ly.get("qn"), ly.get("kn"), c.rms_norm_eps,
                                  pos_shift, kv_cache[i], kv_cache[i].stride(0), kv_cache[i].stride(1), 0)
+            aw = self.hq * self.hd
             ad = H.attn_desc(s["qkv"], s["qkv"], s["qkv"], s["att"], s["lse"], batch=B, hq=self.hq, hkv=self.hkv, sq=S, sk=S, hd=self.hd,
-                             scale=scale, causal=True, kv_start=kv_start, q_off=0, k_off=self.hq * self.hd, v_off=(self.hq + self.hkv) * self.hd)
+                             scale=scale, causal=True, kv_start=kv_start, q_off=0, k_off=self.hq * self.hd, v_off=(self.hq + self.hkv) * self.hd,
+                             q_rs=rsm * self.qkvw, k_rs=rsm * self.qkvw, v_rs=rsm * self.qkvw, o_rs=rsm * aw,
+                             q_bs=self.qkvw if s_major else None, k_bs=self.qkvw if s_major else None,
+                             v_bs=self.qkvw if s_major else None, o_bs=aw if s_major else None)
             H.attention_fwd(ad)
             s["ad"] = ad
             H.gemm(s["att"], ly["wo"], s["xm"], M, h, self.hq * self.hd, residual=x)
@@ -714,11 +724,11 @@ class CausalLMHIP:
             idx, lab_c, count_host, ev = target_rows
             ev.synchronize()
             Mc = int(count_host[0])
-            if 0 < Mc < M:
+            if Mc > 0:
                 H.gather_rows(self.hb, idx, Mc, h, self.hbc)
                 H.gemm(self.hbc, self.head, self.logits, Mc, self.V, h, ldc=self.Vp)        # compact logits in rows [0, Mc)
-                self.compact = (idx, lab_c, Mc)
-                return self.logits
+            self.compact = (idx, lab_c, Mc)                                                  # Mc == 0: no target in the batch
+            return self.logits
         H.gemm(self.hb, self.head, self.logits, M, self.V, h, ldc=self.Vp)
         return self.logits
 
@@ -826,36 +836,54 @@ class CausalLMHIP:
         """ForCausalLMLoss on the logits of the last forward; with write_grad the logits buffer becomes dlogits."""
         if getattr(self, "compact", None) is not None:
             idx, lab_c, Mc = self.compact
+            if Mc == 0:
+                self.loss.zero_()                                                            # ForCausalLMLoss of an all-ignored batch
+                return self.loss
             H.causal_lm_loss(self.logits, self.Vp, lab_c, 1, Mc + 1, self.V, self.loss, write_grad=write_grad)
             return self.loss
         H.causal_lm_loss(self.logits, self.Vp, labels, self.B, self.S, self.V, self.loss, write_grad=write_grad)
         return self.loss
 
-    def backward(self) -> torch.Tensor:
-        """dlogits (in self.logits) -> dL/d inputs_embeds [B*S, h] bf16."""
-        c, h, M, S = self.c, self.h, self.M, self.S
+    def backward(self, first_needed_pos: int = 0) -> torch.Tensor:
+        """dlogits (in self.logits) -> dL/d inputs_embeds [B*S, h] bf16.  In the position-major training layout only the rows of
+        positions >= first_needed_pos (the first audio span of the batch) are propagated: the rows in front of it are frozen
+        text embeddings whose gradient nothing consumes (under the causal mask they do not feed any needed row either)."""
+        c, h, M, S, B = self.c, self.h, self.M, self.S, self.B
+        r0 = first_needed_pos * B if self.s_major else 0
+        Mr = M - r0
+        smb = B if self.s_major else 0
         dhb = self.hb
+        if getattr(self, "compact", None) is not None and self.compact[2] == 0:
+            self.dxa.zero_()                                                              # no target: every gradient is zero
+            return self.dxa
         if getattr(self, "compact", None) is not None:
             idx, _, Mc = self.compact
             H.gemm(self.logits, self.headT, self.hbc, Mc, h, self.Vp, ldb=self.Vp)       # d(final norm out) of the target rows
-            dhb.zero_()                                                                   # the other rows have zero gradient
+            dhb[r0:].zero_()                                                              # the other rows have zero gradient
             H.scatter_rows(self.hbc, idx, Mc, h, dhb)
         else:
             H.gemm(self.logits, self.headT, dhb, M, h, self.Vp, ldb=self.Vp)
         dx, other = self.dxa, self.dxb
-        H.rmsnorm_bwd(dhb, self.xs[self.L], self.norm, self.rf, dx)
+        H.rmsnorm_bwd(dhb[r0:], self.xs[self.L][r0:], self.norm, self.rf[r0:], dx[r0:])
+        aw = self.hq * self.hd
         for i in reversed(range(self.L)):
             ly, s = self.layers[i], self.sv[i]
-            H.gemm(dx, ly["wdT"], self.act, M, self.I, h)                                     # d act
-            H.swiglu_bwd(s["gu"], self.act, self.dgu, M, self.I)
-            H.gemm(self.dgu, ly["wguT"], dhb, M, h, 2 * self.I)
-            H.rmsnorm_bwd(dhb, s["xm"], ly["n2"], s["r2"], other, dres=dx)                   # other := d x_mid
-            H.gemm(other, ly["woT"], self.datt, M, self.hq * self.hd, h)
-            H.attention_bwd(s["ad"], self.datt, self.dqkv, self.dqkv, self.dqkv, dq_off=0, dk_off=self.hq * self.hd, dv_off=(self.hq + self.hkv) * self.hd)
+            H.gemm(dx[r0:], ly["wdT"], self.act[r0:], Mr, self.I, h)                          # d act
+            H.swiglu_bwd(s["gu"][r0:], self.act[r0:], self.dgu[r0:], Mr, self.I)
+            H.gemm(self.dgu[r0:], ly["wguT"], dhb[r0:], Mr, h, 2 * self.I)
+            H.rmsnorm_bwd(dhb[r0:], s["xm"][r0:], ly["n2"], s["r2"][r0:], other[r0:], dres=dx[r0:])   # other := d x_mid
+            H.gemm(other[r0:], ly["woT"], self.datt[r0:], Mr, aw, h)
+            # attention backward runs on the whole grid (rows < r0 of datt stay zero; their dQ / the dK,dV of those keys are unused)
+            if self.s_major:
+                H.attention_bwd(s["ad"], self.datt, self.dqkv, self.dqkv, self.dqkv, dq_off=0, dk_off=aw, dv_off=(self.hq + self.hkv) * self.hd,
+                                do_rs=B * aw, dq_rs=B * self.qkvw, dk_rs=B * self.qkvw, dv_rs=B * self.qkvw,
+                                do_bs=aw, dq_bs=self.qkvw, dk_bs=self.qkvw, dv_bs=self.qkvw)
+            else:
+                H.attention_bwd(s["ad"], self.datt, self.dqkv, self.dqkv, self.dqkv, dq_off=0, dk_off=aw, dv_off=(self.hq + self.hkv) * self.hd)
             H.rope(self.dqkv, self.qkvw, M, S, self.hq, self.hkv, self.hd, self.cos_sin, ly.get("qn"), ly.get("kn"), c.rms_norm_eps,
-                   pre_norm=s.get("pre"), ld_pre=self.qkvw, backward=True)
-            H.gemm(self.dqkv, ly["wqkvT"], dhb, M, h, self.qkvw)
-            H.rmsnorm_bwd(dhb, self.xs[i], ly["n1"], s["r1"], dx, dres=other)                # dx := d x_in
+                   pre_norm=s.get("pre"), ld_pre=self.qkvw, backward=True, s_major_batch=smb)
+            H.gemm(self.dqkv[r0:], ly["wqkvT"], dhb[r0:], Mr, h, self.qkvw)
+            H.rmsnorm_bwd(dhb[r0:], self.xs[i][r0:], ly["n1"], s["r1"][r0:], dx[r0:], dres=other[r0:])   # dx := d x_in
         return dx
 
 
@@ -1030,10 +1058,14 @@ class DeSTA25AudioModel:
             def fill(buf):
                 H.embed_gather(self.llm.embed, af, src, B * S, h, buf)
             target_rows = None
+            s_major = False
             if (labels is not None and self.training and N_audio > 0 and not kwargs.get("keep_logits", False)
                     and self.compact_lm_head):
-                target_rows = self._target_rows(labels, B, S)
-            logits = self.llm.forward(fill, B, S, kv_start, labels, self.training, target_rows=target_rows)
+                # training fast path: position-major token grid (row = s * B + b) + lm_head on the target rows only
+                s_major = True
+                src = src.view(B, S).t().contiguous().view(-1)
+                target_rows = self._target_rows(labels, B, S, s_major=True)
+            logits = self.llm.forward(fill, B, S, kv_start, labels, self.training, target_rows=target_rows, s_major=s_major)
             V = cfg.llm_config.vocab_size
             out_logits = logits.view(B, S, self.llm.Vp)[:, :, :V]
             loss = None
@@ -1050,7 +1082,7 @@ class DeSTA25AudioModel:
                 loss = self.llm.loss_and_grad(labels, write_grad=need_grad).clone().view(())
             # audio rows of inputs_embeds, for the backward gather
             self._fwd = dict(B=B, S=S, N_audio=N_audio, starts=[(int(r), int(s)) for r, s in batch_start_positions],
-                             has_grad=labels is not None and self.training and N_audio > 0)
+                             has_grad=labels is not None and self.training and N_audio > 0, s_major=s_major)
         return _Out(loss, out_logits)
 
     __call__ = forward
@@ -1114,7 +1146,7 @@ class DeSTA25AudioModel:
         raise NotImplementedError("chat-level generate() (tokenizer + audio-file front end) is out of scope of the MI355X hot path; "
                                   "use _generate_step(inputs, pad_token_id, do_sample=False, max_new_tokens=…) on a collated batch")
 
-    def _target_rows(self, labels, B: int, S: int):
+    def _target_rows(self, labels, B: int, S: int, s_major: bool = False):
         """Index list / compact labels / host-visible count of the rows that carry a target, on a side stream: it waits for
         the main stream's current position (the producer of `labels`), runs one tiny kernel and copies the count to pinned
         memory; the main stream's later work is not involved, so synchronising on the event at lm_head time does not drain it."""
@@ -1132,7 +1164,7 @@ class DeSTA25AudioModel:
         self._tr_labels_keep = lab_dev                                           # alive until the side stream has read it
         self._tr_stream.wait_stream(main)
         with torch.cuda.stream(self._tr_stream):
-            H.target_rows(lab_dev, B, S, self._tr_idx, self._tr_lab, self._tr_count)
+            H.target_rows(lab_dev, B, S, self._tr_idx, self._tr_lab, self._tr_count, s_major=s_major)
             self._tr_count_host.copy_(self._tr_count, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self._tr_stream)
@@ -1156,10 +1188,14 @@ class DeSTA25AudioModel:
         f = self._fwd
         if not f or not f["has_grad"]:
             raise RuntimeError("backward() needs a training-mode forward with labels and at least one audio")
-        K, S = self.config.prompt_size, f["S"]
+        K, S, B = self.config.prompt_size, f["S"], f["B"]
         with torch.cuda.device(self.device):
-            dx0 = self.llm.backward()
-            idx = torch.cat([torch.arange(r * S + s, r * S + s + K, dtype=torch.int32) for r, s in f["starts"]]).to(self.device)
+            if f["s_major"]:
+                dx0 = self.llm.backward(first_needed_pos=min(s for _, s in f["starts"]))
+                idx = torch.cat([torch.arange(s, s + K, dtype=torch.int32) * B + r for r, s in f["starts"]]).to(self.device)
+            else:
+                dx0 = self.llm.backward()
+                idx = torch.cat([torch.arange(r * S + s, r * S + s + K, dtype=torch.int32) for r, s in f["starts"]]).to(self.device)
             d_af = torch.empty(f["N_audio"] * K, self.config.llm_config.hidden_size, dtype=BF16, device=self.device)
             H.gather_rows(dx0, idx, f["N_audio"] * K, self.config.llm_config.hidden_size, d_af)
             self.connector.backward(d_af)

@@ -163,10 +163,12 @@ int desta_colsum_bf16(const void* x, int rows, int cols, int64_t ld, float* out,
  * runs first (forward) / is differentiated (backward, needs the saved pre-norm q|k in pre_norm).
  * backward != 0 applies the transposed rotation to gradients. head_dim 64 or 128.
  * pos_shift (int32 [rows/seq] or NULL): position = max(0, row % seq + pos_shift[row / seq]) — generate() derives
- * position_ids from the attention mask (prompt: -left_pad; decode step: cache_len - left_pad). */
+ * position_ids from the attention mask (prompt: -left_pad; decode step: cache_len - left_pad).
+ * s_major_batch > 0: the token grid is stored position-major (row = s * s_major_batch + b) instead of batch-major
+ * (row = b * seq + s) — the training layout, in which "all positions >= s0" is one contiguous row range. */
 int desta_rope(void* buf, int64_t ld, int rows, int seq, int n_q_heads, int n_kv_heads, int head_dim,
                const float* cos_sin, const float* q_norm_w, const float* k_norm_w, float eps,
-               const void* pre_norm, int64_t ld_pre, int backward, const int32_t* pos_shift, void* stream);
+               const void* pre_norm, int64_t ld_pre, int backward, const int32_t* pos_shift, int s_major_batch, void* stream);
 
 /* SwiGLU on a fused [rows, 2*inter] gate|up buffer (LlamaMLP, TF:models/llama/modeling_llama.py:163-176),
  * GELU'(erf) for the Q-Former FFN backward, and small layout helpers. */
@@ -265,7 +267,7 @@ int desta_dropout_mask_u8(uint64_t seed, int64_t n, float p, uint8_t* out, void*
  * [n + 1, vocab] logits buffer then gives the same loss / gradients as the full grid.  desta_scatter_rows_bf16 is the
  * inverse of desta_gather_rows_bf16 (out[idx[i]] = in[i]). */
 int desta_target_rows(const int64_t* labels, int batch, int seq, int32_t* idx, int64_t* compact_labels, int32_t* count,
-                      void* stream);
+                      int s_major, void* stream);   /* s_major != 0: idx holds position-major row ids s * batch + b */
 int desta_scatter_rows_bf16(const void* in, const int32_t* idx, int rows, int hidden, void* out, void* stream);
 
 /* Greedy decoding helper: out[r] = argmax over the first `cols` entries of bf16 row r (first maximum, two-stage

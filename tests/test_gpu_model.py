@@ -370,14 +370,21 @@ def test_compact_lm_head_equals_full_grid(golden_dir, name):
         model.mark_weights_updated()
         out = model(**batch)
         assert out.logits is None
-        assert (model.llm.compact is not None) == compact
+        assert (model.llm.compact is not None) == compact and model.llm.s_major == compact
         model.backward()
         res[compact] = (float(out.loss), model.arena.grads.clone())
     assert abs(res[True][0] - res[False][0]) < 1e-6 * max(1.0, abs(res[False][0]))
     a, b = res[True][1].double(), res[False][1].double()
     assert float((a - b).norm() / b.norm()) < 2e-3
     assert abs(res[True][0] - float(g["loss"])) < 2e-2
-    # keep_logits / eval still take the full grid
+    # keep_logits / eval still take the full (batch-major) grid
     model.compact_lm_head = True
     out = model(**batch, keep_logits=True)
-    assert out.logits is not None and model.llm.compact is None
+    assert out.logits is not None and model.llm.compact is None and not model.llm.s_major
+    # a batch without any target: loss 0, all gradients 0 (ForCausalLMLoss of an all-ignored batch)
+    nb = dict(batch)
+    nb["labels"] = torch.full_like(batch["labels"], -100)
+    out = model(**nb)
+    assert float(out.loss) == 0.0
+    model.backward()
+    assert float(model.arena.grads.abs().max()) == 0.0

@@ -488,6 +488,10 @@ def test_target_rows_and_scatter(hip):
     back = torch.zeros_like(full)
     hip.scatter_rows(comp, idx, n, V, back)
     assert torch.equal(back, full)                                  # non-target rows of the full gradient are exactly zero
+    # position-major row ids (s * B + b), same compact order
+    idx_s = torch.full((B * S,), -1, dtype=torch.int32, device="cuda")
+    hip.target_rows(labels.cuda(), B, S, idx_s, lab, cnt, s_major=True)
+    assert idx_s[:n].cpu().tolist() == [(r % S) * B + r // S for r, _ in ref]
     # no targets at all -> count 0
     hip.target_rows(torch.full((B, S), -100).cuda(), B, S, idx, lab, cnt)
     assert int(cnt) == 0 and lab[:2].cpu().tolist() == [-100, -100]
