@@ -388,3 +388,25 @@ def test_compact_lm_head_equals_full_grid(golden_dir, name):
     assert float(out.loss) == 0.0
     model.backward()
     assert float(model.arena.grads.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("name", ["llama", "qwen3"])
+def test_training_fast_path_vs_reference_golden(golden_dir, name):
+    """The training fast path (position-major grid, lm_head on target rows, backward from the first audio span) pinned
+    directly to the reference's own loss and gradients (left-padded rows, different audio starts per sample)."""
+    d = O.tiny_dims(name == "qwen3")
+    g, batch = golden_batch(golden_dir, name)
+    model, w = _model(d)
+    out = model(**batch)
+    assert out.logits is None and model.llm.s_major and model.llm.compact is not None
+    assert abs(float(out.loss) - float(g["loss"])) < 2e-2
+    model.backward()
+    names = model.trainable_parameter_names
+    gn = sorted(float(g["grad::" + n].double().norm()) for n in names)
+    floor = gn[len(gn) // 2] * 1e-2
+    worst = max(float((model.arena.grad(n).double().cpu() - g["grad::" + n].double()).norm() / max(float(g["grad::" + n].double().norm()), floor))
+                for n in names)
+    assert worst < 8e-2, worst
+    a = torch.cat([model.arena.grad(n).reshape(-1).double().cpu() for n in names])
+    b = torch.cat([g["grad::" + n].reshape(-1).double() for n in names])
+    assert float((a @ b) / (a.norm() * b.norm())) > 0.999
