@@ -210,7 +210,12 @@ def main():
                                    f"S={S} ({a.ctx} ctx + {cfg.prompt_size} audio + {a.tgt} target tokens), random-init weights at true shapes",
                        "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}",
                        "step_definition": "one pass of the hot path over one per-GPU batch; value = per-GPU batch-steps per second "
-                                          "summed over the node (N x K / max-over-ranks time), weak scaling"},
+                                          "summed over the node (N x K / max-over-ranks time), weak scaling",
+                       "training_fast_path": ("off (--full-lm-head): lm_head / CE over the whole token grid, backward over every row"
+                                              if a.full_lm_head else
+                                              "on: lm_head / CE on the rows that carry a target, LLM backward from the first audio span "
+                                              "(rows whose logits the loss ignores / whose gradient nothing consumes are not computed; "
+                                              "loss and every parameter gradient identical to the full grid, tests/test_gpu_model.py)")},
             "final_loss": final_loss,
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_256_kernel", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
