@@ -10,8 +10,12 @@ walks the layers in reverse calling the backward kernels, gradients land in the 
 the fused Adafactor and the RCCL all-reduce consume.
 
 Precision policy (== HF autocast(bf16) of the reference, hazard H11): GEMM operands bf16 with fp32
-accumulation; LayerNorm / RMSNorm / softmax / loss statistics fp32; Whisper and LLM residual streams
-bf16; Q-Former residual stream and all trainable parameters / gradients / optimizer state fp32.
+accumulation; LayerNorm / RMSNorm / softmax / loss statistics fp32; the LLM residual stream is bf16 (its
+weights are loaded in bf16, modeling_desta25.py:715); the Whisper and Q-Former residual streams are fp32
+(fp32 weights under autocast: LayerNorm returns fp32 and `fp32 + bf16` promotes, so the reference never
+rounds them — with a bf16 Whisper stream the tap error grew with depth, 0.7e-2 -> 1.2e-2 at layer 31
+against 0.55e-2 flat for the reference's own policy, tests/test_gpu_model.py::test_deep_*); all trainable
+parameters / gradients / optimizer state fp32.
 """
 from __future__ import annotations
 
@@ -266,7 +270,7 @@ class WhisperEncoderHIP:
         self.conv1_b = g("conv1.bias").float().contiguous()
         self.conv2_w = g("conv2.weight").float().permute(0, 2, 1).reshape(self.d, 3 * self.d).to(BF16).contiguous()
         self.conv2_b = g("conv2.bias").float().contiguous()
-        self.pos = g("embed_positions.weight")[: self.T].to(BF16).contiguous()
+        self.pos = g("embed_positions.weight")[: self.T].float().contiguous()          # fp32: added to the fp32 residual stream
         self.layers = []
         for i in range(self.L):
             p = f"layers.{i}."
@@ -287,7 +291,8 @@ class WhisperEncoderHIP:
         self.B = B
         self.melrows = torch.zeros(B, 2 * T + 2, self.Cp, dtype=BF16, device=dev)
         self.h1 = torch.zeros(B, 2 * T + 1, d, dtype=BF16, device=dev)          # row 0 of each clip stays 0 (conv2 left pad)
-        self.x = torch.empty(B * T, d, dtype=BF16, device=dev)
+        # residual stream in fp32 (three rotating buffers: layer input, post-attention, layer output)
+        self.xr = [torch.empty(B * T, d, dtype=F32, device=dev) for _ in range(3)]
         self.hb = torch.empty(B * T, d, dtype=BF16, device=dev)
         self.qkv = torch.empty(B * T, 3 * d, dtype=BF16, device=dev)
         self.att = torch.empty(B * T, d, dtype=BF16, device=dev)
@@ -308,9 +313,9 @@ class WhisperEncoderHIP:
         H.gemm(self.melrows, self.conv1_w, self.h1[:, 1:], 2 * T, d, 3 * self.Cp, lda=self.Cp, ldc=d, bias=self.conv1_b,
                act=1, batch=B, stride_a=(2 * T + 2) * self.Cp, stride_c=(2 * T + 1) * d)
         # conv2 (k3,s2,p1) + GELU + positions
-        H.gemm(self.h1, self.conv2_w, self.x, T, d, 3 * d, lda=2 * d, ldc=d, bias=self.conv2_b, act=1,
+        cur, mid, nxt = self.xr
+        H.gemm(self.h1, self.conv2_w, cur, T, d, 3 * d, lda=2 * d, ldc=d, bias=self.conv2_b, act=1,
                residual=self.pos, ldr=d, stride_r=0, batch=B, stride_a=(2 * T + 1) * d, stride_c=T * d)
-        cur = self.x
         taps = self.cfg.target_layer_ids
         scale = 64 ** -0.5
         for i, ly in enumerate(self.layers):
@@ -319,12 +324,13 @@ class WhisperEncoderHIP:
             ad = H.attn_desc(self.qkv, self.qkv, self.qkv, self.att, None, batch=B, hq=self.heads, hkv=self.heads, sq=T, sk=T,
                              hd=64, scale=scale, q_off=0, k_off=d, v_off=2 * d)
             H.attention_fwd(ad)
-            H.gemm(self.att, ly["wo"], self.x, M, d, d, bias=ly["bo"], residual=cur)
-            H.layernorm_fwd(self.x, ly["ln2_g"], ly["ln2_b"], 1e-5, y16=self.hb)
+            H.gemm(self.att, ly["wo"], mid, M, d, d, bias=ly["bo"], residual=cur)
+            H.layernorm_fwd(mid, ly["ln2_g"], ly["ln2_b"], 1e-5, y16=self.hb)
             H.gemm(self.hb, ly["w1"], self.ff, M, self.ffn, d, bias=ly["b1"], act=1)
-            out = enc_all[taps.index(i)] if i in taps else self.x
-            H.gemm(self.ff, ly["w2"], out, M, d, self.ffn, bias=ly["b2"], residual=self.x)
-            cur = out
+            H.gemm(self.ff, ly["w2"], nxt, M, d, self.ffn, bias=ly["b2"], residual=mid)
+            if i in taps:                                   # the Q-Former's K/V projections read the tapped state as a bf16 operand
+                H.cast_bf16(nxt, enc_all[taps.index(i)], M * d)
+            cur, nxt = nxt, cur
 
 
 # =========================================================================================== Q-Former connector
@@ -1042,7 +1048,10 @@ class DeSTA25AudioModel:
                 nt = len(cfg.target_layer_ids)
                 if self.enc_all is None or self.enc_all.shape[1] != N_audio * e.max_source_positions:
                     self.enc_all = torch.empty(nt, N_audio * e.max_source_positions, e.d_model, dtype=BF16, device=dev)
-                if self._enc_prefetched != (batch_features.data_ptr(), tuple(batch_features.shape)):
+                pf = self._enc_prefetched
+                # hit only for the very tensor OBJECT that was prefetched, unmodified since (a new tensor can reuse a freed
+                # tensor's address and shape, so data_ptr/shape keys can alias a stale encoder output)
+                if not (pf is not None and pf[0] is batch_features and pf[1] == batch_features._version and pf[2] == N_audio):
                     self.encoder.forward(mel, self.enc_all)
                 self._enc_prefetched = None
                 self.connector.p_drop = cfg.qformer_dropout if self.training else 0.0
@@ -1181,7 +1190,7 @@ class DeSTA25AudioModel:
             if self.enc_all is None or self.enc_all.shape[1] != N * e.max_source_positions:
                 self.enc_all = torch.empty(nt, N * e.max_source_positions, e.d_model, dtype=BF16, device=dev)
             self.encoder.forward(mel, self.enc_all)
-        self._enc_prefetched = (batch_features.data_ptr(), tuple(batch_features.shape))
+        self._enc_prefetched = (batch_features, batch_features._version, N)
 
     def backward(self) -> None:
         """Gradients of the last forward's loss w.r.t. every connector tensor -> arena.grads (overwritten)."""

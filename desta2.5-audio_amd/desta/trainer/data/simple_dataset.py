@@ -1,0 +1,239 @@
+"""Producer of the batch layout the hot path consumes.
+
+Host-side mirror of the reference's `desta/trainer/data/simple_dataset.py`:
+
+* `prepare_audio_context_and_start_positions` / `prepare_audio_context_with_start_end_tags` — placeholder expansion of the
+  `<|AUDIO|>` locator (`modeling_desta25.py:99-123`, `simple_dataset.py:42-101`);
+* `BaseCollateFn` — left-padded tokenisation, labels, `start_answer_position`, pad-shifted `batch_start_positions`, the
+  `[1, n]` transcription ids, the context-only copy for evaluation and the `_empty_batch` marker (`:116-301`);
+* `BaseAudioTextDataset` — prompt-only preprocessing of JSONL manifests (`:574-743`), without the HF `datasets` disk cache
+  and the rank-0 lock-file protocol (control plane, out of scope): the manifest is read and preprocessed in memory.
+
+All of it is integer / index / string work on the host; it takes ANY object with the tokenizer call protocol (`__call__`
+with padding / truncation, `tokenize`, `encode`, `convert_tokens_to_string`, `apply_chat_template`, `padding_side`,
+`eos_token`) and any `processor(list_of_waveforms, sampling_rate=16000, return_tensors="pt").input_features`.  The MI355X
+difference is the processor: `desta.utils.audio.HipLogMelProcessor` runs the log-mel kernel on the device instead of the CPU
+`WhisperFeatureExtractor`, and waveforms stay numpy / torch arrays (the reference round-trips them through `tolist()`).
+Bit parity of every integer field against the reference's own class: tests/test_collate.py (fixture made by importing the
+reference, tests/golden/make_collate_golden.py).
+"""
+from __future__ import annotations
+
+import json
+import logging
+import os
+import re
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from ...utils.audio import AudioSegment
+
+START_TAG, END_TAG = "<start_audio>", "<end_audio>"
+
+
+def prepare_audio_context_and_start_positions(token_list: Sequence[str], audio_locator: str, audio_size_list: List[int],
+                                              transcription_size_list: List[int], placeholder_token: str) -> Tuple[List[str], List[int]]:
+    """Every `audio_locator` token becomes audio_size + transcription_size placeholder tokens; the index of the first one
+    is the audio's start position (`modeling_desta25.py:99-123`).  The size lists are consumed front to back."""
+    if len(audio_size_list) != len(transcription_size_list):
+        raise AssertionError(f"audio_size_list and transcription_size_list must have the same length, audio_size_list: "
+                             f"{audio_size_list}, transcription_size_list: {transcription_size_list}")
+    out: List[str] = []
+    starts: List[int] = []
+    k = 0                                                             # locators seen == entries consumed from the FRONT of both lists
+    for tok in token_list:
+        if tok != audio_locator:
+            out.append(tok)
+            continue
+        if k >= len(audio_size_list):
+            raise IndexError("pop from empty list")                   # more locators than audios (what list.pop(0) raises)
+        starts.append(len(out))
+        out += [placeholder_token] * (audio_size_list[k] + transcription_size_list[k])
+        k += 1
+    del audio_size_list[:k], transcription_size_list[:k]              # the reference pops them; callers see the lists shrink
+    return out, starts
+
+
+def prepare_audio_context_with_start_end_tags(text: str, audio_size_list: List[int], transcription_size_list: List[int],
+                                              placeholder_token: str, tokenizer, start_tag: str = START_TAG,
+                                              end_tag: str = END_TAG) -> Tuple[str, List[int]]:
+    """`<start_audio>…<end_audio>` blocks -> placeholder runs (`simple_dataset.py:42-101`)."""
+    blocks = list(re.finditer(re.escape(start_tag) + r".*?" + re.escape(end_tag), text, re.DOTALL))
+    if len(blocks) != len(audio_size_list):
+        logging.warning(f"Audio block count ({len(blocks)}) != audio_size_list ({len(audio_size_list)})")
+    toks: List[str] = []
+    starts: List[int] = []
+    pos = 0
+    n_sized = min(len(audio_size_list), len(transcription_size_list))
+    for j, m in enumerate(blocks):
+        if m.start() > pos:
+            toks += tokenizer.tokenize(text[pos:m.start()], add_special_tokens=False)
+        starts.append(len(toks))
+        if j < n_sized:
+            toks += [placeholder_token] * (audio_size_list[j] + transcription_size_list[j])
+        pos = m.end()
+    if pos < len(text):
+        toks += tokenizer.tokenize(text[pos:], add_special_tokens=False)
+    return tokenizer.convert_tokens_to_string(toks), starts
+
+
+def resolve_audio_filepath(path: str) -> str:
+    """The path itself, or the same stem with `.wav` (`simple_dataset.py:104-114`)."""
+    if os.path.exists(path):
+        return path
+    wav = os.path.splitext(path)[0] + ".wav"
+    if os.path.exists(wav):
+        return wav
+    raise FileNotFoundError(f"Audio file not found: {path}")
+
+
+class BaseCollateFn:
+    """List of preprocessed samples -> the batch dict `DeSTA25AudioModel.forward` / `_generate_step` consume."""
+
+    def __init__(self, data_cfg, tokenizer, processor, audio_loader=None):
+        self.tokenizer, self.processor = tokenizer, processor
+        self.max_seq_length = data_cfg["max_seq_length"] if isinstance(data_cfg, dict) else data_cfg.max_seq_length
+        # `audio` entries are file paths (decoded by desta.utils.audio) or already-decoded waveforms
+        self.audio_loader = audio_loader or (lambda a: AudioSegment.from_file(a, target_sr=16000, channel_selector="average").samples)
+
+    def _tok(self, texts: List[str]):
+        return self.tokenizer(texts, truncation=True, padding="longest", max_length=self.max_seq_length, return_tensors="pt",
+                              return_length=True, add_special_tokens=False)
+
+    def __call__(self, batch: List[Dict[str, Any]]) -> Dict[str, Any]:
+        tok = self.tokenizer
+        assert tok.padding_side == "left", f"padding_side must be left, got {tok.padding_side}"
+        # 1. decode; a sample with any undecodable audio is dropped, an all-bad batch becomes the empty marker
+        kept, waves = [], []
+        for item in batch:
+            ws = []
+            for a in item["processed_audios"]:
+                try:
+                    ws.append(self.audio_loader(a["audio"]))
+                except Exception as e:                                 # noqa: BLE001 (the reference catches everything here)
+                    logging.warning(f"Skipping sample due to audio decode error: {a['audio']} - {e}")
+                    ws = None
+                    break
+            if ws is not None:
+                kept.append(item)
+                waves.append(ws)
+        if not kept:
+            failed = [a.get("audio", "unknown") for item in batch for a in item.get("processed_audios", [])]
+            logging.warning(f"Entire batch skipped due to audio decode errors. Failed paths: {failed[:3]}...")
+            return {"_empty_batch": True}
+        batch = kept
+        # 2. two left-padded tokenisations: context + target (training) and context only (generation)
+        full = self._tok([it["audio_context"] + it["target"] for it in batch])
+        ctx = self._tok([it["audio_context"] for it in batch])
+        ids, mask = full["input_ids"], full["attention_mask"]
+        # 3. index arithmetic, vectorised: pad = padded length - real tokens; the answer starts after pad + context tokens
+        n_ctx_tokens = torch.tensor([len(tok.tokenize(it["audio_context"])) for it in batch], dtype=torch.long)
+        pad = torch.as_tensor(full["length"], dtype=torch.long) - mask.sum(dim=1)
+        ctx_pad = torch.as_tensor(ctx["length"], dtype=torch.long) - ctx["attention_mask"].sum(dim=1)
+        answer_start = pad + n_ctx_tokens
+        col = torch.arange(ids.shape[1]).unsqueeze(0)
+        labels = torch.where(col >= answer_start.unsqueeze(1), ids, torch.full_like(ids, -100))
+        features, starts, ctx_starts, tr_ids = [], [], [], []
+        for i, it in enumerate(batch):
+            features += waves[i]
+            tr_ids += [tok.encode(t, add_special_tokens=False, return_tensors="pt").long() for t in it["transcription_list"]]
+            starts += [(i, s + pad[i]) for s in it["start_positions"]]
+            ctx_starts += [(i, s + ctx_pad[i]) for s in it["start_positions"]]
+        feats = self.processor(features, sampling_rate=16000, return_tensors="pt").input_features
+        assert len(feats) == len(starts) == len(tr_ids), \
+            f"Length mismatch: features={len(feats)}, positions={len(starts)}, transcriptions={len(tr_ids)}"
+        out = {"input_ids": ids, "attention_mask": mask, "labels": labels,
+               "audio_start_answer_positions": list(answer_start.unbind(0)),
+               "batch_features": feats, "batch_transcription_ids": tr_ids, "batch_start_positions": starts,
+               "context_input_ids": ctx["input_ids"], "context_attention_mask": ctx["attention_mask"],
+               "context_batch_start_positions": ctx_starts, "metadata": list(batch)}
+        # optional ORCA prosody side inputs are carried through untouched in shape (zero-filled where a sample has none)
+        if any("f0_energy_global" in it for it in batch):
+            out["f0_energy_global"] = torch.stack([torch.tensor(it["f0_energy_global"], dtype=torch.float32) if "f0_energy_global" in it
+                                                   else torch.zeros(4) for it in batch])
+        if any("f0_energy_local" in it for it in batch):
+            loc = [torch.tensor(it["f0_energy_local"], dtype=torch.float32) if "f0_energy_local" in it else None for it in batch]
+            T = max(t.shape[0] for t in loc if t is not None)
+            out["f0_energy_local"] = torch.stack([torch.zeros(T, 2) if t is None else torch.nn.functional.pad(t, (0, 0, 0, T - t.shape[0]))
+                                                  for t in loc])
+        return out
+
+
+class BaseAudioTextDataset:
+    """JSONL manifests -> preprocessed samples (`audio_context`, `start_positions`, `processed_audios`, `transcription_list`,
+    `target`, `length`).  Training is prompt-only (hazard H9): `messages` / `seed_description` are ignored, the audio locator is
+    appended to the prompt when missing, transcriptions are always "" so an audio span is exactly `prompt_size` tokens."""
+
+    def __init__(self, cfg, data_cfg, tokenizer, processor, records: Optional[List[Dict[str, Any]]] = None):
+        g = (lambda o, k, d=None: (o.get(k, d) if hasattr(o, "get") else getattr(o, k, d)))
+        model_cfg = g(cfg, "model")
+        self.audio_locator, self.placeholder_token = g(model_cfg, "audio_locator"), g(model_cfg, "placeholder_token")
+        con = g(model_cfg, "connector")
+        self.prompt_size, self.connector_mode = g(con, "prompt_size"), g(con, "mode")
+        self.orca_global_num_tokens = g(g(model_cfg, "orca", {}) or {}, "global_num_tokens", 4)
+        self.system_prompt = g(model_cfg, "system_prompt", None)
+        self.data_root = g(data_cfg, "data_root", "")
+        self.tokenizer, self.processor = tokenizer, processor
+        if records is None:
+            paths = g(data_cfg, "manifest_filepaths")
+            records = []
+            for fp in ([paths] if isinstance(paths, str) else list(paths)):
+                logging.info(f"Loading manifest: {fp}")
+                with open(fp) as f:
+                    records += [json.loads(line) for line in f if line.strip()]
+        cols = {k: [r.get(k) for r in records] for k in ("id", "prompt", "response")}
+        cols["prompt"] = [p or "" for p in cols["prompt"]]
+        cols["response"] = [r or "" for r in cols["response"]]
+        pre = self._preprocess_function(cols)
+        n = len(records)
+        rows = [{k: pre[k][i] for k in pre} for i in range(n)]
+        self.dataset = [r for r in rows if r["length"] > 0 and len(r["audio_context"]) > 0 and len(r["processed_audios"]) > 0]
+        logging.info(f"Dataset: {n} samples, {len(self.dataset)} valid, {n - len(self.dataset)} skipped")
+        self.collate_fn = BaseCollateFn(data_cfg=data_cfg, tokenizer=tokenizer, processor=processor)
+
+    def _preprocess_function(self, examples: Dict[str, List]) -> Dict[str, List]:
+        tok = self.tokenizer
+        ids = examples["id"]
+        prompts = examples.get("prompt", [""] * len(ids))
+        n = len(ids)
+        ctxs, starts_l, audios_l, trans_l = [""] * n, [[] for _ in range(n)], [[] for _ in range(n)], [[] for _ in range(n)]
+        block_re = re.compile(re.escape(START_TAG) + r".*?" + re.escape(END_TAG), re.DOTALL)
+        for i, (sid, prompt) in enumerate(zip(ids, prompts)):
+            text = (prompt or "").strip()
+            if not text:
+                continue                                                               # empty prompt: skipped
+            content = text if self.audio_locator in text else f"{text} {self.audio_locator}"
+            messages = ([{"role": "system", "content": self.system_prompt}] if self.system_prompt else [])
+            messages.append({"role": "user", "content": content, "audios": [{"audio": sid, "text": ""}]})
+            ctx = tok.apply_chat_template(messages, tokenize=False, add_generation_prompt=True)
+            try:
+                audios = [{"audio": resolve_audio_filepath(os.path.join(self.data_root, sid)), "text": ""}]
+            except FileNotFoundError:
+                continue                                                               # audio file missing: skipped
+            size = self.orca_global_num_tokens if self.connector_mode == "orca_hybrid" else self.prompt_size
+            sizes, trans = [size] * len(audios), [""] * len(audios)
+            tsizes = [len(tok.tokenize(t, add_special_tokens=False)) for t in trans]
+            if block_re.search(ctx):
+                ctx, st = prepare_audio_context_with_start_end_tags(ctx, sizes, tsizes, self.placeholder_token, tok)
+            elif ctx.count(self.audio_locator) > 0:
+                toks, st = prepare_audio_context_and_start_positions(tok.tokenize(ctx), self.audio_locator, sizes, tsizes, self.placeholder_token)
+                ctx = tok.convert_tokens_to_string(toks)
+            else:
+                continue                                                               # no audio marker survived the template
+            ctxs[i], starts_l[i], audios_l[i], trans_l[i] = ctx, st, audios, trans
+        examples["audio_context"], examples["start_positions"] = ctxs, starts_l
+        examples["transcription_list"], examples["processed_audios"] = trans_l, audios_l
+        targets, lengths = [], []
+        for ctx, resp in zip(ctxs, examples["response"]):
+            ok = bool(ctx) and bool(resp)
+            targets.append(resp + tok.eos_token if ok else "")
+            lengths.append(len(tok.tokenize(ctx + resp)) if ok else 0)
+        examples["target"], examples["length"] = targets, lengths
+        return examples
+
+    def __len__(self) -> int:
+        return len(self.dataset)
+
+    def __getitem__(self, idx: int) -> Dict[str, Any]:
+        return self.dataset[idx]

@@ -42,6 +42,8 @@ class TrainingArguments:
     optim: str = "adafactor"
     bf16: bool = True
     overlap_comm: bool = True
+    save_strategy: str = "no"                      # "epoch" (train_desta.py:146, enable_checkpointing) | "no"
+    steps_per_epoch: Optional[int] = None          # len(train dataloader) when the dataset is not sized (synthetic streams)
 
 
 def allreduce_mean_(flat: torch.Tensor) -> None:
@@ -56,6 +58,28 @@ def allreduce_mean_(flat: torch.Tensor) -> None:
         flat.mul_(1.0 / dist.get_world_size())
 
 
+def steps_per_epoch(args: TrainingArguments, n_samples: Optional[int], world: int) -> Optional[int]:
+    """Optimizer steps per epoch as HF derives them (TF:trainer.py `set_initial_training_values`): len(dataloader) // GA with
+    len(dataloader) = ceil(ceil(N / world) / per_device_batch) (DistributedSampler pads every rank to an equal share)."""
+    if args.steps_per_epoch is not None:
+        return max(1, int(args.steps_per_epoch))
+    if n_samples is None:
+        return None
+    per_rank = math.ceil(n_samples / world)
+    return max(1, math.ceil(per_rank / args.per_device_train_batch_size) // args.gradient_accumulation_steps)
+
+
+def resolve_total_steps(args: TrainingArguments, spe: Optional[int]) -> int:
+    """`num_training_steps` handed to get_linear_schedule_with_warmup: max_steps if positive (it takes precedence over epochs),
+    else ceil(num_train_epochs * steps_per_epoch).  Every shipped full-size YAML uses max_steps: -1 with max_epochs: 5."""
+    if args.max_steps > 0:
+        return int(args.max_steps)
+    if spe is None:
+        raise ValueError("args.max_steps must be set to a positive value if dataloader does not have a length, "
+                         f"was {args.max_steps}")                              # the HF Trainer's own message
+    return max(1, math.ceil(args.num_train_epochs * spe))
+
+
 class DeSTA25Trainer:
     def __init__(self, model: DeSTA25AudioModel, cfg: Any = None, args: Optional[TrainingArguments] = None,
                  train_dataset=None, eval_dataset=None, data_collator=None, processing_class=None, **kwargs):
@@ -68,7 +92,7 @@ class DeSTA25Trainer:
             raise NotImplementedError("gradient_accumulation_steps != 1 (every shipped config uses 1)")
         self.optimizer = FusedAdafactor(model.arena, weight_decay=self.args.weight_decay, max_grad_norm=self.args.max_grad_norm)
         self.global_step = 0
-        self.total_steps = self.args.max_steps if self.args.max_steps > 0 else 10 ** 9
+        self._total_steps: Optional[int] = None
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
         model.dropout_seed = 1 + self.rank                                    # ranks draw different dropout masks (as under DDP)
@@ -76,6 +100,20 @@ class DeSTA25Trainer:
         self._side_done: Optional[torch.cuda.Event] = None
         self._log_buffer: List[Dict[str, Any]] = []
         self.log_history: List[Dict[str, float]] = []
+
+    def steps_per_epoch(self) -> Optional[int]:
+        ds = self.train_dataset
+        return steps_per_epoch(self.args, len(ds) if ds is not None and hasattr(ds, "__len__") else None, self.world)
+
+    @property
+    def total_steps(self) -> int:
+        if self._total_steps is None:
+            self._total_steps = resolve_total_steps(self.args, self.steps_per_epoch())
+        return self._total_steps
+
+    @total_steps.setter
+    def total_steps(self, v: int) -> None:
+        self._total_steps = int(v)
 
     # -- reference surface ---------------------------------------------------------------------
     def _is_empty_batch(self, inputs: Dict[str, Any]) -> bool:
@@ -129,11 +167,21 @@ class DeSTA25Trainer:
         Whisper encoder of `next_inputs`."""
         model = self.model
         model.train()
-        if self._is_empty_batch(inputs):
+        empty = self._is_empty_batch(inputs)
+        if empty and self.world == 1:
+            # HF loop on one device: zero loss, backward leaves every .grad None, Adafactor skips every parameter
+            # (TF:optimization.py:1220), the scheduler and global_step still advance
+            self.global_step += 1
             return self.compute_loss(model, inputs)
         self.wait_update()                                                    # connector weights of step t-1 are final
         loss = self.compute_loss(model, inputs)
-        model.backward()
+        if empty:
+            # data parallel: this rank MUST still enter the flat all-reduce and the optimizer step, or its peers block in the
+            # collective forever and step counts diverge (under DDP the reference deadlocks here).  It contributes zeros: the
+            # update is the mean over ranks with this rank's share empty.
+            model.arena.grads.zero_()
+        else:
+            model.backward()
         self.global_step += 1
         lr = linear_warmup_lr(self.global_step - 1, self.args.learning_rate, self.args.warmup_steps, self.total_steps)
         if self._side is None:
@@ -152,25 +200,62 @@ class DeSTA25Trainer:
                 model.prefetch_encoder(next_inputs["batch_features"])
         return loss
 
-    def train(self, batches: Optional[Iterable[Dict[str, Any]]] = None, max_steps: Optional[int] = None):
-        """Minimal loop over an iterable of collated batches (the HF DataLoader plumbing is out of scope)."""
-        if batches is None:
-            if self.train_dataset is None or self.data_collator is None:
-                raise ValueError("train() needs `batches` or train_dataset + data_collator")
-            bs = self.args.per_device_train_batch_size
-            n = len(self.train_dataset)
-            batches = (self.data_collator([self.train_dataset[i] for i in range(s, min(s + bs, n))]) for s in range(0, n, bs))
-        it = iter(batches)
-        cur = next(it, None)
-        losses = []
-        while cur is not None and (max_steps is None or self.global_step < max_steps):
-            nxt = next(it, None)
-            losses.append(self.training_step(cur, nxt))
-            cur = nxt
+    def train(self, batches: Optional[Iterable[Dict[str, Any]]] = None, max_steps: Optional[int] = None,
+              resume_from_checkpoint: Optional[str] = None):
+        """`batches` given: ONE pass over that iterable of collated batches (tests, benchmarks).  Otherwise the HF loop shape
+        (TF:trainer.py `_inner_training_loop`): epochs over `train_dataset` until `total_steps`, `checkpoint-<step>/` at every
+        epoch end with save_strategy="epoch", and `resume_from_checkpoint` restores parameters / optimizer / schedule / step
+        and skips the batches of the interrupted epoch that were already consumed (`steps_trained_in_current_epoch`)."""
+        if resume_from_checkpoint:
+            self.resume_from_checkpoint(resume_from_checkpoint)
+        if batches is not None:
+            losses = self._train_pass(iter(batches), max_steps)
+        else:
+            if self.train_dataset is None:
+                raise ValueError("train() needs `batches` or train_dataset (+ data_collator)")
+            total = self.total_steps if max_steps is None else min(self.total_steps, max_steps)
+            spe = self.steps_per_epoch()
+            losses = []
+            epoch, skip = (self.global_step // spe, self.global_step % spe) if spe else (0, 0)
+            while self.global_step < total:
+                it = iter(self._epoch_batches(epoch))
+                for _ in range(skip):
+                    if next(it, None) is None:
+                        break
+                skip = 0
+                before = self.global_step
+                losses += self._train_pass(it, total)
+                if self.global_step == before:
+                    break                                                     # empty dataset
+                epoch += 1
+                if self.args.save_strategy == "epoch" and (spe is None or self.global_step % spe == 0 or self.global_step >= total):
+                    self.save_checkpoint(os.path.join(self.args.output_dir, f"checkpoint-{self.global_step}"))
         self.wait_update()
         torch.cuda.synchronize(self.model.device)
+        self.model._enc_prefetched = None                                     # a prefetch for a batch that never ran is void
         self._flush_logs()
         return [float(x) for x in losses]
+
+    def _epoch_batches(self, epoch: int):
+        ds = self.train_dataset
+        if hasattr(ds, "batches"):                                            # streaming dataset that yields collated batches
+            import inspect
+            return ds.batches(epoch) if len(inspect.signature(ds.batches).parameters) >= 1 else ds.batches()
+        if self.data_collator is None:
+            raise ValueError("train() needs a data_collator for a map-style train_dataset")
+        bs, n = self.args.per_device_train_batch_size, len(ds)
+        idx = list(range(self.rank, n, self.world))                           # DistributedSampler(shuffle=False) share
+        return (self.data_collator([ds[i] for i in idx[s:s + bs]]) for s in range(0, len(idx), bs))
+
+    def _train_pass(self, it, max_steps: Optional[int]) -> List[torch.Tensor]:
+        cur = next(it, None) if (max_steps is None or self.global_step < max_steps) else None
+        losses = []
+        while cur is not None:
+            more = max_steps is None or self.global_step + 1 < max_steps
+            nxt = next(it, None) if more else None
+            losses.append(self.training_step(cur, nxt))
+            cur = nxt
+        return losses
 
     # -- evaluation (desta_trainer.py:104-189): eval loss / perplexity + generation through `_generate_step` ----------
     def evaluate(self, eval_batches: Optional[Iterable[Dict[str, Any]]] = None, metric_key_prefix: str = "eval",
@@ -281,10 +366,3 @@ class DeSTA25Trainer:
         self.wait_update()
         if self.rank == 0:
             self.model.save_pretrained(output_dir)
-
-    def save_optimizer(self, output_dir: str) -> None:
-        self.wait_update()
-        if self.rank == 0:
-            os.makedirs(output_dir, exist_ok=True)
-            torch.save(self.optimizer.state_dict(), os.path.join(output_dir, "optimizer.pt"))
-            torch.save({"global_step": self.global_step}, os.path.join(output_dir, "scheduler.pt"))

@@ -9,8 +9,10 @@ Same command line and YAML schema as the reference's examples/train/train_desta.
 Hydra/OmegaConf are not installed here, so the few features the reference uses are restated on plain
 `yaml.safe_load`: `--config-name`, the `+dataset=<group file>` addition, dotted `key=value` overrides and
 the `???` mandatory marker.  `create_model` / `create_training_args` read exactly the keys the reference
-reads (train_desta.py:96-162).  Real manifests + audio file decode are out of scope:
-datasets must be `synthetic: true`.
+reads (train_desta.py:96-162).  Checkpoints are HF `checkpoint-<step>/` directories written at every epoch end
+(save_strategy="epoch", :146) and `resume_from_checkpoint` is handed to `trainer.train` (:231), which restores the
+parameters, Adafactor moments, schedule position and step.  Datasets: `synthetic: true` streams, or a manifest of
+decoded waveforms through `desta.trainer.data.simple_dataset` (audio FILE decode is out of scope).
 """
 import argparse
 import logging
@@ -121,7 +123,12 @@ def create_training_args(cfg: Cfg):
         gradient_accumulation_steps=cfg.trainer.accumulate_grad_batches,
         learning_rate=float(cfg.optim.lr), weight_decay=float(cfg.optim.weight_decay),
         warmup_steps=cfg.optim.sched.warmup_steps, logging_steps=cfg.trainer.log_every_n_steps,
-        max_steps=cfg.trainer.get("max_steps", -1), bf16="bf16" in cfg.trainer.precision, optim="adafactor")
+        max_steps=cfg.trainer.get("max_steps", -1), bf16="bf16" in cfg.trainer.precision, optim="adafactor",
+        save_strategy="epoch" if cfg.trainer.get("enable_checkpointing", False) else "no",
+        overlap_comm=bool(cfg.trainer.get("overlap_comm", True)),
+        # synthetic streams have no len(): every rank draws num_samples // batch_size batches per epoch
+        steps_per_epoch=(cfg.dataset.train_ds.num_samples // cfg.dataset.train_ds.batch_size
+                         if cfg.dataset.train_ds.get("synthetic", False) else None))
 
 
 def load_pretrained_weights(model, path: str) -> None:
@@ -145,13 +152,14 @@ class SyntheticAudioTextDataset:
         if S > data_cfg.max_seq_length:
             raise ValueError(f"sequence {S} exceeds max_seq_length {data_cfg.max_seq_length} (hazard H10)")
 
-    def batches(self):
+    def batches(self, epoch: int = 0):
         from desta import _hip
         from desta.synthetic import synthetic_inputs, synthetic_waveform
         dc, cfgm, dev = self.data_cfg, self.model.config, self.model.device
         for i in range(dc.num_samples // dc.batch_size):
-            b = synthetic_inputs(cfgm, dc.batch_size, dc.context_tokens, dc.target_tokens, dev, seed=1234 + self.rank + 7919 * i)
-            wave = synthetic_waveform(dc.batch_size, dev, seed=1234 + self.rank + 7919 * i)
+            seed = 1234 + self.rank + 7919 * i + 104729 * epoch               # a pure function of (rank, epoch, index): resumable
+            b = synthetic_inputs(cfgm, dc.batch_size, dc.context_tokens, dc.target_tokens, dev, seed=seed)
+            wave = synthetic_waveform(dc.batch_size, dev, seed=seed)
             b["batch_features"] = _hip.logmel(wave, cfgm.encoder_config.num_mel_bins)
             yield b
 
@@ -173,27 +181,21 @@ def main(argv=None):
     model = create_model(cfg, device=f"cuda:{local}")
     if cfg.get("init_from_pretrained_weights"):
         load_pretrained_weights(model, cfg.init_from_pretrained_weights)
-    if cfg.get("resume_from_checkpoint"):
-        from safetensors.torch import load_file
-        model.load_state_dict(load_file(os.path.join(cfg.resume_from_checkpoint, "model.safetensors")), strict=False)
     train_ds = SyntheticAudioTextDataset(cfg, cfg.dataset.train_ds, model, rank)
-    trainer = DeSTA25Trainer(model=model, args=create_training_args(cfg), cfg=cfg)
+    trainer = DeSTA25Trainer(model=model, args=create_training_args(cfg), cfg=cfg, train_dataset=train_ds)
     if rank == 0:
         with open(os.path.join(cfg.exp_dir, "config.yaml"), "w") as f:
             yaml.safe_dump(dict(cfg), f)
         if not cfg.get("resume_from_checkpoint"):
             trainer.save_model(os.path.join(cfg.exp_dir, "checkpoint-initial"))
-    max_steps = cfg.trainer.get("max_steps", -1)
-    for epoch in range(int(cfg.trainer.max_epochs)):
-        losses = trainer.train(train_ds.batches(), max_steps=max_steps if max_steps and max_steps > 0 else None)
-        logging.info(f"epoch {epoch}: {len(losses)} steps, loss {losses[0]:.4f} -> {losses[-1]:.4f}")
-        if cfg.trainer.enable_checkpointing:
-            trainer.save_model(os.path.join(cfg.exp_dir, f"checkpoint-{trainer.global_step}"))
-            trainer.save_optimizer(os.path.join(cfg.exp_dir, f"checkpoint-{trainer.global_step}"))
-        if max_steps and max_steps > 0 and trainer.global_step >= max_steps:
-            break
+    # reference :231 — trainer.train(resume_from_checkpoint=...): parameters, optimizer.pt, scheduler.pt, step
+    losses = trainer.train(resume_from_checkpoint=cfg.get("resume_from_checkpoint") or None)
+    if losses:
+        logging.info(f"{len(losses)} steps (global step {trainer.global_step} of {trainer.total_steps}), "
+                     f"loss {losses[0]:.4f} -> {losses[-1]:.4f}")
     if world > 1:
         dist.destroy_process_group()
+    return trainer
 
 
 if __name__ == "__main__":

@@ -44,6 +44,55 @@ import torch
 import torch.nn.functional as F
 
 Tensor = torch.Tensor
+BF16 = torch.bfloat16
+
+# ----------------------------------------------------------------------------- precision policy
+# fp32 (default): every op in fp32 — the goldens produced by the reference's code are fp32 as well.
+# autocast_bf16(): the CASTING POLICY of ``torch.autocast("cuda", dtype=torch.bfloat16)`` restated by hand, which is
+# what HF Trainer(bf16=True) wraps ``compute_loss`` in (``TF:trainer.py:1930``, hazard H11): linear / matmul / conv
+# run on bf16 operands and return bf16, layer_norm and softmax run in fp32 and return fp32, everything else follows
+# type promotion (fp32 + bf16 -> fp32).  LLM weights are stored in bf16 (``modeling_desta25.py:715``), so its whole
+# residual stream is bf16; Whisper / Q-Former weights are fp32, so their residual streams stay fp32.  CPU autocast has
+# a different op list (softmax stays bf16 there), hence the explicit restatement instead of torch.autocast("cpu").
+_AC = False
+
+
+class autocast_bf16:
+    def __enter__(self):
+        global _AC
+        self._prev, _AC = _AC, True
+        return self
+
+    def __exit__(self, *exc):
+        global _AC
+        _AC = self._prev
+        return False
+
+
+def _lin(x, w, b=None):
+    if _AC:
+        return F.linear(x.to(BF16), w.to(BF16), None if b is None else b.to(BF16))
+    return F.linear(x, w, b)
+
+
+def _mm(a, b):
+    if _AC:
+        return a.to(BF16) @ b.to(BF16)
+    return a @ b
+
+
+def _conv1d(x, w, b, **kw):
+    if _AC:
+        return F.conv1d(x.to(BF16), w.to(BF16), b.to(BF16), **kw)
+    return F.conv1d(x, w, b, **kw)
+
+
+def _ln(x, n, g, b, eps):
+    return F.layer_norm(x.float(), (n,), g.float(), b.float(), eps)
+
+
+def _softmax(s):
+    return torch.softmax(s.float(), dim=-1)
 
 
 # ----------------------------------------------------------------------------- dims
@@ -90,6 +139,23 @@ def tiny_dims(qwen3: bool = False) -> Dims:
                 rope_theta=1e6 if qwen3 else 500000.0,
                 rope_llama3=None if qwen3 else (8.0, 1.0, 4.0, 64),
                 qk_norm=qwen3, tie_embeddings=False)
+
+
+def deep_dims(qwen3: bool = False) -> Dims:
+    """Tiny WIDTH at the reference's real DEPTH: 32 encoder layers tapped at 7/15/23/31 (whisper-large-v3[-turbo],
+    modeling_desta25.py:140-143), Q-Former 6L (every shipped *_Qformer6L.yaml), 32 (Llama-3.1-8B) or 36 (Qwen3-4B/8B)
+    decoder layers — pins how the bf16-vs-fp32 error grows with depth."""
+    d = tiny_dims(qwen3)
+    d.enc_layers, d.taps, d.qf_layers, d.llm_layers = 32, (7, 15, 23, 31), 6, (36 if qwen3 else 32)
+    return d
+
+
+def tied_dims() -> Dims:
+    """Qwen3-4B-like head geometry at tiny width: Hq*hd (512) != hidden (320), q/k-norm, TIED lm_head
+    (examples/train/config/desta25_qwen3-4B_Qformer6L.yaml; modeling_desta25.py:638 of the product)."""
+    d = tiny_dims(True)
+    d.llm_h, d.llm_hq, d.llm_hkv, d.llm_hd, d.tie_embeddings = 320, 4, 2, 128, True
+    return d
 
 
 ENC = "perception.whisper.model.encoder."
@@ -164,7 +230,8 @@ def init_weights(d: Dims, seed: int = 0, scale: float = 1.0) -> Dict[str, Tensor
     ln(CON + "proj.0", d.enc_d)
     lin(CON + "proj.1", d.llm_h, d.enc_d)
     # LLM
-    w[LLM + "model.embed_tokens.weight"] = 0.5 * torch.randn(d.vocab, d.llm_h, generator=g)
+    # tied: the same matrix is the lm_head, so keep the logits O(1) (real tied checkpoints have std ~0.02-0.05)
+    w[LLM + "model.embed_tokens.weight"] = (0.06 if d.tie_embeddings else 0.5) * torch.randn(d.vocab, d.llm_h, generator=g)
     for i in range(d.llm_layers):
         p = f"{LLM}model.layers.{i}."
         ln(p + "input_layernorm", d.llm_h, bias=False)
@@ -250,13 +317,13 @@ def _mha(q, k, v, heads, scale_q: Optional[float] = None, scale_s: Optional[floa
     v = v.view(B, Sk, heads, hd).transpose(1, 2)
     if scale_q is not None:
         q = q * scale_q
-    s = q @ k.transpose(-1, -2)
+    s = _mm(q, k.transpose(-1, -2))
     if scale_s is not None:
         s = s * scale_s
     if mask is not None:
         s = s + mask
-    p = torch.softmax(s, dim=-1)
-    o = p @ v
+    p = _softmax(s)
+    o = _mm(p, v)
     return o.transpose(1, 2).reshape(B, Sq, D)
 
 
@@ -264,8 +331,8 @@ def whisper_stem(w, d: Dims, mel: Tensor) -> Tensor:
     if mel.shape[-1] != 2 * d.enc_T:
         raise ValueError(f"Whisper expects the mel input features to be of length {2 * d.enc_T}, "
                          f"but found {mel.shape[-1]}.")
-    x = F.gelu(F.conv1d(mel, w[ENC + "conv1.weight"], w[ENC + "conv1.bias"], padding=1))
-    x = F.gelu(F.conv1d(x, w[ENC + "conv2.weight"], w[ENC + "conv2.bias"], stride=2, padding=1))
+    x = F.gelu(_conv1d(mel, w[ENC + "conv1.weight"], w[ENC + "conv1.bias"], padding=1))
+    x = F.gelu(_conv1d(x, w[ENC + "conv2.weight"], w[ENC + "conv2.bias"], stride=2, padding=1))
     x = x.permute(0, 2, 1)
     return x + w[ENC + "embed_positions.weight"][: d.enc_T]
 
@@ -273,15 +340,15 @@ def whisper_stem(w, d: Dims, mel: Tensor) -> Tensor:
 def whisper_layer(w, d: Dims, i: int, x: Tensor) -> Tensor:
     p = f"{ENC}layers.{i}."
     hd = d.enc_d // d.enc_heads
-    h = F.layer_norm(x, (d.enc_d,), w[p + "self_attn_layer_norm.weight"], w[p + "self_attn_layer_norm.bias"], 1e-5)
-    q = F.linear(h, w[p + "self_attn.q_proj.weight"], w[p + "self_attn.q_proj.bias"])
-    k = F.linear(h, w[p + "self_attn.k_proj.weight"])                  # no bias (H6)
-    v = F.linear(h, w[p + "self_attn.v_proj.weight"], w[p + "self_attn.v_proj.bias"])
+    h = _ln(x, d.enc_d, w[p + "self_attn_layer_norm.weight"], w[p + "self_attn_layer_norm.bias"], 1e-5)
+    q = _lin(h, w[p + "self_attn.q_proj.weight"], w[p + "self_attn.q_proj.bias"])
+    k = _lin(h, w[p + "self_attn.k_proj.weight"])                      # no bias (H6)
+    v = _lin(h, w[p + "self_attn.v_proj.weight"], w[p + "self_attn.v_proj.bias"])
     a = _mha(q, k, v, d.enc_heads, scale_q=hd ** -0.5)                 # q scaled before QK^T (H6)
-    x = x + F.linear(a, w[p + "self_attn.out_proj.weight"], w[p + "self_attn.out_proj.bias"])
-    h = F.layer_norm(x, (d.enc_d,), w[p + "final_layer_norm.weight"], w[p + "final_layer_norm.bias"], 1e-5)
-    h = F.gelu(F.linear(h, w[p + "fc1.weight"], w[p + "fc1.bias"]))
-    return x + F.linear(h, w[p + "fc2.weight"], w[p + "fc2.bias"])
+    x = x + _lin(a, w[p + "self_attn.out_proj.weight"], w[p + "self_attn.out_proj.bias"])
+    h = _ln(x, d.enc_d, w[p + "final_layer_norm.weight"], w[p + "final_layer_norm.bias"], 1e-5)
+    h = F.gelu(_lin(h, w[p + "fc1.weight"], w[p + "fc1.bias"]))
+    return x + _lin(h, w[p + "fc2.weight"], w[p + "fc2.bias"])
 
 
 def whisper_taps(w, d: Dims, mel: Tensor) -> List[Tensor]:
@@ -298,21 +365,21 @@ def whisper_taps(w, d: Dims, mel: Tensor) -> List[Tensor]:
 # ----------------------------------------------------------------------------- Q-Former (A5, A6)
 def _bert_attn_block(w, p, d: Dims, x: Tensor, kv: Tensor) -> Tensor:
     hd = d.enc_d // d.qf_heads
-    q = F.linear(x, w[p + "self.query.weight"], w[p + "self.query.bias"])
-    k = F.linear(kv, w[p + "self.key.weight"], w[p + "self.key.bias"])
-    v = F.linear(kv, w[p + "self.value.weight"], w[p + "self.value.bias"])
+    q = _lin(x, w[p + "self.query.weight"], w[p + "self.query.bias"])
+    k = _lin(kv, w[p + "self.key.weight"], w[p + "self.key.bias"])
+    v = _lin(kv, w[p + "self.value.weight"], w[p + "self.value.bias"])
     a = _mha(q, k, v, d.qf_heads, scale_s=1.0 / math.sqrt(hd))        # bidirectional / unmasked (H5)
-    o = F.linear(a, w[p + "output.dense.weight"], w[p + "output.dense.bias"])
-    return F.layer_norm(o + x, (d.enc_d,), w[p + "output.LayerNorm.weight"], w[p + "output.LayerNorm.bias"], 1e-12)
+    o = _lin(a, w[p + "output.dense.weight"], w[p + "output.dense.bias"])
+    return _ln(o + x, d.enc_d, w[p + "output.LayerNorm.weight"], w[p + "output.LayerNorm.bias"], 1e-12)
 
 
 def qformer_layer(w, d: Dims, i: int, x: Tensor, enc: Tensor) -> Tensor:
     p = f"{CON}qformer.layer.{i}."
     x = _bert_attn_block(w, p + "attention.", d, x, x)
     x = _bert_attn_block(w, p + "crossattention.", d, x, enc)
-    h = F.gelu(F.linear(x, w[p + "intermediate.dense.weight"], w[p + "intermediate.dense.bias"]))
-    o = F.linear(h, w[p + "output.dense.weight"], w[p + "output.dense.bias"])
-    return F.layer_norm(o + x, (d.enc_d,), w[p + "output.LayerNorm.weight"], w[p + "output.LayerNorm.bias"], 1e-12)
+    h = F.gelu(_lin(x, w[p + "intermediate.dense.weight"], w[p + "intermediate.dense.bias"]))
+    o = _lin(h, w[p + "output.dense.weight"], w[p + "output.dense.bias"])
+    return _ln(o + x, d.enc_d, w[p + "output.LayerNorm.weight"], w[p + "output.LayerNorm.bias"], 1e-12)
 
 
 def qformer(w, d: Dims, j: int, enc: Tensor) -> Tensor:
@@ -327,8 +394,8 @@ def mix_proj(w, d: Dims, tap_outs: List[Tensor]) -> Tensor:
     x = torch.stack(tap_outs, dim=0).permute(1, 2, 0, 3)              # [B, K, taps, d]
     nw = torch.softmax(w[CON + "layer_weights"], dim=-1).unsqueeze(-1)
     x = (x * nw).sum(dim=2)
-    x = F.layer_norm(x, (d.enc_d,), w[CON + "proj.0.weight"], w[CON + "proj.0.bias"], 1e-5)
-    return F.linear(x, w[CON + "proj.1.weight"], w[CON + "proj.1.bias"])
+    x = _ln(x, d.enc_d, w[CON + "proj.0.weight"], w[CON + "proj.0.bias"], 1e-5)
+    return _lin(x, w[CON + "proj.1.weight"], w[CON + "proj.1.bias"])
 
 
 def perception(w, d: Dims, mel: Tensor, keep: Optional[dict] = None) -> Tensor:
@@ -344,6 +411,8 @@ def perception(w, d: Dims, mel: Tensor, keep: Optional[dict] = None) -> Tensor:
 def embed_splice(w, d: Dims, input_ids: Tensor, audio_features: Optional[Tensor],
                  batch_transcription_ids: List[Tensor], batch_start_positions: List[Tuple[int, int]]) -> Tensor:
     emb = w[LLM + "model.embed_tokens.weight"]
+    if _AC:
+        emb = emb.to(BF16)                                             # the LLM is loaded in bf16 (modeling_desta25.py:715)
     x = F.embedding(input_ids, emb)
     if audio_features is None or len(batch_start_positions) == 0:
         return x
@@ -355,7 +424,7 @@ def embed_splice(w, d: Dims, input_ids: Tensor, audio_features: Optional[Tensor]
         seg = torch.cat([audio_features[a], tr], dim=0)
         assert seg.shape[0] == d.prompt_size + tr.shape[0]
         idx = torch.arange(start, start + seg.shape[0])
-        out = out.index_put((torch.tensor(int(row)), idx), seg)
+        out = out.index_put((torch.tensor(int(row)), idx), seg.to(out.dtype))
     return out
 
 
@@ -377,7 +446,7 @@ def rope_inv_freq(d: Dims) -> Tensor:
 
 def _rmsnorm(x, weight, eps):
     v = x.float().pow(2).mean(-1, keepdim=True)
-    return weight * (x.float() * torch.rsqrt(v + eps)).to(x.dtype)
+    return weight.to(x.dtype) * (x.float() * torch.rsqrt(v + eps)).to(x.dtype)     # bf16 weight * bf16 under autocast_bf16
 
 
 def _rot_half(x):
@@ -400,17 +469,19 @@ def llm_forward(w, d: Dims, inputs_embeds: Tensor, attention_mask: Tensor, keep:
         fr = position_ids.float()[:, :, None] * rope_inv_freq(d)[None, None, :]            # [B,S,hd/2]
         cos = torch.cat([fr, fr], -1).cos()[:, None]
         sin = torch.cat([fr, fr], -1).sin()[:, None]
-    neg = torch.finfo(torch.float32).min
+    neg = torch.finfo(BF16 if _AC else torch.float32).min      # HF builds the mask with the model dtype's min
     causal = torch.ones(S, S, dtype=torch.bool).tril()
     allowed = causal[None, None] & attention_mask.bool()[:, None, None, :]
     mask = torch.zeros(B, 1, S, S).masked_fill(~allowed, neg)
+    if _AC:                                   # HF: cos / sin cast to the activations' dtype (TF:…modeling_llama.py:117); mask in model dtype
+        x, cos, sin, mask = x.to(BF16), cos.to(BF16), sin.to(BF16), mask.to(BF16)
     rep = d.llm_hq // d.llm_hkv
     for i in range(d.llm_layers):
         p = f"{LLM}model.layers.{i}."
         h = _rmsnorm(x, w[p + "input_layernorm.weight"], d.rms_eps)
-        q = F.linear(h, w[p + "self_attn.q_proj.weight"]).view(B, S, d.llm_hq, d.llm_hd)
-        k = F.linear(h, w[p + "self_attn.k_proj.weight"]).view(B, S, d.llm_hkv, d.llm_hd)
-        v = F.linear(h, w[p + "self_attn.v_proj.weight"]).view(B, S, d.llm_hkv, d.llm_hd)
+        q = _lin(h, w[p + "self_attn.q_proj.weight"]).view(B, S, d.llm_hq, d.llm_hd)
+        k = _lin(h, w[p + "self_attn.k_proj.weight"]).view(B, S, d.llm_hkv, d.llm_hd)
+        v = _lin(h, w[p + "self_attn.v_proj.weight"]).view(B, S, d.llm_hkv, d.llm_hd)
         if d.qk_norm:
             q = _rmsnorm(q, w[p + "self_attn.q_norm.weight"], d.rms_eps)
             k = _rmsnorm(k, w[p + "self_attn.k_norm.weight"], d.rms_eps)
@@ -419,19 +490,19 @@ def llm_forward(w, d: Dims, inputs_embeds: Tensor, attention_mask: Tensor, keep:
         k = k * cos + _rot_half(k) * sin
         k = k.repeat_interleave(rep, dim=1)
         v = v.repeat_interleave(rep, dim=1)
-        s = (q @ k.transpose(-1, -2)) * (d.llm_hd ** -0.5) + mask
-        a = torch.softmax(s, dim=-1) @ v
+        s = _mm(q, k.transpose(-1, -2)) * (d.llm_hd ** -0.5) + mask
+        a = _mm(_softmax(s).to(q.dtype), v)   # eager_attention_forward: softmax(dtype=float32).to(query.dtype)
         a = a.transpose(1, 2).reshape(B, S, d.llm_hq * d.llm_hd)
-        x = x + F.linear(a, w[p + "self_attn.o_proj.weight"])
+        x = x + _lin(a, w[p + "self_attn.o_proj.weight"])
         h = _rmsnorm(x, w[p + "post_attention_layernorm.weight"], d.rms_eps)
-        g = F.linear(h, w[p + "mlp.gate_proj.weight"])
-        u = F.linear(h, w[p + "mlp.up_proj.weight"])
-        x = x + F.linear(F.silu(g) * u, w[p + "mlp.down_proj.weight"])
+        g = _lin(h, w[p + "mlp.gate_proj.weight"])
+        u = _lin(h, w[p + "mlp.up_proj.weight"])
+        x = x + _lin(F.silu(g) * u, w[p + "mlp.down_proj.weight"])
         if keep is not None:
             keep.setdefault("llm_hidden", []).append(x)
     x = _rmsnorm(x, w[LLM + "model.norm.weight"], d.rms_eps)
     head = w[LLM + "model.embed_tokens.weight"] if d.tie_embeddings else w[LLM + "lm_head.weight"]
-    return F.linear(x, head)
+    return _lin(x, head)
 
 
 def generation_position_ids(attention_mask: Tensor) -> Tensor:
@@ -462,7 +533,7 @@ def greedy_generate(w, d: Dims, inputs_embeds: Tensor, attention_mask: Tensor, m
             unfinished = unfinished & ~torch.isin(nxt, torch.tensor(eos_token_ids)).long()
             if int(unfinished.max()) == 0:
                 break
-        x = torch.cat([x, emb[nxt][:, None]], 1)
+        x = torch.cat([x, emb[nxt][:, None].to(x.dtype)], 1)
         mask = torch.cat([mask, torch.ones(B, 1, dtype=torch.long)], 1)
     return torch.stack(toks, 1), torch.stack(step_logits)
 

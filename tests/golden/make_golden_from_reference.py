@@ -40,7 +40,7 @@ def _stub_missing():
     sys.modules["librosa"].__path__ = []
 
 
-def build_reference_model(d, w):
+def build_reference_model(d, w, encoder_model_id="openai/whisper-tiny"):
     """Assemble the reference classes around local-config HF modules and load weights ``w``."""
     # transformers probes optional packages with find_spec at import: import it BEFORE stubbing
     from transformers import WhisperConfig, WhisperForConditionalGeneration, LlamaConfig, Qwen3Config
@@ -63,7 +63,7 @@ def build_reference_model(d, w):
                               num_hidden_layers=d.llm_layers, num_attention_heads=d.llm_hq,
                               num_key_value_heads=d.llm_hkv, head_dim=d.llm_hd, rms_norm_eps=d.rms_eps,
                               rope_parameters={"rope_type": "default", "rope_theta": d.rope_theta},
-                              tie_word_embeddings=False, attention_bias=False, max_position_embeddings=4096)
+                              tie_word_embeddings=d.tie_embeddings, attention_bias=False, max_position_embeddings=4096)
         llm = Qwen3ForCausalLM(llm_cfg)
     else:
         f, lo, hi, old = d.rope_llama3
@@ -79,7 +79,7 @@ def build_reference_model(d, w):
     llm.config._attn_implementation = "eager"
 
     cfg = types.SimpleNamespace(
-        encoder_model_id="openai/whisper-tiny", llm_model_id="local", connector_mode="qformer_1",
+        encoder_model_id=encoder_model_id, llm_model_id="local", connector_mode="qformer_1",
         qformer_num_hidden_layers=d.qf_layers, prompt_size=d.prompt_size, encoder_config=enc_cfg,
         llm_config=llm_cfg, orca_enabled=False, use_lora=False)
 
@@ -119,6 +119,9 @@ def build_reference_model(d, w):
     model.configure_trainable_parameters()
 
     sd = {k: v for k, v in w.items()}
+    if d.tie_embeddings:                       # tied: lm_head.weight IS embed_tokens.weight (one Parameter, state-dict alias)
+        assert llm.lm_head.weight is llm.model.embed_tokens.weight
+        sd["llm_model.lm_head.weight"] = sd["llm_model.model.embed_tokens.weight"]
     missing, unexpected = torch.nn.Module.load_state_dict(model, sd, strict=False)
     missing = [m for m in missing if "decoder" not in m and "proj_out" not in m and "encoder.layer_norm" not in m]
     assert not missing, missing
@@ -127,20 +130,25 @@ def build_reference_model(d, w):
     return model, M
 
 
-def main():
+def make_case(name, d, encoder_model_id="openai/whisper-tiny", with_generate=True, prefix="ref_tiny_"):
     import desta_oracle as O
     from safetensors.torch import save_file
-
-    for name, d in (("llama", O.tiny_dims(False)), ("qwen3", O.tiny_dims(True))):
+    if True:
         torch.manual_seed(0)
         w = O.init_weights(d, seed=7)
-        model, M = build_reference_model(d, w)
+        model, M = build_reference_model(d, w, encoder_model_id)
         batch = O.synthetic_batch(d, B=2, S_ctx=5, S_tgt=12, seed=11, pad=[3, 0])
         starts = [(b, torch.tensor(s)) for b, s in batch["batch_start_positions"]]
+        # tapped encoder states as the reference's forward_whisper sees them (output of encoder layer i, i in taps)
+        tap_states = {}
+        hooks = [layer.register_forward_hook((lambda i: (lambda mod, inp, out: tap_states.__setitem__(i, (out[0] if isinstance(out, tuple) else out).detach().clone())))(i))
+                 for i, layer in enumerate(model.perception.whisper.model.encoder.layers) if i in d.taps] if not with_generate else []
         out = M.DeSTA25AudioModel.forward(
             model, input_ids=batch["input_ids"], attention_mask=batch["attention_mask"],
             batch_features=batch["batch_features"], batch_transcription_ids=batch["batch_transcription_ids"],
             batch_start_positions=starts, labels=batch["labels"], metadata=None)
+        for h in hooks:
+            h.remove()
         out.loss.backward()
         trainable = sorted(model.trainable_parameter_names)
         assert trainable == sorted(O.trainable_names(d)), set(trainable) ^ set(O.trainable_names(d))
@@ -163,32 +171,54 @@ def main():
                 "input_ids": batch["input_ids"], "attention_mask": batch["attention_mask"],
                 "labels": batch["labels"], "batch_features": batch["batch_features"],
                 "starts": torch.tensor([[b, int(s)] for b, s in batch["batch_start_positions"]]),
-                "conn_states": torch.stack(states), "conn_out": conn_out.contiguous()}
+                "conn_out": conn_out.contiguous()}
+        if with_generate:
+            blob["conn_states"] = torch.stack(states)
+        else:                                   # deep cases: only the tapped states are stored (32 full states would be 3 MB)
+            blob["conn_states"] = torch.stack([states[i] for i in d.taps])
+            blob["tap_states"] = torch.stack([tap_states[i] for i in d.taps]).contiguous()
         for n, gv in grads.items():
             blob["grad::" + n] = gv.contiguous()
-        # greedy generation through the reference's own _generate_step (modeling_desta25.py:1358-1431): the context is
-        # the left-padded prompt up to 3 tokens past the audio span; once without EOS, once with an EOS that row 0
-        # emits as its 4th token (so the finished-row padding / early-stop rules are part of the golden)
-        n_ctx = batch["input_ids"].shape[1] - 12 + 3
-        gen_inputs = {"context_input_ids": batch["input_ids"][:, :n_ctx], "context_attention_mask": batch["attention_mask"][:, :n_ctx],
-                      "context_batch_start_positions": starts, "batch_transcription_ids": batch["batch_transcription_ids"],
-                      "batch_features": batch["batch_features"]}
-        with torch.no_grad():
-            model.llm_model.generation_config.eos_token_id = None
-            gen = model._generate_step(gen_inputs, pad_token_id=0, max_new_tokens=10, do_sample=False)
-            eos = int(gen[0, 3])
-            model.llm_model.generation_config.eos_token_id = eos
-            gen_eos = model._generate_step(gen_inputs, pad_token_id=0, max_new_tokens=10, do_sample=False)
-        assert gen.shape == (2, 10), gen.shape
-        blob["gen_ctx_len"] = torch.tensor([n_ctx])
-        blob["gen_ids"] = gen.contiguous()
-        blob["gen_eos_id"] = torch.tensor([eos])
-        blob["gen_ids_eos"] = gen_eos.contiguous()
-        print(name, "generate:", gen.tolist(), "| eos", eos, "->", gen_eos.tolist())
+        if with_generate:
+            # greedy generation through the reference's own _generate_step (modeling_desta25.py:1358-1431): the context is
+            # the left-padded prompt up to 3 tokens past the audio span; once without EOS, once with an EOS that row 0
+            # emits as its 4th token (so the finished-row padding / early-stop rules are part of the golden)
+            n_ctx = batch["input_ids"].shape[1] - 12 + 3
+            gen_inputs = {"context_input_ids": batch["input_ids"][:, :n_ctx], "context_attention_mask": batch["attention_mask"][:, :n_ctx],
+                          "context_batch_start_positions": starts, "batch_transcription_ids": batch["batch_transcription_ids"],
+                          "batch_features": batch["batch_features"]}
+            with torch.no_grad():
+                model.llm_model.generation_config.eos_token_id = None
+                gen = model._generate_step(gen_inputs, pad_token_id=0, max_new_tokens=10, do_sample=False)
+                eos = int(gen[0, 3])
+                model.llm_model.generation_config.eos_token_id = eos
+                gen_eos = model._generate_step(gen_inputs, pad_token_id=0, max_new_tokens=10, do_sample=False)
+            assert gen.shape == (2, 10), gen.shape
+            blob["gen_ctx_len"] = torch.tensor([n_ctx])
+            blob["gen_ids"] = gen.contiguous()
+            blob["gen_eos_id"] = torch.tensor([eos])
+            blob["gen_ids_eos"] = gen_eos.contiguous()
+            print(name, "generate:", gen.tolist(), "| eos", eos, "->", gen_eos.tolist())
         # only the trainable weights + seed are stored; frozen weights are regenerated from seed 7
-        path = os.path.join(HERE, f"ref_tiny_{name}.safetensors")
+        path = os.path.join(HERE, f"{prefix}{name}.safetensors")
         save_file({k: v.contiguous() for k, v in blob.items()}, path)
         print(name, "loss", float(out.loss), "->", path, os.path.getsize(path) // 1024, "KiB")
+
+
+def main():
+    import desta_oracle as O
+    which = sys.argv[1:] or ["tiny", "deep", "tied"]
+    if "tiny" in which:
+        for name, d in (("llama", O.tiny_dims(False)), ("qwen3", O.tiny_dims(True))):
+            make_case(name, d)
+    if "deep" in which:
+        # the reference's real depth at tiny width: 32 encoder layers tapped at 7/15/23/31, Q-Former 6L, 32 / 36 LLM layers
+        for name, d in (("llama", O.deep_dims(False)), ("qwen3", O.deep_dims(True))):
+            make_case(name, d, encoder_model_id="openai/whisper-large-v3", with_generate=False, prefix="ref_deep_")
+    if "tied" in which:
+        # Qwen3-4B-like: tied lm_head, Hq*hd != hidden, whisper-large-v3-turbo id (taps by name) on a 4-layer stand-in is
+        # not possible (taps 7..31 need 32 layers) -> tiny encoder id
+        make_case("qwen3", O.tied_dims(), with_generate=True, prefix="ref_tied_")
 
 
 if __name__ == "__main__":

@@ -26,7 +26,7 @@ def cfg_from_dims(d: O.Dims, dropout: float = 0.0):
 
 
 def golden_batch(golden_dir, name):
-    g = load_file(os.path.join(golden_dir, f"ref_tiny_{name}.safetensors"))
+    g = load_file(os.path.join(golden_dir, f"{name}.safetensors" if name.startswith("ref_") else f"ref_tiny_{name}.safetensors"))
     n = g["starts"].shape[0]
     batch = {"input_ids": g["input_ids"], "attention_mask": g["attention_mask"], "labels": g["labels"],
              "batch_features": g["batch_features"],
@@ -38,3 +38,73 @@ def golden_batch(golden_dir, name):
 def rel_err(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+# ------------------------------------------------------------------------------------------------ toy tokenizer
+class ToyTokenizer:
+    """Deterministic word-level tokenizer with the slice of the HF tokenizer protocol the reference's collate / dataset code
+    touches (`simple_dataset.py:130-301, 574-743`): left padding, right truncation, `return_length` = padded length, special
+    tokens kept whole.  Used on BOTH sides of the collate parity check: the golden script drives the REFERENCE's BaseCollateFn
+    with it, the tests drive the product's — so only the integer / index logic under test can differ."""
+    padding_side = "left"
+    eos_token = "<|eos|>"
+    pad_token_id = 0
+    eos_token_id = 2
+    _SPLIT = __import__("re").compile(r"<\|[^|\s]*\|>|<[a-z_]+>|[A-Za-z0-9']+|[^\sA-Za-z0-9]")
+
+    def __init__(self, vocab_size: int = 512):
+        self.vocab_size = vocab_size
+        self._fixed = {"<|pad|>": 0, "<|bos|>": 1, "<|eos|>": 2, "<|AUDIO|>": 3, "<|video_pad|>": 4, "<|start|>": 5, "<|end|>": 6}
+
+    def tokenize(self, text, add_special_tokens=False, **kw):
+        return self._SPLIT.findall(text)
+
+    def convert_tokens_to_string(self, tokens):
+        return " ".join(tokens)
+
+    def convert_tokens_to_ids(self, tokens):
+        import zlib
+        one = isinstance(tokens, str)
+        ids = [self._fixed.get(t, 8 + zlib.crc32(t.encode()) % (self.vocab_size - 8)) for t in ([tokens] if one else tokens)]
+        return ids[0] if one else ids
+
+    def encode(self, text, add_special_tokens=False, return_tensors=None, **kw):
+        ids = self.convert_tokens_to_ids(self.tokenize(text))
+        return torch.tensor([ids], dtype=torch.long).reshape(1, len(ids)) if return_tensors == "pt" else ids
+
+    def __call__(self, texts, truncation=False, padding=False, max_length=None, return_tensors=None, return_length=False,
+                 add_special_tokens=False, **kw):
+        rows = [self.encode(t) for t in ([texts] if isinstance(texts, str) else texts)]
+        if truncation and max_length is not None:
+            rows = [r[:max_length] for r in rows]                       # truncation_side = "right"
+        L = max(len(r) for r in rows)
+        ids = torch.full((len(rows), L), self.pad_token_id, dtype=torch.long)
+        am = torch.zeros(len(rows), L, dtype=torch.long)
+        for i, r in enumerate(rows):
+            if r:
+                ids[i, L - len(r):] = torch.tensor(r)
+                am[i, L - len(r):] = 1
+        out = {"input_ids": ids, "attention_mask": am}
+        if return_length:
+            out["length"] = torch.full((len(rows),), L, dtype=torch.long)   # HF: length of each PADDED sequence
+        return out
+
+    def apply_chat_template(self, messages, tokenize=False, add_generation_prompt=True, **kw):
+        s = "".join(f"<|start|>{m['role']}\n{m['content']}<|end|>\n" for m in messages)
+        return s + ("<|start|>assistant\n" if add_generation_prompt else "")
+
+    def batch_decode(self, ids, skip_special_tokens=False):
+        return [" ".join(str(int(t)) for t in row if not (skip_special_tokens and int(t) < 8)) for row in ids]
+
+
+COLLATE_CASES = {
+    # name: (records, batches as index lists, audio keys that fail to decode)
+    "basic": ([dict(id="a.wav", prompt="Describe the audio.", response="A dog barks twice ."),
+               dict(id="b.wav", prompt="What is said? <|AUDIO|> Answer briefly.", response="Hello there , general ."),
+               dict(id="c.wav", prompt="Transcribe", response="one two three four five six seven eight nine ten eleven twelve"),
+               dict(id="d.wav", prompt="", response="skipped: empty prompt"),
+               dict(id="missing.wav", prompt="no file", response="skipped: no audio file"),
+               dict(id="e.wav", prompt="Listen <start_audio>ignored text<end_audio> and answer", response="ok"),
+               dict(id="f.wav", prompt="empty response is skipped", response="")],
+              [[0, 1, 2], [1], [2, 3, 0], [3], [2]], {"c.wav"}),
+}

@@ -1,0 +1,107 @@
+"""CPU: SURVEY §8a row A2 — the product's `BaseAudioTextDataset._preprocess_function` / `BaseCollateFn` produce, bit for bit,
+the integer / index / string fields the REFERENCE's own classes produced on the same records with the same duck-typed tokenizer
+(fixture tests/golden/ref_collate.json, made by tests/golden/make_collate_golden.py importing the reference)."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import COLLATE_CASES, ToyTokenizer
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    with open(os.path.join(golden_dir, "ref_collate.json")) as f:
+        return json.load(f)
+
+
+class StubProcessor:
+    def __call__(self, feats, sampling_rate=None, return_tensors=None):
+        self.calls = getattr(self, "calls", []) + [dict(n=len(feats), lens=[len(f) for f in feats], sampling_rate=sampling_rate)]
+        return types.SimpleNamespace(input_features=torch.zeros(len(feats), 2, 4))
+
+
+def _wave_for(key):
+    import zlib
+    n = 1000 + zlib.crc32(key.encode()) % 500
+    return np.random.default_rng(zlib.crc32(key.encode())).standard_normal(n).astype(np.float32)
+
+
+def _dataset(tmp_path, records, system_prompt):
+    from desta.trainer.data.simple_dataset import BaseAudioTextDataset
+    for r in records:
+        if not r["id"].startswith("missing"):
+            open(os.path.join(tmp_path, r["id"]), "wb").close()
+    cfg = {"model": {"audio_locator": "<|AUDIO|>", "placeholder_token": "<|video_pad|>", "system_prompt": system_prompt,
+                     "connector": {"prompt_size": 64, "mode": "qformer_1"}}}
+    return BaseAudioTextDataset(cfg, {"data_root": str(tmp_path), "max_seq_length": 4096}, ToyTokenizer(), StubProcessor(), records=records)
+
+
+@pytest.mark.parametrize("system", ["no", "yes"])
+def test_preprocess_and_collate_bit_exact_vs_reference(golden, tmp_path, system):
+    from desta.trainer.data.simple_dataset import BaseCollateFn
+    records, batches, bad = COLLATE_CASES["basic"]
+    g = golden[f"basic|system={system}"]
+    ds = _dataset(tmp_path, records, "Focus on the audio clips and instructions." if system == "yes" else None)
+    # preprocessing: every field of every record, including the skipped ones (empty strings / lists, length 0)
+    pre = ds._preprocess_function({k: [r[k] for r in records] for k in ("id", "prompt", "response")})
+    for i, ref in enumerate(g["preprocess"]):
+        for k in ("audio_context", "start_positions", "transcription_list", "target", "length"):
+            assert pre[k][i] == ref[k], (i, k)
+        assert [os.path.basename(a["audio"]) for a in pre["processed_audios"][i]] == ref["processed_audios"], i
+    assert len(ds) == 4                                                       # d (empty prompt), missing.wav, f (empty response) dropped
+
+    def loader(path):
+        key = os.path.basename(path)
+        if key in bad:
+            raise RuntimeError(f"cannot decode {key}")
+        return _wave_for(key)
+    it = iter(g["collate"])
+    for max_len in (4096, 90):
+        coll = BaseCollateFn({"max_seq_length": max_len}, ToyTokenizer(), StubProcessor(), audio_loader=loader)
+        for idx in batches:
+            ref = next(it)
+            assert ref["max_seq_length"] == max_len and ref["items"] == idx
+            b = coll([ds[i] for i in idx])
+            if ref.get("_empty_batch"):
+                assert b == {"_empty_batch": True}
+                continue
+            for k in ("input_ids", "attention_mask", "labels", "context_input_ids", "context_attention_mask"):
+                assert b[k].dtype == torch.long and b[k].tolist() == ref[k], (idx, k)
+            assert [int(x) for x in b["audio_start_answer_positions"]] == ref["audio_start_answer_positions"]
+            assert [[int(i), int(s)] for i, s in b["batch_start_positions"]] == ref["batch_start_positions"]
+            assert [[int(i), int(s)] for i, s in b["context_batch_start_positions"]] == ref["context_batch_start_positions"]
+            assert [list(t.shape) + [str(t.dtype)] for t in b["batch_transcription_ids"]] == ref["batch_transcription_ids"]
+            assert int(b["batch_features"].shape[0]) == ref["n_features"]
+            assert coll.processor.calls[-1] == ref["processor_calls"]      # same waveforms, same order, sampling_rate=16000
+            assert [os.path.basename(m["processed_audios"][0]["audio"]) for m in b["metadata"]] == ref["metadata_ids"]
+            # layout facts the model relies on: left padding, labels = ids from the answer start, -100 elsewhere
+            for r, (row, start) in enumerate(b["batch_start_positions"]):
+                assert (b["input_ids"][row, int(start):int(start) + 64] == 4).all()
+
+
+def test_placeholder_expansion_helper(golden):
+    from desta.trainer.data.simple_dataset import prepare_audio_context_and_start_positions as prep
+    g = golden["prepare_two_audios"]
+    a, t = list(g["sizes"][0]), list(g["sizes"][1])
+    r, st = prep(g["tokens"], "<|AUDIO|>", a, t, "P")
+    assert r == g["result"] and st == g["starts"] and a == [] and t == []     # both lists consumed like pop(0)
+    with pytest.raises(AssertionError, match="must have the same length"):
+        prep(["x"], "<|AUDIO|>", [1], [], "P")
+    with pytest.raises(IndexError):
+        prep(["<|AUDIO|>", "<|AUDIO|>"], "<|AUDIO|>", [1], [0], "P")
+
+
+def test_padding_side_and_missing_audio_errors(tmp_path):
+    from desta.trainer.data.simple_dataset import BaseCollateFn, resolve_audio_filepath
+    tok = ToyTokenizer()
+    tok.padding_side = "right"
+    with pytest.raises(AssertionError, match="padding_side must be left"):
+        BaseCollateFn({"max_seq_length": 8}, tok, StubProcessor())([])
+    open(tmp_path / "x.wav", "wb").close()
+    assert resolve_audio_filepath(str(tmp_path / "x.flac")) == str(tmp_path / "x.wav")   # falls back to the .wav twin
+    with pytest.raises(FileNotFoundError, match="Audio file not found"):
+        resolve_audio_filepath(str(tmp_path / "y.flac"))

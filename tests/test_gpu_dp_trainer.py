@@ -1,0 +1,104 @@
+"""GPU: the data-parallel TRAINER path end to end on one card: two fresh child processes share cuda:0 and
+talk over `gloo` (the driver's box has one GPU; RCCL needs one device per rank).  Each child runs `DeSTA25Trainer.training_step`
+on its own batches with `overlap_comm=True` — side-stream flat all-reduce, fused clip + Adafactor, weight re-cast, next-batch
+Whisper prefetch — with Q-Former dropout ON and, at one step, an `_empty_batch` on rank 1 only (the reference deadlocks there
+under DDP; here the rank contributes zeros and stays in the collective).  Asserted: both ranks end with BIT-IDENTICAL parameters
+and optimizer state, equal bit for bit to a single process that averages the two ranks' gradient arenas itself before one
+optimizer step (accelerate DDP mean-of-means semantics, hazard H8)."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STEPS, EMPTY_AT = 4, (2, 1)                      # rank 1 draws an empty batch at step index 2
+LR, WARM, TOTAL = 1e-3, 2, 10
+
+
+def _setup_paths():
+    for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "desta2.5-audio_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _batches(d, rank):
+    import desta_oracle as O
+    out = []
+    for i in range(STEPS):
+        if (i, rank) == EMPTY_AT:
+            out.append({"_empty_batch": True})
+        else:
+            out.append(O.synthetic_batch(d, B=2, S_ctx=4 + rank, S_tgt=10 + 3 * i, seed=100 + 10 * i + rank, pad=[rank, 0]))
+    return out
+
+
+def _model():
+    import desta_oracle as O
+    from helpers import cfg_from_dims
+    from desta.models.modeling_desta25 import DeSTA25AudioModel
+    d = O.tiny_dims(False)
+    return d, DeSTA25AudioModel(cfg_from_dims(d, dropout=0.1), weights=O.init_weights(d, seed=7))
+
+
+def worker(out_dir):
+    _setup_paths()
+    import torch.distributed as dist
+    rank = int(os.environ["RANK"])
+    dist.init_process_group("gloo", rank=rank, world_size=int(os.environ["WORLD_SIZE"]))
+    from desta.trainer.desta_trainer import DeSTA25Trainer, TrainingArguments
+    d, model = _model()
+    tr = DeSTA25Trainer(model, args=TrainingArguments(learning_rate=LR, warmup_steps=WARM, max_steps=TOTAL, logging_steps=1, overlap_comm=True))
+    assert tr.world == 2 and tr._side is not None and model.dropout_seed == 1 + rank
+    losses = tr.train(_batches(d, rank))
+    assert tr.global_step == STEPS and tr.optimizer.step_count == STEPS
+    torch.save({"params": model.arena.params.cpu(), "state": tr.optimizer.state.cpu(), "losses": losses}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_trainer_bit_identical_and_equals_single_process_mean(tmp_path):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 2000), WORLD_SIZE="2",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", str(tmp_path)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    r0, r1 = (torch.load(tmp_path / f"rank{r}.pt", weights_only=True) for r in range(2))
+    assert torch.equal(r0["params"], r1["params"]), "ranks diverged"
+    assert torch.equal(r0["state"], r1["state"]), "optimizer state diverged across ranks"
+    assert r1["losses"][EMPTY_AT[0]] == 0.0 and all(l > 0 for l in r0["losses"])
+
+    # single process: per step, each rank's gradient arena from its own forward/backward, mean of the two, ONE optimizer step
+    _setup_paths()
+    from desta.optim import FusedAdafactor, linear_warmup_lr
+    d, model = _model()
+    opt = FusedAdafactor(model.arena, weight_decay=0.01, max_grad_norm=1.0)
+    data = [_batches(d, r) for r in range(2)]
+    fwd_count = [0, 0]
+    model.train()
+    for i in range(STEPS):
+        grads = []
+        for r in range(2):
+            if data[r][i].get("_empty_batch"):
+                grads.append(torch.zeros_like(model.arena.grads))
+                continue
+            model.dropout_seed, model._fwd_count = 1 + r, fwd_count[r]          # the dropout stream of that rank at that step
+            out = model(**data[r][i])
+            assert abs(float(out.loss) - (r0, r1)[r]["losses"][i]) == 0.0, (i, r)
+            model.backward()
+            fwd_count[r] += 1
+            grads.append(model.arena.grads.clone())
+        model.arena.grads.copy_(grads[0] + grads[1]).mul_(0.5)                     # gloo: SUM then * 1/world
+        opt.step(linear_warmup_lr(i, LR, WARM, TOTAL))
+        model.connector.refresh_weights()
+    torch.cuda.synchronize()
+    assert torch.equal(model.arena.params.cpu(), r0["params"]), float((model.arena.params.cpu() - r0["params"]).abs().max())
+    assert torch.equal(opt.state.cpu(), r0["state"])
+
+
+if __name__ == "__main__" and len(sys.argv) >= 3 and sys.argv[1] == "--worker":
+    worker(sys.argv[2])

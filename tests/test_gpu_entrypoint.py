@@ -1,0 +1,59 @@
+"""GPU: the entry point end to end — `main([...])` trains the debug config, writes HF `checkpoint-<step>/` directories at
+epoch ends, and `resume_from_checkpoint=` (handed to trainer.train like examples/train/train_desta.py:231 does) continues an
+interrupted run bit for bit: parameters, Adafactor moments, schedule position, step and dropout stream."""
+import importlib.util
+import json
+import os
+
+import pytest
+import torch
+from safetensors.torch import load_file
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _mod():
+    spec = importlib.util.spec_from_file_location("train_desta", os.path.join(ROOT, "examples", "train", "train_desta.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_interrupted_6_plus_6_equals_12_steps_through_main(tmp_path):
+    m = _mod()
+    common = ["--config-name", "desta25_debug", "+dataset=debug", "trainer.max_steps=-1", "trainer.max_epochs=2",
+              "dataset.train_ds.num_samples=12", "optim.sched.warmup_steps=3", "optim.lr=1e-3"]       # 6 steps per epoch, 12 in all
+    a = m.main(common + [f"exp_dir={tmp_path}/a"])
+    assert a.global_step == 12 and a.total_steps == 12
+    for step in (6, 12):
+        d = tmp_path / "a" / f"checkpoint-{step}"
+        assert sorted(os.listdir(d)) == ["config.json", "model.safetensors", "optimizer.pt", "scheduler.pt", "trainer_state.json"]
+    assert os.path.isdir(tmp_path / "a" / "checkpoint-initial")
+    # optimizer.pt is the transformers.Adafactor wire format (two groups, factored moments)
+    sd = torch.load(tmp_path / "a" / "checkpoint-6" / "optimizer.pt", weights_only=True)
+    assert len(sd["param_groups"]) == 2 and sd["state"][0]["step"] == 6 and "exp_avg_sq_row" in sd["state"][0]
+    sched = torch.load(tmp_path / "a" / "checkpoint-6" / "scheduler.pt", weights_only=True)
+    assert sched["last_epoch"] == 6
+    # LR decays linearly to zero over the 12 steps derived from epochs x steps-per-epoch (was constant)
+    assert a.get_last_lr() == 0.0
+    # the "interrupted" run: a fresh process state resumed from the step-6 checkpoint of run A
+    b = m.main(common + [f"exp_dir={tmp_path}/b", f"resume_from_checkpoint={tmp_path}/a/checkpoint-6"])
+    assert b.global_step == 12
+    assert not os.path.isdir(tmp_path / "b" / "checkpoint-initial")              # reference: only when not resuming
+    pa, pb = load_file(tmp_path / "a" / "checkpoint-12" / "model.safetensors"), load_file(tmp_path / "b" / "checkpoint-12" / "model.safetensors")
+    assert pa.keys() == pb.keys()
+    for k in pa:
+        assert torch.equal(pa[k], pb[k]), k
+    oa = torch.load(tmp_path / "a" / "checkpoint-12" / "optimizer.pt", weights_only=True)
+    ob = torch.load(tmp_path / "b" / "checkpoint-12" / "optimizer.pt", weights_only=True)
+    for i in oa["state"]:
+        for k, v in oa["state"][i].items():
+            assert (torch.equal(v, ob["state"][i][k]) if torch.is_tensor(v) else v == ob["state"][i][k]), (i, k)
+    with open(tmp_path / "b" / "checkpoint-12" / "trainer_state.json") as f:
+        assert json.load(f)["global_step"] == 12
+    # the parameters did move between the checkpoints (the comparison above is not vacuous)
+    p6 = load_file(tmp_path / "a" / "checkpoint-6" / "model.safetensors")
+    assert any(not torch.equal(p6[k], pa[k]) for k in pa)
+    with pytest.raises(AssertionError, match="Cannot provide both"):
+        m.main(common + [f"exp_dir={tmp_path}/c", f"resume_from_checkpoint={tmp_path}/a/checkpoint-6", "init_from_pretrained_weights=/x.ckpt"])
