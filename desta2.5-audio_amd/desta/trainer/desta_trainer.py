@@ -100,6 +100,7 @@ class DeSTA25Trainer:
         self._side_done: Optional[torch.cuda.Event] = None
         self._log_buffer: List[Dict[str, Any]] = []
         self.log_history: List[Dict[str, float]] = []
+        self.prediction_step_outputs: List[Dict[str, Any]] = []
 
     def steps_per_epoch(self) -> Optional[int]:
         ds = self.train_dataset

@@ -639,7 +639,7 @@ def linear_warmup_lr(step: int, base_lr: float, warmup: int, total: int) -> floa
 
 
 def train_step(w: Dict[str, Tensor], d: Dims, batch: dict, opt_state: List[dict], lr: float,
-               weight_decay: float = 0.01, max_grad_norm: float = 1.0, keep: Optional[dict] = None):
+               weight_decay: float = 0.01, max_grad_norm: float = 1.0, keep: Optional[dict] = None, autocast: bool = False):
     """One optimiser step in the HF-Trainer order (``TF:trainer.py:1722-1797``):
     forward → loss → backward → clip_grad_norm_(1.0) → Adafactor → (caller steps the schedule)."""
     names = trainable_names(d)
@@ -647,7 +647,11 @@ def train_step(w: Dict[str, Tensor], d: Dims, batch: dict, opt_state: List[dict]
     for p in params:
         p.requires_grad_(True)
         p.grad = None
-    loss, logits = model_forward(w, d, batch, keep)
+    if autocast:                          # HF Trainer(bf16=True): autocast around compute_loss only; optimizer in fp32
+        with autocast_bf16():
+            loss, logits = model_forward(w, d, batch, keep)
+    else:
+        loss, logits = model_forward(w, d, batch, keep)
     loss.backward()
     grads = [p.grad.detach().clone() for p in params]
     for p in params:
