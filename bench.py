@@ -23,6 +23,31 @@ import torch
 import torch.distributed as dist
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md §Chip-level parameters
+HBM_PEAK_GBS = 8000.0               # HBM3E, same guide
+
+
+def cpu_baseline_debug(threads, steps=20):
+    """the debug config (tiny Whisper-like encoder + tiny causal LM, Q-Former 2L) timed FULLY —
+    every step is the whole HF-Trainer-ordered step of the oracle (forward under the autocast(bf16) policy -> loss -> backward ->
+    clip 1.0 -> Adafactor -> schedule) on 30 s clips (3000 mel frames), B = 2, 1 warm-up + `steps` timed steps."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import desta_oracle as O
+    torch.set_num_threads(threads)
+    d = O.tiny_dims(False)
+    d.enc_T = 1500
+    w = O.init_weights(d, seed=0)
+    st = O.adafactor_init([w[n] for n in O.trainable_names(d)])
+    pool = [O.synthetic_batch(d, B=2, S_ctx=8, S_tgt=24, seed=10 + i) for i in range(4)]
+    ts = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        O.train_step(w, d, pool[i % 4], st, O.linear_warmup_lr(i, 1e-4, 5, steps + 1), autocast=True)
+        ts.append(time.perf_counter() - t0)
+    ts = ts[1:]
+    mean = sum(ts) / len(ts)
+    sd = (sum((t - mean) ** 2 for t in ts) / max(1, len(ts) - 1)) ** 0.5
+    return {"value": 1.0 / mean, "unit": "steps/s", "steps": steps, "ms_per_step": 1e3 * mean, "ms_per_step_sd": 1e3 * sd,
+            "precision": "autocast(bf16) policy", "workload": "desta25_debug: B=2 x 30 s clips, S=96, 4-layer d=128 encoder, Q-Former 2L, 2-layer h=256 LM"}
 
 
 def cpu_baseline(cfg, B, S_ctx, S_tgt, threads):
@@ -74,20 +99,64 @@ def cpu_baseline(cfg, B, S_ctx, S_tgt, threads):
     t_l1 = timed(lambda: llm(1))
     t_l0 = timed(lambda: llm(0))
     t_layer, t_head = max(t_l1 - t_l0, 1e-6), t_l0
+    # the same LLM layer under the reference's autocast(bf16) policy (BASELINE.md §3 names it): reported beside fp32; the
+    # FASTER of the two is the baseline (CPU bf16 GEMMs are slower than fp32 without AMX / AVX512-BF16)
+    with O.autocast_bf16():
+        t_l1_ac = timed(lambda: llm(1))
+        t_l0_ac = timed(lambda: llm(0))
+    t_layer_ac = max(t_l1_ac - t_l0_ac, 1e-6)
     nt = len(cfg.target_layer_ids)
     full = B * (t_mel + t_stem + e.encoder_layers * t_enc + nt * cfg.qformer_num_hidden_layers * t_qf
-                + c.num_hidden_layers * t_layer + t_head)
+                + c.num_hidden_layers * min(t_layer, t_layer_ac) + min(t_head, t_l0_ac))
     sample = (f"oracle fp32 on {threads} threads, B=1: log-mel {t_mel:.2f}s, conv stem {t_stem:.2f}s, 1 Whisper layer fwd {t_enc:.2f}s, "
-              f"1 Q-Former layer fwd+bwd on one tap {t_qf:.2f}s, 1 LLM layer fwd+bwd {t_layer:.2f}s, final norm+lm_head+CE fwd+bwd {t_head:.2f}s; "
+              f"1 Q-Former layer fwd+bwd on one tap {t_qf:.2f}s, 1 LLM layer fwd+bwd {t_layer:.2f}s (autocast-bf16 policy: {t_layer_ac:.2f}s), "
+              f"final norm+lm_head+CE fwd+bwd {t_head:.2f}s (autocast {t_l0_ac:.2f}s); the faster precision is used; "
               f"scaled to B={B}, {e.encoder_layers}+{nt}x{cfg.qformer_num_hidden_layers}+{c.num_hidden_layers} layers (optimizer/clip time excluded: <1% of the step)")
+    sample += ("; the one-layer extrapolation is validated by one real full-depth B=1 step (python bench.py --cpu-full-step, "
+               "log committed as profiles/r02_cpu_full_step_B1.log)")
     return {"value": 1.0 / full, "unit": "steps/s", "cores": threads, "kind": "port", "sample": sample}
+
+
+def cpu_full_step(cfg, S_ctx, S_tgt, threads):
+    """One REAL full-depth oracle step at true shapes, B = 1 (32 Whisper + 4 x 6 Q-Former + 32 LLM layers, lm_head, CE, backward,
+    clip, Adafactor), fp32: validates the one-layer extrapolation of `cpu_baseline`.  Minutes of CPU time and ~45 GB of host
+    memory: not part of the default run."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import desta_oracle as O
+    torch.set_num_threads(threads)
+    c, e = cfg.llm_config, cfg.encoder_config
+    sc = c.rope_scaling
+    d = O.Dims(n_mels=e.num_mel_bins, enc_d=e.d_model, enc_layers=e.encoder_layers, enc_heads=e.encoder_attention_heads, enc_ffn=e.encoder_ffn_dim,
+               enc_T=e.max_source_positions, taps=tuple(cfg.target_layer_ids), qf_layers=cfg.qformer_num_hidden_layers,
+               qf_inter=cfg.qformer_intermediate_size, prompt_size=cfg.prompt_size,
+               llm_h=c.hidden_size, llm_layers=c.num_hidden_layers, llm_hq=c.num_attention_heads, llm_hkv=c.num_key_value_heads, llm_hd=c.head_dim,
+               llm_inter=c.intermediate_size, vocab=c.vocab_size, rms_eps=c.rms_norm_eps, rope_theta=c.rope_theta,
+               rope_llama3=(sc["factor"], sc["low_freq_factor"], sc["high_freq_factor"], sc["original_max_position_embeddings"]) if sc else None,
+               qk_norm=c.qk_norm, tie_embeddings=c.tie_word_embeddings)
+    t0 = time.perf_counter()
+    w = O.init_weights(d, seed=0)
+    print(f"[cpu-full-step] weights ({sum(v.numel() for v in w.values()) / 1e9:.2f} B fp32 values) in {time.perf_counter() - t0:.0f}s", flush=True)
+    st = O.adafactor_init([w[n] for n in O.trainable_names(d)])
+    batch = O.synthetic_batch(d, B=1, S_ctx=S_ctx, S_tgt=S_tgt, seed=1)
+    wave = (0.1 * torch.randn(1, 480000)).clamp(-1, 1)
+    ts = []
+    for i in range(2):
+        t0 = time.perf_counter()
+        batch["batch_features"] = O.logmel(wave, d.n_mels)
+        loss, _, _, _ = O.train_step(w, d, batch, st, 1e-4)
+        ts.append(time.perf_counter() - t0)
+        print(f"[cpu-full-step] step {i}: {ts[-1]:.1f}s, loss {float(loss):.4f}", flush=True)
+    return {"seconds_per_sample_step": ts[-1], "first_step_seconds": ts[0], "steps_per_s_at_B8_equivalent": 1.0 / (8 * ts[-1]),
+            "cores": threads, "precision": "fp32"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--cpu-full-step", action="store_true", help="only: one real full-depth B=1 oracle step on the host cores (minutes)")
+    ap.add_argument("--no-kernel-pass", action="store_true", help="skip the untimed per-kernel HBM / attention event pass")
     ap.add_argument("--config", default="desta25_llama31-8B_Qformer6L")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--ctx", type=int, default=64)
@@ -103,6 +172,14 @@ def main():
     ap.add_argument("--gemm-4phase", action="store_true", help="A/B: the 4-phase (16 MFMAs per phase) GEMM schedule")
     ap.add_argument("--full-lm-head", action="store_true", help="A/B: lm_head / CE over the whole token grid, not only the target rows")
     a = ap.parse_args()
+
+    if a.cpu_full_step:                                  # host-only leg, no device involved
+        sys.path.insert(0, os.path.join(ROOT, "desta2.5-audio_amd"))
+        from desta.models.modeling_desta25 import DeSTA25Config
+        from desta.synthetic import FULL_CONFIGS
+        print(json.dumps({"cpu_full_step": cpu_full_step(DeSTA25Config(**FULL_CONFIGS[a.config]), a.ctx, a.tgt,
+                                                         min(len(os.sched_getaffinity(0)), 64)), "config": a.config}))
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -157,13 +234,21 @@ def main():
         b["batch_features"] = H.logmel(waves[i % 2], n_mels)              # A1 runs inside the step
         return b
 
-    def run(nsteps, start):
+    step_events = []
+
+    def run(nsteps, start, mark=False):
         cur = batch(start)
         loss = None
+        if mark:
+            step_events.append(torch.cuda.Event(enable_timing=True))
+            step_events[-1].record()
         for i in range(start, start + nsteps):
             nxt = batch(i + 1)
             loss = trainer.training_step(cur, nxt)
             cur = nxt
+            if mark:                                     # main-stream step boundary (no sync): per-step spread for mean +- sd
+                step_events.append(torch.cuda.Event(enable_timing=True))
+                step_events[-1].record()
         trainer.wait_update()
         return loss
 
@@ -176,10 +261,20 @@ def main():
     fence()
     H.gemm_profile_start()
     t0 = time.perf_counter()
-    loss = run(a.steps, a.warmup)
+    loss = run(a.steps, a.warmup, mark=True)
     fence()
     elapsed = time.perf_counter() - t0
     prof = H.gemm_profile_stop(by_kernel=True)
+    per_step = [x.elapsed_time(y) for x, y in zip(step_events[:-1], step_events[1:])]
+    # untimed extra pass: HIP events around every HBM-bound / attention launch (algorithmic bytes / FLOP per call from the wrappers)
+    kprof, kp_steps = {}, 3
+    if not a.no_kernel_pass:                             # every rank steps (the all-reduce is collective); rank 0 records
+        if rank == 0:
+            H.kernel_profile_start()
+        run(kp_steps, a.warmup + a.steps)
+        if rank == 0:
+            kprof = H.kernel_profile_stop()
+    fence()
     n_launch, flops, gemm_ms = prof.get(2, (0, 0.0, 0.0))                 # the dominant kernel: gemm_bf16_nt_256_kernel
     n_other = sum(v[0] for k, v in prof.items() if k != 2)
     ms_other = sum(v[2] for k, v in prof.items() if k != 2)
@@ -195,15 +290,34 @@ def main():
         # HBM bytes per launch of the dominant kernel: from the separate rocprofv3 --pmc passes of this same
         # command (profiles/, FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes); null if absent
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_c_gemm_hbm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_gemm_hbm_traffic.json")
+        if not os.path.isfile(tpath):
+            tpath = os.path.join(ROOT, "profiles", "r01_c_gemm_hbm_traffic.json")
         if a.config == "desta25_llama31-8B_Qformer6L" and os.path.isfile(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
             traffic = tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"]
+        ms_step = 1e3 * elapsed / a.steps
+        mean_ps = sum(per_step) / max(1, len(per_step))
+        sd_ps = (sum((x - mean_ps) ** 2 for x in per_step) / max(1, len(per_step) - 1)) ** 0.5
+        # executed FLOP per step: every GEMM launch of the timed region (HIP-event records carry 2MNK) + the attention kernels'
+        # MFMA FLOP from the kernel pass (4 Sq Sk D per head forward, x2.5 backward, halved under the causal mask)
+        attn = {t: v for t, v in kprof.items() if t.startswith("attn_")}
+        attn_flop_step = sum(v[1] for v in attn.values()) / kp_steps
+        gemm_flop_step = (flops + flops_other) / a.steps
+        exec_flop = gemm_flop_step + attn_flop_step
+        hbm_kernels = {t: {"calls_per_step": v[0] / kp_steps, "algorithmic_GB_per_step": v[1] / kp_steps / 1e9, "ms_per_step": v[2] / kp_steps,
+                           "GBps": v[1] / (v[2] * 1e-3) / 1e9 if v[2] > 0 else 0.0, "frac_of_hbm_peak": (v[1] / (v[2] * 1e-3) / 1e9 / HBM_PEAK_GBS) if v[2] > 0 else 0.0}
+                       for t, v in sorted(kprof.items()) if not t.startswith("attn_")}
+        attn_kernels = {t: {"calls_per_step": v[0] / kp_steps, "GFLOP_per_call": v[1] / max(v[0], 1) / 1e9, "us_per_call": 1e3 * v[2] / max(v[0], 1),
+                            "TFLOPs": v[1] / (v[2] * 1e-3) / 1e12 if v[2] > 0 else 0.0,
+                            "frac_of_mfma_peak": (v[1] / (v[2] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS) if v[2] > 0 else 0.0}
+                        for t, v in sorted(attn.items())}
         out = {
             "metric": "train steps/sec (node) Whisper-v3+Llama3.1-8B Q-Former6L at 1/2/4/8 MI355X",
             "value": world * a.steps / elapsed, "unit": "steps/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
+            "ms_per_step_mean_sd": [mean_ps, sd_ps], "ms_per_step_min_max": [min(per_step), max(per_step)] if per_step else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{a.config}: {os.path.basename(cfg.encoder_model_id)} + {os.path.basename(cfg.llm_model_id)}, "
                                    f"Q-Former {cfg.qformer_num_hidden_layers}L, per-GPU batch {B} x 30 s clips, "
@@ -223,12 +337,23 @@ def main():
                          "flop_per_launch": flops / max(n_launch, 1), "gemm_ms_per_step": gemm_ms / a.steps,
                          "other_gemm_kernels": {"launches_per_step": n_other / a.steps, "ms_per_step": ms_other / a.steps,
                                                 "tflops": (flops_other / (ms_other * 1e-3) / 1e12) if ms_other > 0 else 0.0,
-                                                "note": "gemm_bf16_nt_kernel (128x128, incl. transposed-storage dW on a side stream)"}},
+                                                "note": "gemm_bf16_nt_kernel (128x128, incl. transposed-storage dW on a side stream)"},
+                         # the WHOLE step against the same peak: executed FLOP (GEMMs + attention MFMA work; the fast path skips
+                         # lm_head rows without a target and the backward in front of the first audio span) / wall time
+                         "whole_step": {"executed_flop_per_step": exec_flop, "gemm_flop_per_step": gemm_flop_step,
+                                        "attention_flop_per_step": attn_flop_step, "achieved": exec_flop / (ms_step * 1e-3) / 1e12,
+                                        "frac": exec_flop / (ms_step * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                                        "reference_flop_per_step": 1.82e14,
+                                        "frac_on_reference_flop": 1.82e14 / (ms_step * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS
+                                        if a.config.startswith("desta25_llama31-8B") and (B, a.ctx, a.tgt) == (8, 64, 512) else None},
+                         # HBM-bound kernels of the step: ALGORITHMIC bytes / HIP-event time of an untimed 3-step pass, vs 8 TB/s
+                         "hbm_kernels": hbm_kernels, "attention_kernels": attn_kernels},
         }
         if not a.no_cpu_baseline and world == 1:
             try:
                 threads = min(len(os.sched_getaffinity(0)), 64)
                 out["cpu_baseline"] = cpu_baseline(cfg, B, a.ctx, a.tgt, threads)
+                out["cpu_baseline"]["debug_config"] = cpu_baseline_debug(threads)
             except Exception as ex:                                   # noqa: BLE001
                 out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": 0, "kind": "port", "sample": f"failed: {ex}"}
         print(json.dumps(out))

@@ -144,6 +144,41 @@ def gemm_profile_stop(by_kernel: bool = False):
     return len(rec), sum(f for _, _, f, _ in rec), ms
 
 
+# HBM-bound / attention kernels: HIP events around the launches of a tagged wrapper while a profile is open (bench.py's
+# `roofline.hbm_kernels` leg; never on in the timed region).  `work` = ALGORITHMIC bytes (or FLOP for attention) of the call.
+_kprof = None
+
+
+def kernel_profile_start():
+    global _kprof
+    _kprof = {}
+
+
+def kernel_profile_stop():
+    """-> {tag: (n_calls, total_work, total_ms)}"""
+    global _kprof
+    rec, _kprof = _kprof, None
+    torch.cuda.synchronize()
+    return {tag: (len(v), sum(w for _, _, w in v), sum(a.elapsed_time(b) for a, b, _ in v)) for tag, v in rec.items()}
+
+
+def _profiled(tag, work):
+    """Decorator: `work(*args, **kw)` -> algorithmic bytes (FLOP) of the call; evaluated only while profiling."""
+    def deco(fn):
+        def wrapped(*a, **kw):
+            if _kprof is None:
+                return fn(*a, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **kw)
+            e1.record()
+            _kprof.setdefault(tag if isinstance(tag, str) else tag(*a, **kw), []).append((e0, e1, float(work(*a, **kw))))
+            return out
+        wrapped.__name__, wrapped.__doc__ = fn.__name__, fn.__doc__
+        return wrapped
+    return deco
+
+
 # ----------------------------------------------------------------------------- log-mel
 lib.desta_logmel_table_floats.restype = C.c_size_t
 lib.desta_logmel_table_floats.argtypes = [i32]
@@ -165,6 +200,7 @@ def logmel_tables(n_mels: int, device) -> torch.Tensor:
     return _logmel_tables[key]
 
 
+@_profiled("logmel", lambda wave, n_mels, out=None: wave.shape[0] * (4 * min(wave.shape[1], 480000) + 4 * n_mels * 3000))
 def logmel(wave: torch.Tensor, n_mels: int, out: torch.Tensor = None) -> torch.Tensor:
     """wave [B, n] f32 (cuda) -> [B, n_mels, 3000] f32; 30-s zero-pad/truncate semantics."""
     assert wave.is_cuda and wave.dtype == torch.float32 and wave.dim() == 2 and wave.stride(1) == 1
@@ -190,6 +226,7 @@ lib.desta_adafactor_workspace_floats.argtypes = [i32, i32, i64, i64, i64]
 _adafactor = _sig("desta_clip_adafactor_step", C.POINTER(OptPlan), vp, vp, vp, vp, f32, f32, f32, f32, f32, vp)
 
 
+@_profiled("clip_adafactor", lambda plan, params, *a, **k: 12 * params.numel())          # read g, read p, write p (fp32)
 def clip_adafactor_step(plan: OptPlan, params, grads, state, workspace, lr, beta2t, eps1, clip_threshold,
                         max_grad_norm):
     check(_adafactor(C.byref(plan), p(params), p(grads), p(state), p(workspace), lr, beta2t, eps1,
@@ -229,12 +266,14 @@ def scratch(nfloats: int, device, tag="ws") -> torch.Tensor:
     return t
 
 
+@_profiled("layernorm_fwd", lambda x, g, b, eps, y16=None, y32=None, stats=None: x.numel() * (x.element_size() + (2 if y16 is not None else 0) + (4 if y32 is not None else 0)))
 def layernorm_fwd(x, gamma, beta, eps, y16=None, y32=None, stats=None):
     rows, cols = x.numel() // x.shape[-1], x.shape[-1]
     check(_ln_fwd(p(x), int(x.dtype == torch.float32), p(gamma), p(beta), eps, rows, cols, p(y16), p(y32), p(stats),
                   stream()), "desta_layernorm_fwd")
 
 
+@_profiled("layernorm_bwd", lambda dy, x, g, st, dx32=None, dx16=None, **k: x.numel() * (dy.element_size() + x.element_size() + (4 if dx32 is not None else 0) + (2 if dx16 is not None else 0)))
 def layernorm_bwd(dy, x, gamma, stats, dx32=None, dx16=None, dgamma=None, dbeta=None, accumulate=False):
     rows, cols = x.numel() // x.shape[-1], x.shape[-1]
     ws = scratch(lib.desta_layernorm_bwd_workspace_floats(rows, cols), x.device) if dgamma is not None else None
@@ -242,11 +281,13 @@ def layernorm_bwd(dy, x, gamma, stats, dx32=None, dx16=None, dgamma=None, dbeta=
                   cols, p(dx32), p(dx16), p(dgamma), p(dbeta), int(accumulate), p(ws), stream()), "desta_layernorm_bwd")
 
 
+@_profiled("rmsnorm_fwd", lambda x, w, eps, y, rstd=None: 4 * x.numel())                       # bf16 in + bf16 out
 def rmsnorm_fwd(x, weight, eps, y, rstd=None):
     rows, cols = x.numel() // x.shape[-1], x.shape[-1]
     check(_rms_fwd(p(x), p(weight), eps, rows, cols, p(y), p(rstd), stream()), "desta_rmsnorm_fwd")
 
 
+@_profiled("rmsnorm_bwd", lambda dy, x, w, rstd, dx, dres=None: x.numel() * (6 + (2 if dres is not None else 0)))
 def rmsnorm_bwd(dy, x, weight, rstd, dx, dres=None):
     rows, cols = x.numel() // x.shape[-1], x.shape[-1]
     check(_rms_bwd(p(dy), p(x), p(weight), p(rstd), p(dres), rows, cols, p(dx), stream()), "desta_rmsnorm_bwd")
@@ -257,16 +298,19 @@ def colsum(x, rows, cols, ld, out, accumulate=False, tag="ws"):
     check(_colsum(p(x), rows, cols, ld, p(out), int(accumulate), p(ws), stream()), "desta_colsum_bf16")
 
 
+@_profiled("rope", lambda buf, ld, rows, seq, n_q, n_kv, hd, *a, **k: 4 * rows * (n_q + n_kv) * hd)      # q|k read + written in place
 def rope(buf, ld, rows, seq, n_q, n_kv, hd, cos_sin, q_norm_w=None, k_norm_w=None, eps=1e-6, pre_norm=None,
          ld_pre=0, backward=False, pos_shift=None, s_major_batch=0):
     check(_rope(p(buf), ld, rows, seq, n_q, n_kv, hd, p(cos_sin), p(q_norm_w), p(k_norm_w), eps, p(pre_norm), ld_pre,
                 int(backward), p(pos_shift), s_major_batch, stream()), "desta_rope")
 
 
+@_profiled("swiglu_fwd", lambda gu, act, rows, inter: 6 * rows * inter)                    # gate|up read, act written (bf16)
 def swiglu_fwd(gate_up, act, rows, inter):
     check(_swiglu_fwd(p(gate_up), p(act), rows, inter, stream()), "desta_swiglu_fwd")
 
 
+@_profiled("swiglu_bwd", lambda gu, dact, dgu, rows, inter: 10 * rows * inter)            # gate|up + d_act read, d(gate|up) written
 def swiglu_bwd(gate_up, dact, dgate_up, rows, inter):
     check(_swiglu_bwd(p(gate_up), p(dact), p(dgate_up), rows, inter, stream()), "desta_swiglu_bwd")
 
@@ -311,6 +355,7 @@ def gather_rows(src, idx, rows, hidden, out):
     check(_gather(p(src), p(idx), rows, hidden, p(out), stream()), "desta_gather_rows_bf16")
 
 
+@_profiled("causal_lm_loss", lambda logits, ld, labels, batch, seq, vocab, loss, write_grad=True: (2 + 2 * int(write_grad)) * batch * (seq - 1) * vocab)
 def causal_lm_loss(logits, ld, labels, batch, seq, vocab, loss, write_grad=True):
     ws = scratch(lib.desta_ce_workspace_floats(batch, seq), logits.device, "ce")
     check(_ce(p(logits), ld, p(labels), batch, seq, vocab, p(loss), p(ws), int(write_grad), stream()),
@@ -373,10 +418,22 @@ def attn_desc(q, k, v, o, lse, *, batch, hq, hkv, sq, sk, hd, scale, causal=Fals
     return d
 
 
+def _attn_flops(d, mult):
+    """Executed MFMA FLOP: 4*Sq*Sk*D per (batch, head) forward (QK^T + PV), halved under the causal mask."""
+    f = 4.0 * d.batch * d.n_q_heads * d.seq_q * d.seq_k * d.head_dim
+    return mult * (f * 0.5 if d.causal else f)
+
+
+def _attn_tag(d, *a, **k):
+    return f"D{d.head_dim}{'c' if d.causal else ''}_q{d.seq_q}_k{d.seq_k}"
+
+
+@_profiled(lambda d: "attn_fwd:" + _attn_tag(d), lambda d: _attn_flops(d, 1.0))
 def attention_fwd(d: AttnDesc):
     check(_attn_fwd(C.byref(d), stream()), "desta_attention_fwd")
 
 
+@_profiled(lambda d, *a, **k: "attn_bwd:" + _attn_tag(d), lambda d, *a, **k: _attn_flops(d, 2.5))     # dS, dP recompute, dQ, dK, dV
 def attention_bwd(d: AttnDesc, do, dq, dk=None, dv=None, *, do_rs=None, dq_off=0, dk_off=0, dv_off=0, dq_rs=None,
                   dk_rs=None, dv_rs=None, do_bs=None, dq_bs=None, dk_bs=None, dv_bs=None):
     """Backward of the attention described by `d` (O and lse filled by forward); *_bs override the batch strides

@@ -102,25 +102,44 @@ def synthetic_waveform(B: int, device, seed: int = 1234, n: int = 480000) -> tor
     return (0.1 * torch.randn(B, n, generator=g, device=device)).clamp_(-1.0, 1.0)
 
 
+_ENC_LARGE_V3 = dict(num_mel_bins=128, d_model=1280, encoder_layers=32, encoder_attention_heads=20,
+                     encoder_ffn_dim=5120, max_source_positions=1500)      # large-v3 and large-v3-turbo share the ENCODER
+_LLAMA31_8B = dict(model_type="llama", hidden_size=4096, num_hidden_layers=32, num_attention_heads=32,
+                   num_key_value_heads=8, head_dim=128, intermediate_size=14336, vocab_size=128256,
+                   rms_norm_eps=1e-5, rope_theta=500000.0,
+                   rope_scaling={"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0,
+                                 "high_freq_factor": 4.0, "original_max_position_embeddings": 8192})
+
+
+def _qwen3(h, layers, heads, kv, inter, tied, theta=1000000.0):
+    return dict(model_type="qwen3", hidden_size=h, num_hidden_layers=layers, num_attention_heads=heads, num_key_value_heads=kv,
+                head_dim=128, intermediate_size=inter, vocab_size=151936, rms_norm_eps=1e-6, rope_theta=theta,
+                tie_word_embeddings=tied)
+
+
 FULL_CONFIGS = {
-    # BASELINE.json configs[1]/[2]: Whisper-large-v3 + Llama-3.1-8B, Q-Former 6L (Appendix B dims)
+    # BASELINE.json configs[1]/[2]: Whisper-large-v3 + Llama-3.1-8B, Q-Former 6L (SURVEY Appendix B dims)
     "desta25_llama31-8B_Qformer6L": dict(
         llm_model_id="DeSTA-ntu/Llama-3.1-8B-Instruct", encoder_model_id="openai/whisper-large-v3",
-        qformer_num_hidden_layers=6, prompt_size=64,
-        llm_config=dict(model_type="llama", hidden_size=4096, num_hidden_layers=32, num_attention_heads=32,
-                        num_key_value_heads=8, head_dim=128, intermediate_size=14336, vocab_size=128256,
-                        rms_norm_eps=1e-5, rope_theta=500000.0,
-                        rope_scaling={"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0,
-                                      "high_freq_factor": 4.0, "original_max_position_embeddings": 8192}),
-        encoder_config=dict(num_mel_bins=128, d_model=1280, encoder_layers=32, encoder_attention_heads=20,
-                            encoder_ffn_dim=5120, max_source_positions=1500)),
+        qformer_num_hidden_layers=6, prompt_size=64, llm_config=_LLAMA31_8B, encoder_config=_ENC_LARGE_V3),
+    # configs[3]: the large-v3-turbo encoder variant (turbo prunes the DECODER; the reference taps layers 7/15/23/31 of a
+    # 32-layer encoder for both ids, modeling_desta25.py:140-143) -> the same kernels and tilings as configs[1]
+    "desta25_llama31-8B_turbo_Qformer6L": dict(
+        llm_model_id="DeSTA-ntu/Llama-3.1-8B-Instruct", encoder_model_id="openai/whisper-large-v3-turbo",
+        qformer_num_hidden_layers=6, prompt_size=64, llm_config=_LLAMA31_8B, encoder_config=_ENC_LARGE_V3),
     # configs[4]: Qwen3-8B backbone
     "desta25_qwen3-8B_Qformer6L": dict(
         llm_model_id="Qwen/Qwen3-8B", encoder_model_id="openai/whisper-large-v3",
         qformer_num_hidden_layers=6, prompt_size=64, placeholder_token="<|video_pad|>",
-        llm_config=dict(model_type="qwen3", hidden_size=4096, num_hidden_layers=36, num_attention_heads=32,
-                        num_key_value_heads=8, head_dim=128, intermediate_size=12288, vocab_size=151936,
-                        rms_norm_eps=1e-6, rope_theta=1000000.0),
-        encoder_config=dict(num_mel_bins=128, d_model=1280, encoder_layers=32, encoder_attention_heads=20,
-                            encoder_ffn_dim=5120, max_source_positions=1500)),
+        llm_config=_qwen3(4096, 36, 32, 8, 12288, False), encoder_config=_ENC_LARGE_V3),
+    # the two Qwen3 Q-Former configs the reference ships (examples/train/config/desta25_qwen3-{4B,0.6b}_Qformer6L.yaml):
+    # tied lm_head, hidden != heads x head_dim, turbo encoder id (Qwen3-4B-Instruct-2507: rope_theta 5e6 per its model card)
+    "desta25_qwen3-4B_Qformer6L": dict(
+        llm_model_id="Qwen/Qwen3-4B-Instruct-2507", encoder_model_id="openai/whisper-large-v3-turbo",
+        qformer_num_hidden_layers=6, prompt_size=64, placeholder_token="<|video_pad|>",
+        llm_config=_qwen3(2560, 36, 32, 8, 9728, True, theta=5000000.0), encoder_config=_ENC_LARGE_V3),
+    "desta25_qwen3-0.6b_Qformer6L": dict(
+        llm_model_id="Qwen/Qwen3-0.6B", encoder_model_id="openai/whisper-large-v3-turbo",
+        qformer_num_hidden_layers=6, prompt_size=64, placeholder_token="<|video_pad|>",
+        llm_config=_qwen3(1024, 28, 16, 8, 3072, True), encoder_config=_ENC_LARGE_V3),
 }

@@ -37,7 +37,9 @@ def test_full_configs_parse_and_map_to_model_config():
     sys.path.insert(0, os.path.join(ROOT, "desta2.5-audio_amd"))
     from desta.models.modeling_desta25 import DeSTA25Config
     from desta.synthetic import FULL_CONFIGS
-    for name in ("desta25_llama31-8B_Qformer6L", "desta25_qwen3-8B_Qformer6L"):
+    assert set(FULL_CONFIGS) == {os.path.splitext(f)[0] for f in os.listdir(os.path.join(ROOT, "examples", "train", "config"))
+                                 if f.endswith("Qformer6L.yaml")}, "every shipped *_Qformer6L.yaml has its true-shape dims"
+    for name in FULL_CONFIGS:
         cfg = m.load_config(["--config-name", name, "+dataset=synthetic", "exp_dir=/tmp/x"])
         assert cfg.model.connector.num_hidden_layers == 6 and cfg.model.connector.prompt_size == 64
         assert cfg.optim.sched.warmup_steps == 5000 and cfg.trainer.accumulate_grad_batches == 1
@@ -45,6 +47,11 @@ def test_full_configs_parse_and_map_to_model_config():
         mc = DeSTA25Config(**FULL_CONFIGS[name])           # the dims bench.py uses for the same names
         assert mc.qformer_num_hidden_layers == 6 and mc.target_layer_ids == [7, 15, 23, 31]
         assert mc.to_dict()["model_type"] == "desta25"
+        assert mc.llm_model_id == cfg.model.llm.model_id and mc.encoder_model_id == cfg.model.encoder.model_id
+        assert mc.placeholder_token == cfg.model.placeholder_token
+        assert mc.llm_config.tie_word_embeddings == ("qwen3-4B" in name or "0.6b" in name)
+        args = m.create_training_args(cfg)                 # epochs-only: 5 x (256 // 8) steps from the synthetic stream
+        assert args.max_steps == -1 and args.steps_per_epoch == 32 and args.save_strategy == "epoch"
     with pytest.raises(NotImplementedError):
         DeSTA25Config(connector_mode="orca_hybrid", llm_config=FULL_CONFIGS[name]["llm_config"],
                       encoder_config=FULL_CONFIGS[name]["encoder_config"])

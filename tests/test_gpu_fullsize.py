@@ -169,3 +169,57 @@ def test_full_size_generate_cache_consistency(hip, full_model):
     one = model._generate_step(inputs, pad_token_id=0, max_new_tokens=n_new, do_sample=False, eos_token_id=first)
     assert one.shape == (B, 1) and torch.equal(one[:, 0], ids[:, 0])
     model.train()
+
+
+@pytest.mark.parametrize("name", ["desta25_qwen3-8B_Qformer6L", "desta25_qwen3-4B_Qformer6L"])
+def test_full_size_step_properties_qwen3(hip, name):
+    """BASELINE.json configs[4] (Qwen3-8B: q/k-norm, 36 layers, V = 151936, inter 12288) and the reference's shipped Qwen3-4B
+    config (tied lm_head, hidden 2560 != 32 x 128, large-v3-turbo encoder id) at TRUE shapes: ln V loss at random init, finite
+    non-zero gradients, bit-identical rerun, loss descent over a few optimizer steps."""
+    import gc
+    from desta.models.modeling_desta25 import DeSTA25AudioModel, DeSTA25Config
+    from desta.synthetic import FULL_CONFIGS, RandomWeights, synthetic_inputs, synthetic_waveform
+    from desta.trainer.desta_trainer import DeSTA25Trainer, TrainingArguments
+    cfg = DeSTA25Config(**FULL_CONFIGS[name])
+    model = DeSTA25AudioModel(cfg, weights=RandomWeights(cfg, "cuda:0", seed=0), device="cuda:0")
+    c = cfg.llm_config
+    assert c.qk_norm and cfg.target_layer_ids == [7, 15, 23, 31]
+    if c.tie_word_embeddings:
+        assert model.llm.head is model.llm.embed and c.num_attention_heads * c.head_dim != c.hidden_size
+    B = 8
+    batch = synthetic_inputs(cfg, B, 64, 512, "cuda:0", seed=3)
+    batch["batch_features"] = hip.logmel(synthetic_waveform(B, "cuda:0", seed=3), 128)
+    model.train()
+    model._fwd_count = 0
+    out = model(**batch)
+    loss0 = float(out.loss)
+    assert abs(loss0 - math.log(c.vocab_size)) < 1.0, loss0
+    model.backward()
+    g1 = model.arena.grads.clone()
+    assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
+    model.mark_weights_updated()
+    model._fwd_count = 0
+    out = model(**batch)
+    model.backward()
+    assert float(out.loss) == loss0 and torch.equal(model.arena.grads, g1)
+    tr = DeSTA25Trainer(model, args=TrainingArguments(learning_rate=2e-3, warmup_steps=0, max_steps=100, logging_steps=100))
+    losses = tr.train([batch] * 6)
+    assert losses[-1] < losses[0] - 0.05 and all(math.isfinite(x) for x in losses), losses
+    del tr, model, out, g1
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def test_turbo_variant_is_the_same_encoder_problem():
+    """BASELINE.json configs[3]: `openai/whisper-large-v3-turbo` prunes Whisper's DECODER; the reference taps layers 7/15/23/31
+    of a 32-layer, d = 1280 encoder for it exactly as for large-v3 (modeling_desta25.py:140-143), so the encoder / connector
+    problem — every GEMM shape, attention shape and tiling — is identical to configs[1], which the tests above run."""
+    from desta.models.modeling_desta25 import DeSTA25Config, connector_param_shapes
+    from desta.synthetic import FULL_CONFIGS
+    a, b = (DeSTA25Config(**FULL_CONFIGS[n]) for n in ("desta25_llama31-8B_Qformer6L", "desta25_llama31-8B_turbo_Qformer6L"))
+    assert b.encoder_model_id.endswith("whisper-large-v3-turbo") and a.target_layer_ids == b.target_layer_ids == [7, 15, 23, 31]
+    assert a.encoder_config == b.encoder_config and a.llm_config == b.llm_config
+    assert connector_param_shapes(a) == connector_param_shapes(b)
+    # resolved by NAME too when no explicit target_layer_ids / depth table entry would apply
+    assert DeSTA25Config(llm_config=FULL_CONFIGS["desta25_llama31-8B_Qformer6L"]["llm_config"], encoder_model_id="/models/whisper-large-v3-turbo",
+                         encoder_config=dict(FULL_CONFIGS["desta25_llama31-8B_Qformer6L"]["encoder_config"])).target_layer_ids == [7, 15, 23, 31]
