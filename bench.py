@@ -163,6 +163,7 @@ def main():
     ap.add_argument("--tgt", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--encoder-overlap", action="store_true", help="A/B: next batch's Whisper forward on its own stream beside the LLM instead of at the end of the step")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for rehearsals)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--persistent-gemm", action="store_true", help="A/B: enable the persistent GEMM kernel")
@@ -213,7 +214,7 @@ def main():
     t0 = time.time()
     model = DeSTA25AudioModel(cfg, weights=RandomWeights(cfg, dev, seed=0), device=dev)
     args = TrainingArguments(learning_rate=1e-4, weight_decay=0.01, warmup_steps=5000, max_steps=10 ** 6, logging_steps=10 ** 9,
-                             overlap_comm=not a.no_overlap)
+                             overlap_comm=not a.no_overlap, overlap_encoder=a.encoder_overlap)
     trainer = DeSTA25Trainer(model, args=args)
     if a.no_dw_overlap:
         model.connector.overlap_dw = False
@@ -325,6 +326,9 @@ def main():
                        "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}",
                        "step_definition": "one pass of the hot path over one per-GPU batch; value = per-GPU batch-steps per second "
                                           "summed over the node (N x K / max-over-ranks time), weak scaling",
+                       "stream_overlap": ("--encoder-overlap: the frozen Whisper forward of batch t+1 on its own HIP stream beside the LLM of batch t; "
+                                          if a.encoder_overlap else "") +
+                                         "all-reduce + Adafactor + weight re-cast of step t on a side stream beside the Whisper forward of batch t+1",
                        "training_fast_path": ("off (--full-lm-head): lm_head / CE over the whole token grid, backward over every row"
                                               if a.full_lm_head else
                                               "on: lm_head / CE on the rows that carry a target, LLM backward from the first audio span "

@@ -39,7 +39,7 @@ class GemmDesc(C.Structure):
 
 lib.desta_abi_version.restype = i32
 lib.desta_last_error.restype = C.c_char_p
-ABI_VERSION = 2
+ABI_VERSION = 3
 if lib.desta_abi_version() != ABI_VERSION:
     raise ImportError(f"libdesta_hip.so has ABI version {lib.desta_abi_version()}, this binding needs {ABI_VERSION}: "
                       "rebuild with `python desta2.5-audio_amd/build.py`")
@@ -97,19 +97,20 @@ def gemm(A, B, out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, residua
     d.aux, d.ld_aux = p(aux), ld_aux
     d.dropout_p, d.dropout_seed = dropout_p, dropout_seed
     d.a_rms_weight, d.a_rms_eps = p(a_rms_weight), a_rms_eps
-    ws = _gemm_ws.get(A.device)
-    if ws is None:
-        ws = _gemm_ws[A.device] = torch.empty(GEMM_WS_BYTES // 4, dtype=torch.float32, device=A.device)
+    st = stream()
+    ws = _gemm_ws.get((A.device, st))                       # one split-K scratch per STREAM: GEMMs of one stream run serially,
+    if ws is None:                                          # GEMMs of two streams (encoder prefetch beside the LLM) must not share it
+        ws = _gemm_ws[(A.device, st)] = torch.empty(GEMM_WS_BYTES // 4, dtype=torch.float32, device=A.device)
     d.workspace, d.workspace_bytes = ws.data_ptr(), GEMM_WS_BYTES
     if _gemm_prof is not None:
         # HIP events on the launch stream around this one kernel (bench.py roofline leg)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        check(_gemm(C.byref(d), stream()), "desta_gemm_bf16_nt")
+        check(_gemm(C.byref(d), st), "desta_gemm_bf16_nt")
         e1.record()
         _gemm_prof.append((e0, e1, 2.0 * M * N * K * batch, lib.desta_gemm_last_kernel()))
         return out
-    check(_gemm(C.byref(d), stream()), "desta_gemm_bf16_nt")
+    check(_gemm(C.byref(d), st), "desta_gemm_bf16_nt")
     return out
 
 
@@ -119,7 +120,7 @@ def rms_fusable(M: int, K: int) -> bool:
 
 
 _gemm_prof = None
-_gemm_ws = {}                      # per-device split-K scratch (GEMMs of one stream run serially)
+_gemm_ws = {}                      # (device, stream) -> split-K scratch
 GEMM_WS_BYTES = 64 << 20
 
 
@@ -218,11 +219,16 @@ class OptPlan(C.Structure):
     _fields_ = [("tensors", vp), ("tensor_wd", vp), ("n_tensors", i32),
                 ("units", vp), ("unit_col_off", vp), ("n_units", i32),
                 ("vecs", vp), ("vec_wd", vp), ("n_vec", i32),
-                ("sum_rows", i64), ("sum_cols", i64), ("max_batch", i32), ("max_cols", i32)]
+                ("sum_rows", i64), ("sum_cols", i64), ("max_batch", i32), ("max_cols", i32),
+                ("chunks", vp), ("ten_chunks", vp), ("n_chunks", i32), ("max_chunks_per_tensor", i32),
+                ("fin", vp), ("n_fin", i32), ("colpart_floats", i64), ("cols_multiple_of_4", i32),
+                ("group_bounds", vp), ("n_groups", i32)]
 
 
 lib.desta_adafactor_workspace_floats.restype = C.c_size_t
 lib.desta_adafactor_workspace_floats.argtypes = [i32, i32, i64, i64, i64]
+lib.desta_adafactor_workspace_floats_v3.restype = C.c_size_t
+lib.desta_adafactor_workspace_floats_v3.argtypes = [C.POINTER(OptPlan), i64]
 _adafactor = _sig("desta_clip_adafactor_step", C.POINTER(OptPlan), vp, vp, vp, vp, f32, f32, f32, f32, f32, vp)
 
 

@@ -916,10 +916,12 @@ class DeSTA25AudioModel:
         self._init_connector(weights)
         e = config.encoder_config
         self.enc_all = None
+        self._enc_bufs: List[Optional[torch.Tensor]] = [None, None]      # tapped states of the current batch / of the prefetched next one
+        self._enc_cur = 0
         self.training = True
         self._weights_dirty = True
         self._fwd = None
-        self._enc_prefetched = None
+        self._enc_pending: List[tuple] = []    # prefetched encoder outputs not consumed yet: (tensor, version, N, buffer, event)
         self.dropout_seed = 0                  # per-rank stream id of the Q-Former dropout RNG (trainer sets rank)
         self.compact_lm_head = True            # training: lm_head / CE / its backward on target rows only
         self._tr_stream = self._tr_idx = self._tr_lab = self._tr_count = self._tr_count_host = None
@@ -1043,17 +1045,7 @@ class DeSTA25AudioModel:
             if N_audio > 0:
                 assert len(batch_start_positions) == len(batch_transcription_ids) == batch_features.shape[0], \
                     "batch_start_positions, batch_transcription_ids, audio_features, speech_feature_lengths must have the same length."
-                mel = batch_features.to(dev, F32).contiguous()
-                e = cfg.encoder_config
-                nt = len(cfg.target_layer_ids)
-                if self.enc_all is None or self.enc_all.shape[1] != N_audio * e.max_source_positions:
-                    self.enc_all = torch.empty(nt, N_audio * e.max_source_positions, e.d_model, dtype=BF16, device=dev)
-                pf = self._enc_prefetched
-                # hit only for the very tensor OBJECT that was prefetched, unmodified since (a new tensor can reuse a freed
-                # tensor's address and shape, so data_ptr/shape keys can alias a stale encoder output)
-                if not (pf is not None and pf[0] is batch_features and pf[1] == batch_features._version and pf[2] == N_audio):
-                    self.encoder.forward(mel, self.enc_all)
-                self._enc_prefetched = None
+                self._encode(batch_features, N_audio)
                 self.connector.p_drop = cfg.qformer_dropout if self.training else 0.0
                 self.connector.seed_base = ((self.dropout_seed & 0xFFFFFF) << 40) | ((self._fwd_count & 0xFFFFFFFF) << 8)
                 self._fwd_count += 1
@@ -1122,11 +1114,7 @@ class DeSTA25AudioModel:
                     feats = inputs["batch_features"]
                     trs = [t.to(dev) for t in inputs["batch_transcription_ids"]]
                     assert len(starts) == len(trs) == feats.shape[0]
-                    e, nt = cfg.encoder_config, len(cfg.target_layer_ids)
-                    if self.enc_all is None or self.enc_all.shape[1] != N_audio * e.max_source_positions:
-                        self.enc_all = torch.empty(nt, N_audio * e.max_source_positions, e.d_model, dtype=BF16, device=dev)
-                    self.encoder.forward(feats.to(dev, F32).contiguous(), self.enc_all)
-                    self._enc_prefetched = None
+                    self._encode(feats, N_audio)
                     self.connector.p_drop = 0.0
                     af = self.connector.forward(self.enc_all, N_audio)
                     src = self._src_rows(input_ids, trs, starts, None)
@@ -1180,17 +1168,79 @@ class DeSTA25AudioModel:
         main.wait_stream(self._tr_stream)                                        # idx / compact labels are read on the main stream
         return self._tr_idx, self._tr_lab, self._tr_count_host, ev
 
-    def prefetch_encoder(self, batch_features: torch.Tensor) -> None:
-        """Run the FROZEN Whisper encoder for the next batch now (it does not depend on the connector
-        weights, so it may overlap the previous step's all-reduce + optimizer on another stream)."""
-        cfg, dev = self.config, self.device
-        e, nt, N = cfg.encoder_config, len(cfg.target_layer_ids), batch_features.shape[0]
+    def _enc_buf(self, idx: int, N: int) -> torch.Tensor:
+        e, nt = self.config.encoder_config, len(self.config.target_layer_ids)
+        b = self._enc_bufs[idx]
+        if b is None or b.shape[1] != N * e.max_source_positions:
+            b = self._enc_bufs[idx] = torch.empty(nt, N * e.max_source_positions, e.d_model, dtype=BF16, device=self.device)
+        return b
+
+    def drop_prefetched(self) -> None:
+        """Forget prefetched encoder outputs (their batches will never run); the encoder's scratch is free again afterwards."""
+        main = torch.cuda.current_stream(self.device)
+        for pf in self._enc_pending:
+            if pf[4] is not None:
+                main.wait_event(pf[4])
+        self._enc_pending = []
+
+    def _encode(self, batch_features: torch.Tensor, N: int) -> None:
+        """self.enc_all := tapped Whisper states of `batch_features`: the prefetched ones when `prefetch_encoder` ran for this
+        very tensor OBJECT, unmodified since (a new tensor can reuse a freed tensor's address and shape, so data_ptr / shape
+        keys could alias a stale encoder output), else computed now."""
+        main = torch.cuda.current_stream(self.device)
+        for k, pf in enumerate(self._enc_pending):
+            if pf[0] is batch_features and pf[1] == batch_features._version and pf[2] == N:
+                if pf[4] is not None:
+                    main.wait_event(pf[4])
+                del self._enc_pending[k]                 # a prefetch for the batch AFTER this one may stay pending
+                self._enc_cur = pf[3]
+                self.enc_all = self._enc_bufs[self._enc_cur]
+                return
+        # miss: the encoder's scratch buffers are shared with any prefetch still running -> wait for all of them
+        busy = {pf[3] for pf in self._enc_pending}
+        for pf in self._enc_pending:
+            if pf[4] is not None:
+                main.wait_event(pf[4])
+        if len(busy) > 1:                                # both buffers hold prefetched batches that are not this one: stale
+            self._enc_pending, busy = [], set()
+        if self._enc_cur in busy:
+            self._enc_cur = 1 - self._enc_cur
+        self.enc_all = self._enc_buf(self._enc_cur, N)
+        self.encoder.forward(batch_features.to(self.device, F32).contiguous(), self.enc_all)
+
+    def prefetch_encoder(self, batch_features: torch.Tensor, stream: Optional["torch.cuda.Stream"] = None) -> None:
+        """Run the FROZEN Whisper encoder for a LATER batch now, into the tapped-state buffer no pending batch occupies.  It
+        depends on nothing the optimizer writes, so with `stream` it runs on that HIP stream from the current position of the
+        calling stream on, CONCURRENTLY with whatever the calling stream does next (the LLM forward / backward of the current
+        batch: its VALU-bound attention, HBM-bound norms and partial GEMM rounds fill in beside the MFMA-bound LLM GEMMs); the
+        consumer waits on its event in `_encode`.  Without `stream` it runs in line on the current stream.  At most one
+        consumed-later batch besides the current one is kept (two buffers)."""
+        dev = self.device
+        N = batch_features.shape[0]
         with torch.cuda.device(dev):
+            main = torch.cuda.current_stream(dev)
+            if len(self._enc_pending) >= 2:
+                self.drop_prefetched()
+            # the buffer of the batch consumed LAST (its backward is already queued on the calling stream) unless a pending
+            # prefetch sits there; the one in flight for the current batch keeps the other
+            busy = {pf[3] for pf in self._enc_pending}
+            idx = (1 - next(iter(busy))) if busy else 1 - self._enc_cur
+            for pf in self._enc_pending:                 # one encoder at a time on the shared scratch: order behind the pending one
+                if pf[4] is not None:
+                    (stream or main).wait_event(pf[4])
+            buf = self._enc_buf(idx, N)
             mel = batch_features.to(dev, F32).contiguous()
-            if self.enc_all is None or self.enc_all.shape[1] != N * e.max_source_positions:
-                self.enc_all = torch.empty(nt, N * e.max_source_positions, e.d_model, dtype=BF16, device=dev)
-            self.encoder.forward(mel, self.enc_all)
-        self._enc_prefetched = (batch_features, batch_features._version, N)
+            ev = None
+            if stream is None:
+                self.encoder.forward(mel, buf)
+            else:
+                stream.wait_stream(main)                 # inputs ready; the buffer's last reader (a finished batch's backward) queued
+                with torch.cuda.stream(stream):
+                    self.encoder.forward(mel, buf)
+                    ev = torch.cuda.Event()
+                    ev.record(stream)
+                self._enc_keep = mel
+        self._enc_pending.append((batch_features, batch_features._version, N, idx, ev))
 
     def backward(self) -> None:
         """Gradients of the last forward's loss w.r.t. every connector tensor -> arena.grads (overwritten)."""

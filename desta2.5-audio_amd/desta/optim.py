@@ -7,6 +7,7 @@ and `get_linear_schedule_with_warmup` (TF:optimization.py:101-104, train_desta.p
 """
 from __future__ import annotations
 
+import ctypes
 import math
 from collections import OrderedDict
 from typing import Dict, List, Sequence, Tuple
@@ -17,6 +18,8 @@ from . import _hip
 
 ALIGN = 64           # floats; keeps every tensor 256-B aligned in the arena
 UNIT_ROWS = 64
+CHUNK = 16384        # elements per work item of the update kernels (256 threads x 16 float4, csrc/adafactor.hip)
+GROUP_FLOATS = 16 << 20   # <= 64 MB of gradients per (sum u^2, apply) launch pair: g + p read + p write of a group = 192 MB < 256 MB Infinity Cache
 
 
 def _al(n: int, a: int = ALIGN) -> int:
@@ -132,8 +135,40 @@ class FusedAdafactor:
         pl.vecs, pl.vec_wd, pl.n_vec = self._vecs.data_ptr(), self._vwd.data_ptr(), len(vecs)
         pl.sum_rows, pl.sum_cols = st_off, st_off
         pl.max_batch, pl.max_cols = max_batch, max_cols
+        # work items of the update kernels: <= CHUNK contiguous elements of one [rows, cols] matrix; tensors in DESCENDING
+        # arena order (the update pass starts where the statistics pass ended: that tail is still in the Infinity Cache),
+        # the chunks of one tensor contiguous
+        chunks, ten_chunks, fin = [], [[0, 0] for _ in tensors], []
+        for ti in reversed(range(len(tensors))):
+            _, nb, R, Cn = tensors[ti][:4]
+            ten_chunks[ti][0] = len(chunks)
+            for b in range(nb):
+                for e0 in range(0, R * Cn, CHUNK):
+                    chunks.append([ti, b, e0, min(CHUNK, R * Cn - e0)])
+            ten_chunks[ti][1] = len(chunks) - ten_chunks[ti][0]
+        for ti, (_, nb, R, Cn, *_rest) in enumerate(tensors):
+            for b in range(nb):
+                fin += [[ti, b, part] for part in range(1 + (Cn + 255) // 256)]
+        self._chunks = torch.tensor(chunks or [[0] * 4], dtype=i32, device=dev)
+        self._ten_chunks = torch.tensor(ten_chunks or [[0, 0]], dtype=i32, device=dev)
+        self._fin = torch.tensor(fin or [[0] * 3], dtype=i32, device=dev)
+        pl.chunks, pl.ten_chunks, pl.n_chunks = self._chunks.data_ptr(), self._ten_chunks.data_ptr(), len(chunks)
+        pl.max_chunks_per_tensor = max([c[1] for c in ten_chunks] or [0])
+        pl.fin, pl.n_fin, pl.colpart_floats = self._fin.data_ptr(), len(fin), col_ws_off
+        pl.cols_multiple_of_4 = int(all(t[3] % 4 == 0 for t in tensors))
+        # launch groups: cut the chunk list at tensor boundaries (a tensor's rms needs all of its chunk sums before its apply)
+        bounds, acc = [0], 0
+        for ti in reversed(range(len(tensors))):
+            n = tensors[ti][1] * tensors[ti][2] * tensors[ti][3]
+            if acc and acc + n > GROUP_FLOATS:
+                bounds.append(ten_chunks[ti][0])
+                acc = 0
+            acc += n
+        bounds.append(len(chunks))
+        self._group_bounds = (ctypes.c_int32 * len(bounds))(*bounds)            # HOST array, kept alive with the plan
+        pl.group_bounds, pl.n_groups = ctypes.cast(self._group_bounds, ctypes.c_void_p), len(bounds) - 1
         self.plan = pl
-        nws = _hip.lib.desta_adafactor_workspace_floats(len(units), len(vecs), st_off, st_off, col_ws_off)
+        nws = _hip.lib.desta_adafactor_workspace_floats_v3(ctypes.byref(pl), col_ws_off)
         self.workspace = torch.zeros(nws, dtype=torch.float32, device=dev)
 
     def step(self, lr: float) -> None:

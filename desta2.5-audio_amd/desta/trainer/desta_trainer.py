@@ -42,6 +42,7 @@ class TrainingArguments:
     optim: str = "adafactor"
     bf16: bool = True
     overlap_comm: bool = True
+    overlap_encoder: bool = False                  # next batch's frozen Whisper forward on its own HIP stream beside the LLM (A/B: -1.2 % step time, see DESIGN)
     save_strategy: str = "no"                      # "epoch" (train_desta.py:146, enable_checkpointing) | "no"
     steps_per_epoch: Optional[int] = None          # len(train dataloader) when the dataset is not sized (synthetic streams)
 
@@ -97,6 +98,7 @@ class DeSTA25Trainer:
         self.rank = dist.get_rank() if self.world > 1 else 0
         model.dropout_seed = 1 + self.rank                                    # ranks draw different dropout masks (as under DDP)
         self._side = torch.cuda.Stream(device=model.device) if self.args.overlap_comm else None
+        self._enc_stream = torch.cuda.Stream(device=model.device) if self.args.overlap_encoder else None
         self._side_done: Optional[torch.cuda.Event] = None
         self._log_buffer: List[Dict[str, Any]] = []
         self.log_history: List[Dict[str, float]] = []
@@ -174,6 +176,12 @@ class DeSTA25Trainer:
             # (TF:optimization.py:1220), the scheduler and global_step still advance
             self.global_step += 1
             return self.compute_loss(model, inputs)
+        prefetch = next_inputs is not None and not self._is_empty_batch(next_inputs)
+        if prefetch and self._enc_stream is not None and not empty:
+            # the frozen encoder of batch t+1 starts NOW on its own stream and runs beside this step's LLM forward / backward
+            # (it reads nothing the optimizer writes)
+            model.prefetch_encoder(next_inputs["batch_features"], stream=self._enc_stream)
+            prefetch = False
         self.wait_update()                                                    # connector weights of step t-1 are final
         loss = self.compute_loss(model, inputs)
         if empty:
@@ -197,7 +205,7 @@ class DeSTA25Trainer:
                 ev.record(self._side)
             self._side_done = ev
             model._weights_dirty = False
-            if next_inputs is not None and not self._is_empty_batch(next_inputs):
+            if prefetch:                                                      # no encoder stream: overlap at least the optimizer tail
                 model.prefetch_encoder(next_inputs["batch_features"])
         return loss
 
@@ -233,7 +241,7 @@ class DeSTA25Trainer:
                     self.save_checkpoint(os.path.join(self.args.output_dir, f"checkpoint-{self.global_step}"))
         self.wait_update()
         torch.cuda.synchronize(self.model.device)
-        self.model._enc_prefetched = None                                     # a prefetch for a batch that never ran is void
+        self.model.drop_prefetched()                                          # a prefetch for a batch that never ran is void
         self._flush_logs()
         return [float(x) for x in losses]
 

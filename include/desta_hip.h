@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DESTA_ABI_VERSION 2
+#define DESTA_ABI_VERSION 3
 
 int desta_abi_version(void);
 /* sizeof of the descriptor structs as this library was compiled (0 = desta_gemm_desc, 1 = desta_attn_desc,
@@ -111,9 +111,22 @@ typedef struct desta_opt_plan {
     const int64_t* vecs; const float* vec_wd; int n_vec;
     int64_t sum_rows, sum_cols;      /* total factored row / column state entries */
     int max_batch, max_cols;
+    /* ABI 3: work items of the update kernels and of the factor kernel.
+     * chunks [n_chunks][4] = (tensor, batch index, first element inside the [rows, cols] matrix, count <= 16384), the chunks of
+     * one tensor contiguous, tensors in DESCENDING arena order (the update passes walk the arena backwards, from the end the
+     * statistics pass has just streamed through the Infinity Cache); ten_chunks [n_tensors][2] = (first chunk, chunk count);
+     * fin [n_fin][3] = (tensor, batch index, part): part 0 = the row factors, k >= 1 = columns [256 (k-1), 256 k);
+     * group_bounds: HOST array [n_groups + 1] of chunk indices cutting the chunk list at tensor boundaries into groups of
+     * <= 64 MB of gradients (the re-read of a group's gradients is then served by the Infinity Cache). */
+    const int32_t* chunks; const int32_t* ten_chunks; int n_chunks, max_chunks_per_tensor;
+    const int32_t* fin; int n_fin;
+    int64_t colpart_floats;
+    int cols_multiple_of_4;          /* every factored tensor has cols % 4 == 0 (16-B row accesses in the chunk kernels) */
+    const int32_t* group_bounds; int n_groups;
 } desta_opt_plan;
 size_t desta_adafactor_workspace_floats(int n_units, int n_vec, int64_t sum_rows, int64_t sum_cols,
-                                        int64_t colpart_floats);
+                                        int64_t colpart_floats);      /* ABI <= 2 layout, kept for old callers */
+size_t desta_adafactor_workspace_floats_v3(const desta_opt_plan* plan, int64_t colpart_floats);
 int desta_clip_adafactor_step(const desta_opt_plan* plan, float* params, const float* grads, float* state,
                               float* workspace, float lr, float beta2t, float eps1, float clip_threshold,
                               float max_grad_norm, void* stream);

@@ -392,7 +392,21 @@ def test_adafactor_matches_oracle_small(hip):
 def test_adafactor_connector_shapes(hip):
     """Shapes of the real connector tensors (largest: 1280x3072, 4096x1280) incl. the 3-D prompts."""
     shapes = [(64, 4), (1, 64, 1280), (3072, 1280), (3072,), (1280, 3072), (1280,), (4096, 1280), (4096,)]
-    _run_adafactor_case(hip, shapes, steps=2, gscale=[0.02, 3.0])
+    _, opt = _run_adafactor_case(hip, shapes, steps=2, gscale=[0.02, 3.0])
+    assert opt.plan.n_groups >= 2                      # 13 M gradient floats: two (sum u^2, apply) launch pairs
+
+
+def test_adafactor_ragged_rows_take_the_two_launch_path(hip):
+    """cols % 4 != 0 (no 16-B row accesses): the plan is routed to the two-launch update; same numbers."""
+    _, opt = _run_adafactor_case(hip, [(33, 7), (5, 3, 9), (11,), (40, 64)], steps=3, gscale=[0.5, 4.0])
+    assert opt.plan.cols_multiple_of_4 == 0
+
+
+def test_adafactor_many_chunk_tensor_and_full_arena_order(hip):
+    """A tensor of 321 chunks between small ones, several launch groups in the reverse arena order; 2 steps against the
+    exact-reduction oracle."""
+    _, opt = _run_adafactor_case(hip, [(8, 64), (4100, 1280), (1280,), (2, 16, 1280), (257, 516)], steps=2, gscale=[0.03, 2.0])
+    assert opt.plan.cols_multiple_of_4 == 1 and opt.plan.max_chunks_per_tensor == 321
 
 
 def test_adafactor_is_deterministic(hip):
