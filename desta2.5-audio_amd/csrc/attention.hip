@@ -50,16 +50,16 @@ template <int N> struct stage_vec;
 template <> struct stage_vec<1> { typedef __attribute__((ext_vector_type(4))) unsigned type; };
 template <> struct stage_vec<2> { typedef __attribute__((ext_vector_type(8))) unsigned type; };
 template <> struct stage_vec<4> { typedef __attribute__((ext_vector_type(16))) unsigned type; };
-template <int D, int ROWS> using stage_t = typename stage_vec<ROWS * (D / 8) / 256>::type;
+template <int D, int ROWS, int NT = 256> using stage_t = typename stage_vec<ROWS * (D / 8) / NT>::type;
 
-// global -> registers (16-B chunks), rows clamped to [0, max_row]
-template <int D, int ROWS>
-__device__ __forceinline__ stage_t<D, ROWS> tile_load(const bf16_t* base, long rs, int row0, int max_row) {
-    constexpr int CH = D / 8, N = ROWS * CH / 256;
-    stage_t<D, ROWS> out;
+// global -> registers (16-B chunks), rows clamped to [0, max_row]; NT = threads of the block
+template <int D, int ROWS, int NT = 256>
+__device__ __forceinline__ stage_t<D, ROWS, NT> tile_load(const bf16_t* base, long rs, int row0, int max_row) {
+    constexpr int CH = D / 8, N = ROWS * CH / NT;
+    stage_t<D, ROWS, NT> out;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const int id = i * 256 + threadIdx.x;
+        const int id = i * NT + threadIdx.x;
         const int r = id / CH, c = id % CH;
         const int gr = min(row0 + r, max_row);
         const uint4 v = *(const uint4*)(base + (long)gr * rs + c * 8);
@@ -67,12 +67,12 @@ __device__ __forceinline__ stage_t<D, ROWS> tile_load(const bf16_t* base, long r
     }
     return out;
 }
-template <int D, int ROWS>
-__device__ __forceinline__ void tile_store(char* img, const stage_t<D, ROWS>& regs) {
-    constexpr int CH = D / 8, N = ROWS * CH / 256;
+template <int D, int ROWS, int NT = 256>
+__device__ __forceinline__ void tile_store(char* img, const stage_t<D, ROWS, NT>& regs) {
+    constexpr int CH = D / 8, N = ROWS * CH / NT;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const int id = i * 256 + threadIdx.x;
+        const int id = i * NT + threadIdx.x;
         const int r = id / CH, c = id % CH;
         *(uint4*)(img + img_off<D>(r, c)) = make_uint4(regs[4 * i + 0], regs[4 * i + 1], regs[4 * i + 2], regs[4 * i + 3]);
     }
@@ -120,14 +120,17 @@ __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8
 #ifndef ATTN_FWD_PF
 #define ATTN_FWD_PF 1
 #endif
-template <int D, bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_fwd_k(AttnArgs p) {
+// NW = waves per block (32 query rows each): 4, or 2 for Sq <= 64 (the Q-Former's 64 prompt queries: with 4 waves half of
+// every block computed clamped duplicate rows, and 640 four-wave blocks left most of the chip's wave slots empty)
+template <int D, bool DROP, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 3) void attn_fwd_k(AttnArgs p) {
+    constexpr int NT = 64 * NW, QB = 32 * NW;
     __shared__ __attribute__((aligned(16))) char lds[2 * 64 * D * 2];
     char* kimg = lds;
     char* vimg = lds + 64 * D * 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h2 = lane >> 5;
     // causal: the last query blocks see the most keys -> dispatch them first
-    const int qb0 = (p.causal ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * 128, q0 = qb0 + wave * 32;
+    const int qb0 = (p.causal ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * QB, q0 = qb0 + wave * 32;
     const int h = blockIdx.y, b = blockIdx.z, hk = h / (p.Hq / p.Hkv);
     const int qcol = q0 + (lane & 31);
 
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_k(AttnArgs p) {
     const int coff = p.Sk - p.Sq;
     const int kv_lo = p.kv_start ? max(0, min(p.kv_start[b], p.Sk)) : 0;
     int kv_hi = p.Sk;
-    if (p.causal) kv_hi = min(p.Sk, min(qb0 + 127, p.Sq - 1) + coff + 1);
+    if (p.causal) kv_hi = min(p.Sk, min(qb0 + QB - 1, p.Sq - 1) + coff + 1);
     const int t_lo = kv_lo / 64, t_hi = (kv_hi + 63) / 64;
     const int q_abs = qcol + coff;
     const int wave_kmax = p.causal ? min(q0 + 31, p.Sq - 1) + coff : p.Sk - 1;   // last key any row of this wave may see
@@ -156,14 +159,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_k(AttnArgs p) {
 
     // K/V tiles are register-staged PF tiles ahead (PF = 2: two register sets, loop unrolled by two)
     constexpr int PF = ATTN_FWD_PF;                        // prefetch distance in tiles (1 or 2)
-    stage_t<D, 64> kr0 = {}, vr0 = {}, kr1 = {}, vr1 = {};
+    stage_t<D, 64, NT> kr0 = {}, vr0 = {}, kr1 = {}, vr1 = {};
     if (t_lo < t_hi) {
-        kr0 = tile_load<D, 64>(kbase, p.k_rs, t_lo * 64, p.Sk - 1);
-        vr0 = tile_load<D, 64>(vbase, p.v_rs, t_lo * 64, p.Sk - 1);
+        kr0 = tile_load<D, 64, NT>(kbase, p.k_rs, t_lo * 64, p.Sk - 1);
+        vr0 = tile_load<D, 64, NT>(vbase, p.v_rs, t_lo * 64, p.Sk - 1);
     }
     if (PF == 2 && t_lo + 1 < t_hi) {
-        kr1 = tile_load<D, 64>(kbase, p.k_rs, (t_lo + 1) * 64, p.Sk - 1);
-        vr1 = tile_load<D, 64>(vbase, p.v_rs, (t_lo + 1) * 64, p.Sk - 1);
+        kr1 = tile_load<D, 64, NT>(kbase, p.k_rs, (t_lo + 1) * 64, p.Sk - 1);
+        vr1 = tile_load<D, 64, NT>(vbase, p.v_rs, (t_lo + 1) * 64, p.Sk - 1);
     }
     auto compute = [&](const int kt) __attribute__((always_inline)) {
         if (kt * 64 > wave_kmax) return;                   // wave-uniform: nothing visible in this tile
@@ -239,12 +242,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_k(AttnArgs p) {
 #define DESTA_KV_STAGE(KT, KR, VR)                                                   \
     __syncthreads(); /* previous tile's LDS reads are done */                        \
     asm volatile("; stage " #KR ::: "memory"); /* distinct text: keeps the two halves from being tail-merged */ \
-    tile_store<D, 64>(kimg, KR);                                                     \
-    tile_store<D, 64>(vimg, VR);                                                     \
+    tile_store<D, 64, NT>(kimg, KR);                                                     \
+    tile_store<D, 64, NT>(vimg, VR);                                                     \
     __syncthreads();                                                                 \
     if ((KT) + PF < t_hi) {                                                          \
-        KR = tile_load<D, 64>(kbase, p.k_rs, ((KT) + PF) * 64, p.Sk - 1);            \
-        VR = tile_load<D, 64>(vbase, p.v_rs, ((KT) + PF) * 64, p.Sk - 1);            \
+        KR = tile_load<D, 64, NT>(kbase, p.k_rs, ((KT) + PF) * 64, p.Sk - 1);            \
+        VR = tile_load<D, 64, NT>(vbase, p.v_rs, ((KT) + PF) * 64, p.Sk - 1);            \
     }
     for (int kt = t_lo; kt < t_hi; kt += 2) {
         DESTA_KV_STAGE(kt, kr0, vr0)
@@ -306,14 +309,15 @@ __global__ __launch_bounds__(256) void attn_delta_k(AttnArgs p, float* __restric
 #ifndef ATTN_DQ_BLOCKS
 #define ATTN_DQ_BLOCKS 2
 #endif
-template <int D, bool DROP>
-__global__ __launch_bounds__(256, ATTN_DQ_BLOCKS) void attn_bwd_dq_k(AttnArgs p) {
+template <int D, bool DROP, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? ATTN_DQ_BLOCKS : 3) void attn_bwd_dq_k(AttnArgs p) {
+    constexpr int NT = 64 * NW, QB = 32 * NW;
     __shared__ __attribute__((aligned(16))) char lds[2 * 64 * D * 2];
     char* kimg = lds;
     char* vimg = lds + 64 * D * 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h2 = lane >> 5;
     // causal: the last query blocks see the most keys -> dispatch them first
-    const int qb0 = (p.causal ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * 128, q0 = qb0 + wave * 32;
+    const int qb0 = (p.causal ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * QB, q0 = qb0 + wave * 32;
     const int h = blockIdx.y, b = blockIdx.z, hk = h / (p.Hq / p.Hkv);
     const int qcol = q0 + (lane & 31), qc = min(qcol, p.Sq - 1);
 
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(256, ATTN_DQ_BLOCKS) void attn_bwd_dq_k(AttnArgs p)
     const int coff = p.Sk - p.Sq;
     const int kv_lo = p.kv_start ? max(0, min(p.kv_start[b], p.Sk)) : 0;
     int kv_hi = p.Sk;
-    if (p.causal) kv_hi = min(p.Sk, min(qb0 + 127, p.Sq - 1) + coff + 1);
+    if (p.causal) kv_hi = min(p.Sk, min(qb0 + QB - 1, p.Sq - 1) + coff + 1);
     const int t_lo = kv_lo / 64, t_hi = (kv_hi + 63) / 64;
     const int q_abs = qcol + coff;
     const int wave_kmax = p.causal ? min(q0 + 31, p.Sq - 1) + coff : p.Sk - 1;
@@ -347,14 +351,14 @@ __global__ __launch_bounds__(256, ATTN_DQ_BLOCKS) void attn_bwd_dq_k(AttnArgs p)
 
     // K/V tiles are register-staged PF tiles ahead (PF = 2: two register sets, loop unrolled by two)
     constexpr int PF = ATTN_DQ_PF;                         // prefetch distance in tiles (1 or 2)
-    stage_t<D, 64> kr0 = {}, vr0 = {}, kr1 = {}, vr1 = {};
+    stage_t<D, 64, NT> kr0 = {}, vr0 = {}, kr1 = {}, vr1 = {};
     if (t_lo < t_hi) {
-        kr0 = tile_load<D, 64>(kbase, p.k_rs, t_lo * 64, p.Sk - 1);
-        vr0 = tile_load<D, 64>(vbase, p.v_rs, t_lo * 64, p.Sk - 1);
+        kr0 = tile_load<D, 64, NT>(kbase, p.k_rs, t_lo * 64, p.Sk - 1);
+        vr0 = tile_load<D, 64, NT>(vbase, p.v_rs, t_lo * 64, p.Sk - 1);
     }
     if (PF == 2 && t_lo + 1 < t_hi) {
-        kr1 = tile_load<D, 64>(kbase, p.k_rs, (t_lo + 1) * 64, p.Sk - 1);
-        vr1 = tile_load<D, 64>(vbase, p.v_rs, (t_lo + 1) * 64, p.Sk - 1);
+        kr1 = tile_load<D, 64, NT>(kbase, p.k_rs, (t_lo + 1) * 64, p.Sk - 1);
+        vr1 = tile_load<D, 64, NT>(vbase, p.v_rs, (t_lo + 1) * 64, p.Sk - 1);
     }
     auto compute = [&](const int kt) __attribute__((always_inline)) {
         if (kt * 64 > wave_kmax) return;
@@ -398,12 +402,12 @@ __global__ __launch_bounds__(256, ATTN_DQ_BLOCKS) void attn_bwd_dq_k(AttnArgs p)
 #define DESTA_KV_STAGE(KT, KR, VR)                                                   \
     __syncthreads(); /* previous tile's LDS reads are done */                        \
     asm volatile("; stage " #KR ::: "memory"); /* distinct text: keeps the two halves from being tail-merged */ \
-    tile_store<D, 64>(kimg, KR);                                                     \
-    tile_store<D, 64>(vimg, VR);                                                     \
+    tile_store<D, 64, NT>(kimg, KR);                                                     \
+    tile_store<D, 64, NT>(vimg, VR);                                                     \
     __syncthreads();                                                                 \
     if ((KT) + PF < t_hi) {                                                          \
-        KR = tile_load<D, 64>(kbase, p.k_rs, ((KT) + PF) * 64, p.Sk - 1);            \
-        VR = tile_load<D, 64>(vbase, p.v_rs, ((KT) + PF) * 64, p.Sk - 1);            \
+        KR = tile_load<D, 64, NT>(kbase, p.k_rs, ((KT) + PF) * 64, p.Sk - 1);            \
+        VR = tile_load<D, 64, NT>(vbase, p.v_rs, ((KT) + PF) * 64, p.Sk - 1);            \
     }
     for (int kt = t_lo; kt < t_hi; kt += 2) {
         DESTA_KV_STAGE(kt, kr0, vr0)
@@ -633,7 +637,10 @@ extern "C" int desta_attention_fwd(const desta_attn_desc* d, void* stream) {
     DESTA_CHECK_ARG(d->O, "attention_fwd: null output");
     DESTA_CHECK_ARG(d->o_row_stride % 4 == 0, "attention_fwd: o_row_stride must be a multiple of 4");
     dim3 grid((a.Sq + 127) / 128, a.Hq, a.B);
+    const bool two = d->head_dim == 64 && a.Sq <= 64;                  // 64-row blocks of two waves (Q-Former queries)
     if (d->head_dim == 128) hipLaunchKernelGGL((attn_fwd_k<128, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else if (two && a.drop_thresh) hipLaunchKernelGGL((attn_fwd_k<64, true, 2>), grid, dim3(128), 0, (hipStream_t)stream, a);
+    else if (two) hipLaunchKernelGGL((attn_fwd_k<64, false, 2>), grid, dim3(128), 0, (hipStream_t)stream, a);
     else if (a.drop_thresh) hipLaunchKernelGGL((attn_fwd_k<64, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((attn_fwd_k<64, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
     DESTA_CHECK_LAUNCH("attention_fwd");
@@ -694,11 +701,14 @@ extern "C" int desta_attention_bwd(const desta_attn_desc* d, float* workspace, v
         }
     } else {
         hipLaunchKernelGGL(attn_delta_k<64>, gd, dim3(256), 0, st, a, workspace);
+        const bool two = a.Sq <= 64;
         if (a.drop_thresh) {
-            hipLaunchKernelGGL((attn_bwd_dq_k<64, true>), gq, dim3(256), 0, st, a);
+            if (two) hipLaunchKernelGGL((attn_bwd_dq_k<64, true, 2>), gq, dim3(128), 0, st, a);
+            else hipLaunchKernelGGL((attn_bwd_dq_k<64, true>), gq, dim3(256), 0, st, a);
             if (d->dK) hipLaunchKernelGGL((attn_bwd_dkdv_k<64, true>), gk, dim3(256), 0, st, a);
         } else {
-            hipLaunchKernelGGL((attn_bwd_dq_k<64, false>), gq, dim3(256), 0, st, a);
+            if (two) hipLaunchKernelGGL((attn_bwd_dq_k<64, false, 2>), gq, dim3(128), 0, st, a);
+            else hipLaunchKernelGGL((attn_bwd_dq_k<64, false>), gq, dim3(256), 0, st, a);
             if (d->dK) hipLaunchKernelGGL((attn_bwd_dkdv_k<64, false>), gk, dim3(256), 0, st, a);
         }
     }
