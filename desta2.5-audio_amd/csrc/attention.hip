@@ -113,6 +113,29 @@ __device__ __forceinline__ bf16x8 acc_frag(const f32x16& x, int s) {
 
 __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
+// XCD-aware work order for the query-block kernels.  Blocks are dealt round-robin over the 8 XCDs (block id % 8), each with
+// its own L2: with (q-block, head, batch) = blockIdx the q-blocks of one (batch, head) landed on 8 different XCDs and every
+// XCD fetched that head's K / V for itself (rocprofv3 FETCH_SIZE of the Whisper shape: 528 MB per launch against 92 MB of
+// Q, K, V).  Here XCD x walks the (batch, kv head) groups g = x, x + 8, ... and, inside a group, the query heads of the GQA
+// group and their q-blocks back to back, so the K / V tiles of a group are re-read from that XCD's L2.  Speed only: any
+// placement is correct.  Causal: q-blocks in descending order (most keys first).
+__device__ __forceinline__ void attn_work_item(const AttnArgs& p, int nq, int& qblk, int& h, int& b) {
+    const int id = blockIdx.x, per = nq * (p.Hq / p.Hkv), ngrp = p.B * p.Hkv;       // per = blocks of one (batch, kv head) group
+    int g, r;
+    if ((ngrp & 7) == 0) {
+        const int xcd = id & 7, slot = id >> 3;
+        g = (slot / per) * 8 + xcd;
+        r = slot % per;
+    } else {
+        g = id / per;
+        r = id % per;
+    }
+    b = g / p.Hkv;
+    h = (g % p.Hkv) * (p.Hq / p.Hkv) + r / nq;
+    qblk = r % nq;
+    if (p.causal) qblk = nq - 1 - qblk;
+}
+
 // ------------------------------------------------------------------------------------------ forward
 // Occupancy beats prefetch depth here (measured, tools/attn_bench.py): with K/V register-staged ONE tile ahead the
 // kernel fits 256 VGPRs at D=128 (160 at D=64) -> 2 (3) blocks per CU, whose MFMA / softmax / staging phases overlap
@@ -122,16 +145,20 @@ __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8
 #endif
 // NW = waves per block (32 query rows each): 4, or 2 for Sq <= 64 (the Q-Former's 64 prompt queries: with 4 waves half of
 // every block computed clamped duplicate rows, and 640 four-wave blocks left most of the chip's wave slots empty)
+#ifndef ATTN_FWD64_WAVES
+#define ATTN_FWD64_WAVES 3
+#endif
 template <int D, bool DROP, int NW = 4>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 3) void attn_fwd_k(AttnArgs p) {
+__global__ __launch_bounds__(64 * NW, NW == 4 ? (D == 64 ? ATTN_FWD64_WAVES : 2) : 3) void attn_fwd_k(AttnArgs p) {
     constexpr int NT = 64 * NW, QB = 32 * NW;
     __shared__ __attribute__((aligned(16))) char lds[2 * 64 * D * 2];
     char* kimg = lds;
     char* vimg = lds + 64 * D * 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h2 = lane >> 5;
-    // causal: the last query blocks see the most keys -> dispatch them first
-    const int qb0 = (p.causal ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * QB, q0 = qb0 + wave * 32;
-    const int h = blockIdx.y, b = blockIdx.z, hk = h / (p.Hq / p.Hkv);
+    int qblk, h, b;
+    attn_work_item(p, (p.Sq + QB - 1) / QB, qblk, h, b);
+    const int qb0 = qblk * QB, q0 = qb0 + wave * 32;
+    const int hk = h / (p.Hq / p.Hkv);
     const int qcol = q0 + (lane & 31);
 
     const bf16_t* qptr = p.Q + (long)b * p.q_bs + (long)min(qcol, p.Sq - 1) * p.q_rs + (long)h * D;
@@ -212,14 +239,25 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 3) void attn_fwd_k(AttnArgs 
         rs += __shfl_xor(rs, 32, 64);
         l = l * alpha + rs;
         if constexpr (DROP) {
-            // inverted dropout of the probabilities that enter P·V (the normaliser l keeps the full sum)
+            // inverted dropout of the probabilities that enter P·V (the normaliser l keeps the full sum).  Accumulator
+            // registers 2j, 2j+1 are ADJACENT keys: with Sk even they are one element pair = one hash (common.h)
             const unsigned long rowbase = (((unsigned long)b * p.Hq + h) * p.Sq + min(qcol, p.Sq - 1)) * p.Sk;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kt * 64 + kb * 32 + acc_row(r, lane);
-                    st[kb][r] = desta_rng32(p.seed_lo, p.seed_hi, rowbase + key) >= p.drop_thresh ? st[kb][r] * p.drop_scale : 0.f;
+                for (int r = 0; r < 16; r += 2) {
+                    const unsigned long i0 = rowbase + (kt * 64 + kb * 32 + acc_row(r, lane));
+                    bool k0, k1;
+                    if ((p.Sk & 1) == 0) {
+                        const unsigned hsh = desta_rng32(p.seed_lo, p.seed_hi, i0 >> 1);
+                        k0 = (hsh & 0xffffu) >= p.drop_thresh;
+                        k1 = (hsh >> 16) >= p.drop_thresh;
+                    } else {
+                        k0 = desta_keep(p.seed_lo, p.seed_hi, i0, p.drop_thresh);
+                        k1 = desta_keep(p.seed_lo, p.seed_hi, i0 + 1, p.drop_thresh);
+                    }
+                    st[kb][r] = k0 ? st[kb][r] * p.drop_scale : 0.f;
+                    st[kb][r + 1] = k1 ? st[kb][r + 1] * p.drop_scale : 0.f;
                 }
         }
         if (__any(mnew != m)) {                            // rescale only when some row's max moved
@@ -316,9 +354,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? ATTN_DQ_BLOCKS : 3) void attn_bw
     char* kimg = lds;
     char* vimg = lds + 64 * D * 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h2 = lane >> 5;
-    // causal: the last query blocks see the most keys -> dispatch them first
-    const int qb0 = (p.causal ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * QB, q0 = qb0 + wave * 32;
-    const int h = blockIdx.y, b = blockIdx.z, hk = h / (p.Hq / p.Hkv);
+    int qblk, h, b;
+    attn_work_item(p, (p.Sq + QB - 1) / QB, qblk, h, b);
+    const int qb0 = qblk * QB, q0 = qb0 + wave * 32;
+    const int hk = h / (p.Hq / p.Hkv);
     const int qcol = q0 + (lane & 31), qc = min(qcol, p.Sq - 1);
 
     const bf16_t* qptr = p.Q + (long)b * p.q_bs + (long)qc * p.q_rs + (long)h * D;
@@ -374,6 +413,24 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? ATTN_DQ_BLOCKS : 3) void attn_bw
             }
             const bool need_mask = (kt * 64 + kb * 32 + 31 >= p.Sk) || (kt * 64 + kb * 32 < kv_lo) ||
                                    (p.causal && kt * 64 + kb * 32 + 31 > q0 + coff);
+            unsigned keep = 0xffffu;                                          // bit r: probability r of this lane survived dropout
+            if constexpr (DROP) {
+                // registers 2j, 2j+1 hold adjacent keys = one element pair = one hash when Sk is even (common.h)
+                const unsigned long rowbase = (((unsigned long)b * p.Hq + h) * p.Sq + qc) * p.Sk;
+                keep = 0;
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const unsigned long i0 = rowbase + (kt * 64 + kb * 32 + acc_row(r, lane));
+                    if ((p.Sk & 1) == 0) {
+                        const unsigned hsh = desta_rng32(p.seed_lo, p.seed_hi, i0 >> 1);
+                        keep |= ((hsh & 0xffffu) >= p.drop_thresh ? 1u : 0u) << r;
+                        keep |= ((hsh >> 16) >= p.drop_thresh ? 1u : 0u) << (r + 1);
+                    } else {
+                        keep |= (desta_keep(p.seed_lo, p.seed_hi, i0, p.drop_thresh) ? 1u : 0u) << r;
+                        keep |= (desta_keep(p.seed_lo, p.seed_hi, i0 + 1, p.drop_thresh) ? 1u : 0u) << (r + 1);
+                    }
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float pv = __builtin_amdgcn_exp2f(fmaf(st[r], p.scale_log2, -lse));
@@ -383,11 +440,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? ATTN_DQ_BLOCKS : 3) void attn_bw
                     pv = ok ? pv : 0.f;
                 }
                 float dpr = dp[r];
-                if constexpr (DROP) {
-                    const int key = kt * 64 + kb * 32 + acc_row(r, lane);
-                    const unsigned long idx = (((unsigned long)b * p.Hq + h) * p.Sq + qc) * p.Sk + key;
-                    dpr = desta_rng32(p.seed_lo, p.seed_hi, idx) >= p.drop_thresh ? dpr * p.drop_scale : 0.f;
-                }
+                if constexpr (DROP) dpr = ((keep >> r) & 1u) ? dpr * p.drop_scale : 0.f;
                 st[r] = pv * (dpr - dlt) * p.scale;        // dS^T
             }
 #pragma unroll
@@ -547,6 +600,33 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_k(AttnArgs p) {
                 lsv[4 * q4 + 0] = a4.x; lsv[4 * q4 + 1] = a4.y; lsv[4 * q4 + 2] = a4.z; lsv[4 * q4 + 3] = a4.w;
                 dlv[4 * q4 + 0] = b4.x; dlv[4 * q4 + 1] = b4.y; dlv[4 * q4 + 2] = b4.z; dlv[4 * q4 + 3] = b4.w;
             }
+            unsigned keep = 0xffffu;                                          // bit r: probability (query row r, this key) survived
+            if constexpr (DROP) {
+                const unsigned long hb = ((unsigned long)b * p.Hq + (hk * group + it / nq)) * p.Sq;
+                keep = 0;
+                if ((p.Sk & 1) == 0) {
+                    // lanes 2j, 2j+1 hold ADJACENT keys = one element pair = one hash (common.h): the even lane hashes query
+                    // rows 0..7 of the slice, the odd lane rows 8..15, and they swap through DPP (half the integer multiplies)
+                    const int half = lane & 1, kpair = k0 + (lane & 30);
+                    unsigned hh[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int ql = (j & 3) + 8 * (2 * half + (j >> 2)) + 4 * h2;           // acc_row(8 * half + j, lane)
+                        hh[j] = desta_rng32(p.seed_lo, p.seed_hi, ((hb + min(qb + ql, p.Sq - 1)) * p.Sk + kpair) >> 1);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const unsigned oth = (unsigned)__builtin_amdgcn_mov_dpp((int)hh[j], 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+                        const unsigned mine = half ? (hh[j] >> 16) : (hh[j] & 0xffffu), theirs = half ? (oth >> 16) : (oth & 0xffffu);
+                        keep |= (mine >= p.drop_thresh ? 1u : 0u) << (8 * half + j);
+                        keep |= (theirs >= p.drop_thresh ? 1u : 0u) << (8 * (1 - half) + j);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        keep |= (desta_keep(p.seed_lo, p.seed_hi, (hb + min(qb + acc_row(r, lane), p.Sq - 1)) * p.Sk + kc, p.drop_thresh) ? 1u : 0u) << r;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ql = acc_row(r, lane);
@@ -557,11 +637,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_k(AttnArgs p) {
                     pv = ok ? pv : 0.f;
                 }
                 float ms = 1.0f;
-                if constexpr (DROP) {
-                    const int hq = hk * group + it / nq;
-                    const unsigned long idx = (((unsigned long)b * p.Hq + hq) * p.Sq + min(qb + ql, p.Sq - 1)) * p.Sk + kc;
-                    ms = desta_rng32(p.seed_lo, p.seed_hi, idx) >= p.drop_thresh ? p.drop_scale : 0.f;
-                }
+                if constexpr (DROP) ms = ((keep >> r) & 1u) ? p.drop_scale : 0.f;
                 st[r] = pv * ms;                                             // (dropped) P for dV
                 dp[r] = pv * (ms * dp[r] - dlv[r]) * p.scale;                // dS
             }
@@ -636,8 +712,8 @@ extern "C" int desta_attention_fwd(const desta_attn_desc* d, void* stream) {
     if (int rc = fill_args(d, a)) return rc;
     DESTA_CHECK_ARG(d->O, "attention_fwd: null output");
     DESTA_CHECK_ARG(d->o_row_stride % 4 == 0, "attention_fwd: o_row_stride must be a multiple of 4");
-    dim3 grid((a.Sq + 127) / 128, a.Hq, a.B);
-    const bool two = d->head_dim == 64 && a.Sq <= 64;                  // 64-row blocks of two waves (Q-Former queries)
+    const bool two = d->head_dim == 64 && a.Sq <= 64;
+    dim3 grid((unsigned)((a.Sq + (two ? 63 : 127)) / (two ? 64 : 128)) * a.Hq * a.B);       // 1-D: attn_work_item() orders it per XCD                  // 64-row blocks of two waves (Q-Former queries)
     if (d->head_dim == 128) hipLaunchKernelGGL((attn_fwd_k<128, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
     else if (two && a.drop_thresh) hipLaunchKernelGGL((attn_fwd_k<64, true, 2>), grid, dim3(128), 0, (hipStream_t)stream, a);
     else if (two) hipLaunchKernelGGL((attn_fwd_k<64, false, 2>), grid, dim3(128), 0, (hipStream_t)stream, a);
@@ -685,7 +761,8 @@ extern "C" int desta_attention_bwd(const desta_attn_desc* d, float* workspace, v
     const long rows = (long)a.B * a.Hq * a.Sq;
     const int G = d->head_dim / 8;
     dim3 gd((unsigned)((rows * G + 255) / 256));
-    dim3 gq((a.Sq + 127) / 128, a.Hq, a.B);
+    const bool two_q = d->head_dim == 64 && a.Sq <= 64;
+    dim3 gq((unsigned)((a.Sq + (two_q ? 63 : 127)) / (two_q ? 64 : 128)) * a.Hq * a.B);
     dim3 gk((unsigned)((a.Sk + 127) / 128) * a.Hkv * a.B);
     if (d->head_dim == 128) {
         hipLaunchKernelGGL(attn_delta_k<128>, gd, dim3(256), 0, st, a, workspace);
@@ -701,7 +778,7 @@ extern "C" int desta_attention_bwd(const desta_attn_desc* d, float* workspace, v
         }
     } else {
         hipLaunchKernelGGL(attn_delta_k<64>, gd, dim3(256), 0, st, a, workspace);
-        const bool two = a.Sq <= 64;
+        const bool two = two_q;
         if (a.drop_thresh) {
             if (two) hipLaunchKernelGGL((attn_bwd_dq_k<64, true, 2>), gq, dim3(128), 0, st, a);
             else hipLaunchKernelGGL((attn_bwd_dq_k<64, true>), gq, dim3(256), 0, st, a);

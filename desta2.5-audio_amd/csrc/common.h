@@ -107,10 +107,17 @@ __device__ __forceinline__ unsigned desta_rng32(unsigned seed_lo, unsigned seed_
     x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
     return x;
 }
-// keep-threshold for drop probability p: element kept iff rng >= thresh
+// Dropout decision of element `idx`: ONE 32-bit hash serves the element PAIR (idx >> 1) — the even element takes the low 16
+// bits, the odd one the high 16 — kept iff its 16 bits >= thresh16 = round(p * 65536) (p resolved to 1.5e-5).  Kernels that
+// hold adjacent elements on one lane (attention probabilities: adjacent keys) hash once per pair; the integer multiplies of
+// the hash are quarter rate on CDNA4 and were most of the Q-Former attention kernels' VALU time at one hash per element.
 __host__ __device__ inline unsigned desta_drop_thresh(float p) {
-    const double t = (double)p * 4294967296.0;
-    return t >= 4294967295.0 ? 0xffffffffu : (unsigned)t;
+    const double t = (double)p * 65536.0 + 0.5;
+    return t >= 65535.0 ? 0xffffu : (t < 1.0 ? 1u : (unsigned)t);
+}
+__device__ __forceinline__ bool desta_keep(unsigned seed_lo, unsigned seed_hi, unsigned long idx, unsigned thresh16) {
+    const unsigned h = desta_rng32(seed_lo, seed_hi, idx >> 1);
+    return ((idx & 1) ? (h >> 16) : (h & 0xffffu)) >= thresh16;
 }
 
 // XCD-aware bijective remap of a 1-D block id: blocks that share an XCD (id % 8) get a contiguous

@@ -43,6 +43,7 @@ struct GemmArgs {
     int tilesM, tilesN;
     int full_tiles, split;                              // 256-kernel: tiles [0,full) whole-K; the rest in `split` K-slices
     float* ws;                                          // fp32 partial slabs [(tile-full)*split + slice][256][256]
+    int* tickets;                                       // per split tile: arrivals of its K-slices (in-kernel reduction) or null
     const float* rms_w; float rms_eps;                  // skinny kernel: RMSNorm(A rows; weight rms_w) applied on the fly
 };
 
@@ -101,7 +102,7 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& p, int z, int m, int n
     if (p.drop_thresh) {
         const unsigned long base = ((unsigned long)z * p.M + m) * p.N + n0;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = desta_rng32(p.seed_lo, p.seed_hi, base + e) >= p.drop_thresh ? v[e] * p.drop_scale : 0.f;
+        for (int e = 0; e < 4; ++e) v[e] = desta_keep(p.seed_lo, p.seed_hi, base + e, p.drop_thresh) ? v[e] * p.drop_scale : 0.f;
     }
     if (p.res) {
         if (p.res_f32) {
@@ -541,7 +542,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the dummy tail loads before LDS is released
 
     if (partial) {
-        // raw fp32 accumulators -> this item's slab; the fix-up kernel sums the slices in order
+        // raw fp32 accumulators -> this item's slab
         float* slab = p.ws + ((long)z * (p.tilesM * p.tilesN - p.full_tiles) * p.split +
                               (long)(blockIdx.x - p.full_tiles)) * (256 * 256);
 #pragma unroll
@@ -549,6 +550,56 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 *(f32x4*)(slab + (wm * 128 + i * 16 + fr) * 256 + wn * 64 + j * 16 + fq * 4) = acc[i][j];
+        if (!p.tickets) return;                            // a fix-up launch sums the slices in order
+        // In-kernel reduction, scattered: once ALL `split` slices of the tile have arrived, slice s sums rows
+        // [256 s / split, 256 (s+1) / split) of the tile over the slabs IN SLICE ORDER (deterministic) and runs the epilogue on
+        // them.  (A single last-arriving block summing the whole tile reads `split` x 256 KB at one block's ~70 GB/s: measured
+        // 6 ms per step SLOWER than the fix-up launch.)  Hand-off per cdna_hip_programming.md Guideline 16: every storing wave
+        // drains its stores, workgroup barrier, lane 0 agent-scope release + arrival add, bounded poll, agent-scope acquire,
+        // barrier, plain loads.  All slices of a tail tile are among the last <= 256 work items of a one-block-per-CU grid, so
+        // they are resident together (or become so as earlier tiles retire: those never wait).  tickets[2 t] counts arrivals,
+        // tickets[2 t + 1] departures; the last to depart zeroes both for the next launch.
+        __shared__ int s_go;
+        int* tk = p.tickets + 2 * ((long)z * (p.tilesM * p.tilesN - p.full_tiles) + (L - p.full_tiles));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int spins = 0, ok = 1;
+            while (__hip_atomic_load(tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.split) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1 << 21)) { ok = 0; break; }                   // bounded: never hang (the tile is then left unwritten)
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            s_go = ok;
+        }
+        __syncthreads();
+        if (s_go) {
+            const float* s0 = p.ws + ((long)z * (p.tilesM * p.tilesN - p.full_tiles) + (L - p.full_tiles)) * p.split * (256 * 256);
+            const int r0 = 256 * slice / p.split, r1 = 256 * (slice + 1) / p.split;
+            for (int idx = tid; idx < (r1 - r0) * 64; idx += 512) {
+                const int ml = r0 + (idx >> 6), nl = (idx & 63) * 4;
+                const float* q = s0 + ml * 256 + nl;
+                f32x4 v = *(const f32x4*)q;
+                for (int s2 = 1; s2 < p.split; ++s2) {
+                    const f32x4 w = *(const f32x4*)(q + (long)s2 * (256 * 256));
+                    v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
+                }
+                const int m = brow + ml, n0 = bcol + nl;
+                if (m < p.M && n0 < p.N) epilogue4(p, z, m, n0, v);
+            }
+        }
+        __syncthreads();                                                       // every thread is done with the slabs
+        if (tid == 0) {
+            const int dpt = __hip_atomic_fetch_add(tk + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (dpt == p.split - 1) {
+                __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(tk + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         return;
     }
     // whole 32-column pairs inside N, bf16 output, no side outputs: wide-store epilogue (block-uniform choice;
@@ -1024,6 +1075,7 @@ static int g_force_variant = 0;   // 0 auto, 1 = 128x128, 2 = 256x256 lockstep, 
 extern "C" int desta_gemm_force_variant(int v) { g_force_variant = v; return DESTA_OK; }
 static int g_persistent = 0;      // automatic choice may use the persistent kernel (in-situ A/B: no gain)
 static int g_stagger = 1;         // automatic choice uses the staggered schedule
+static int g_inkernel_splitk = 0; // option 5: K-slices of tail tiles reduced inside the GEMM launch instead of by the fix-up launch (measured: no gain)
 static int g_phases2 = 1;         // automatic choice uses the 2-phase (32 MFMAs per phase) staggered schedule (+5-16 % on every shape)
 extern "C" int desta_gemm_set_persistent(int on) { g_persistent = on; return DESTA_OK; }
 static int g_skinny = 0;          // 0 auto, else COLS*10 + U of the skinny (M <= 16) kernel (tuning)
@@ -1039,6 +1091,7 @@ extern "C" int desta_gemm_set_option(int option, int value) {
         g_skinny = value;
     }
     else if (option == 4) g_phases2 = value;
+    else if (option == 5) g_inkernel_splitk = value;
     else if (option == 3) {
         if (value < 1 || value > 65535) { desta_set_error("gemm_set_option: skinny grid %d out of range", value); return DESTA_EINVAL; }
         g_skinny_blocks = value;
@@ -1095,7 +1148,7 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
             int sp = NCU / rem;
             if (sp > 8) sp = 8;
             if (sp > nk / 16) sp = nk / 16;              // >= 16 K-tiles per slice, or the 7-half-tile prologue dominates
-            if (sp >= 2 && (size_t)rem * sp * 256 * 256 * sizeof(float) <= d->workspace_bytes) { split = sp; full = (int)(T - rem); }
+            if (sp >= 2 && (size_t)rem * sp * 256 * 256 * sizeof(float) + 4096 <= d->workspace_bytes) { split = sp; full = (int)(T - rem); }
         }
     }
     a.rms_w = d->a_rms_weight; a.rms_eps = d->a_rms_eps;
@@ -1111,7 +1164,7 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
         int cols = 16, u = 2;
         if (g_skinny && d->act != 4) { cols = g_skinny / 10; u = g_skinny % 10; }
         const int ntiles = d->act == 4 ? (d->N + 7) / 8 : (d->N + cols - 1) / cols;
-        a.tilesM = 1; a.tilesN = ntiles; a.full_tiles = ntiles; a.split = 1; a.ws = nullptr;
+        a.tilesM = 1; a.tilesN = ntiles; a.full_tiles = ntiles; a.split = 1; a.ws = nullptr; a.tickets = nullptr;
         const dim3 grid(ntiles < g_skinny_blocks ? ntiles : g_skinny_blocks, d->batch);
         hipStream_t st = (hipStream_t)stream;
         const bool rms = a.rms_w != nullptr;
@@ -1142,6 +1195,11 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
         a.tilesM = tM; a.tilesN = tN;
         a.full_tiles = full; a.split = split; a.ws = (float*)d->workspace;
         const int items = full + (int)(T - full) * split;
+        // tickets: the last 4 KiB of the workspace (<= 128 split tiles); zero at first use (the caller hands over a zeroed
+        // workspace once) and self-resetting afterwards.  Only the plain (non-persistent) kernels carry the in-kernel reduce.
+        const bool persistent_ = g_force_variant == 4 || g_force_variant == 8 || (g_force_variant == 0 && g_persistent && items > NCU);
+        const bool inkernel = split > 1 && g_inkernel_splitk && !persistent_;
+        a.tickets = inkernel ? (int*)((char*)d->workspace + d->workspace_bytes - 4096) : nullptr;
         // variants: 2 = lockstep, 3 = staggered (+4-7 %), 4 = staggered + persistent cross-tile streaming
         //           (default when a block gets more than one item; +3-7 % on the LLM shapes)
         const bool persistent = g_force_variant == 4 || (g_force_variant == 0 && g_persistent && items > NCU);
@@ -1151,11 +1209,11 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
         else if (g_force_variant == 6 || (g_force_variant == 0 && g_phases2)) hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<true, 2>), dim3(items, d->batch), dim3(512), 0, (hipStream_t)stream, a);
         else if (g_force_variant == 7) hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<false, 2>), dim3(items, d->batch), dim3(512), 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<true, 4>), dim3(items, d->batch), dim3(512), 0, (hipStream_t)stream, a);
-        if (split > 1)
+        if (split > 1 && !inkernel)
             hipLaunchKernelGGL(gemm_splitk_fixup_kernel, dim3((unsigned)(T - full) * 64, d->batch), dim3(256), 0, (hipStream_t)stream, a);
     } else {
         a.tilesM = (d->M + BM - 1) / BM; a.tilesN = (d->N + BN - 1) / BN;
-        a.full_tiles = a.tilesM * a.tilesN; a.split = 1; a.ws = nullptr;
+        a.full_tiles = a.tilesM * a.tilesN; a.split = 1; a.ws = nullptr; a.tickets = nullptr;
         dim3 grid(a.tilesM * a.tilesN, d->batch);
         if (d->trans_a && d->trans_b) hipLaunchKernelGGL((gemm_bf16_nt_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
         else if (d->trans_b) hipLaunchKernelGGL((gemm_bf16_nt_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, a);

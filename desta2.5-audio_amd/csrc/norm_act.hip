@@ -542,13 +542,13 @@ __global__ __launch_bounds__(256) void dropout_bf16_k(const bf16_t* __restrict__
         u16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            o[e] = desta_rng32(slo, shi, (unsigned long)(r * cols + c + e)) >= thresh ? f2bf(bf2f(v[e]) * scale) : (bf16_t)0;
+            o[e] = desta_keep(slo, shi, (unsigned long)(r * cols + c + e), thresh) ? f2bf(bf2f(v[e]) * scale) : (bf16_t)0;
         *(u16x4*)(y + r * ld + c) = o;
     }
 }
 __global__ __launch_bounds__(256) void dropout_mask_k(unsigned slo, unsigned shi, long n, unsigned thresh, uint8_t* __restrict__ out) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
-        out[i] = desta_rng32(slo, shi, (unsigned long)i) >= thresh ? 1 : 0;
+        out[i] = desta_keep(slo, shi, (unsigned long)i, thresh) ? 1 : 0;
 }
 
 // greedy decoding: out[r] = argmax_c x[r][c] (first maximum, like torch.argmax).  Keys order by value, then by

@@ -100,7 +100,7 @@ def gemm(A, B, out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, residua
     st = stream()
     ws = _gemm_ws.get((A.device, st))                       # one split-K scratch per STREAM: GEMMs of one stream run serially,
     if ws is None:                                          # GEMMs of two streams (encoder prefetch beside the LLM) must not share it
-        ws = _gemm_ws[(A.device, st)] = torch.empty(GEMM_WS_BYTES // 4, dtype=torch.float32, device=A.device)
+        ws = _gemm_ws[(A.device, st)] = torch.zeros(GEMM_WS_BYTES // 4, dtype=torch.float32, device=A.device)   # zeroed: the arrival tickets of the in-kernel split-K reduce live in its last 4 KiB
     d.workspace, d.workspace_bytes = ws.data_ptr(), GEMM_WS_BYTES
     if _gemm_prof is not None:
         # HIP events on the launch stream around this one kernel (bench.py roofline leg)
@@ -121,7 +121,7 @@ def rms_fusable(M: int, K: int) -> bool:
 
 _gemm_prof = None
 _gemm_ws = {}                      # (device, stream) -> split-K scratch
-GEMM_WS_BYTES = 64 << 20
+GEMM_WS_BYTES = (64 << 20) + 4096
 
 
 def gemm_profile_start():

@@ -68,7 +68,10 @@ typedef struct desta_gemm_desc {
     float dropout_p;                   /* > 0: inverted dropout of act(acc+bias) BEFORE the residual add, mask */
     uint64_t dropout_seed;             /*   = desta_dropout_mask(seed, m*N + n) (BertSelfOutput/BertOutput, p=0.1) */
     void* workspace;                   /* optional fp32 scratch for the split-K tail (NULL = never split);   */
-    size_t workspace_bytes;            /* 64 MiB covers every shape (<= 256 slabs of 256x256 fp32)            */
+    size_t workspace_bytes;            /* 64 MiB + 4 KiB covers every shape (<= 256 slabs of 256x256 fp32);   */
+                                       /* its LAST 4 KiB are the arrival tickets of the in-kernel K-slice     */
+                                       /* reduction: zero when first handed over, self-resetting afterwards;  */
+                                       /* one workspace per stream (two concurrent GEMMs must not share it)   */
     int trans_a, trans_b;              /* != 0: the operand is stored transposed, A as [K,M] (lda = row stride), B as   */
                                        /*   [K,N]: autograd's dW = dY^T X (both) and dX = dY W (trans_b) without a        */
                                        /*   materialised transpose; M resp. N must be a multiple of 8                     */

@@ -1,7 +1,7 @@
 """Per-step kernel-time breakdown from a rocprofv3 kernel trace of bench.py (steady-state steps only).
   rocprofv3 --kernel-trace --output-format csv -d DIR -o tr -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline
   python tools/step_breakdown.py DIR/tr_kernel_trace.csv [out.csv]
-Steps are delimited by the Adafactor update kernel (`af_update`, one launch per step); the first 3 and the last delimited
+Steps are delimited by the Adafactor update kernel (`af_stats`, one launch per step); the first 3 and the last delimited
 intervals are dropped (warm-up / teardown)."""
 import collections
 import csv
@@ -17,11 +17,12 @@ def short(name):
 
 
 def main():
-    rows = list(csv.DictReader(open(sys.argv[1])))
+    import gzip
+    rows = list(csv.DictReader(gzip.open(sys.argv[1], "rt") if sys.argv[1].endswith(".gz") else open(sys.argv[1])))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    marks = [int(r["Start_Timestamp"]) for r in rows if "k34_update" in r["Kernel_Name"] or "af_update" in r["Kernel_Name"]]
+    marks = [int(r["Start_Timestamp"]) for r in rows if "af_stats" in r["Kernel_Name"] or "k1_stats" in r["Kernel_Name"]]
     if len(marks) < 5:
-        raise SystemExit("could not find the per-step Adafactor launches (k34_update)")
+        raise SystemExit("could not find the per-step Adafactor launches (af_stats)")
     # one mark per step: collapse marks closer than 20 ms
     steps = [marks[0]]
     for m in marks[1:]:
