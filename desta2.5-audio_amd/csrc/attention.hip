@@ -149,7 +149,7 @@ __device__ __forceinline__ void attn_work_item(const AttnArgs& p, int nq, int& q
 #define ATTN_FWD64_WAVES 3
 #endif
 template <int D, bool DROP, int NW = 4>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? (D == 64 ? ATTN_FWD64_WAVES : 2) : 3) void attn_fwd_k(AttnArgs p) {
+__global__ __launch_bounds__(64 * NW, NW == 4 ? (D == 64 ? ATTN_FWD64_WAVES : 2) : 2) void attn_fwd_k(AttnArgs p) {
     constexpr int NT = 64 * NW, QB = 32 * NW;
     __shared__ __attribute__((aligned(16))) char lds[2 * 64 * D * 2];
     char* kimg = lds;
@@ -240,24 +240,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (D == 64 ? ATTN_FWD64_WAVES : 2)
         l = l * alpha + rs;
         if constexpr (DROP) {
             // inverted dropout of the probabilities that enter P·V (the normaliser l keeps the full sum).  Accumulator
-            // registers 2j, 2j+1 are ADJACENT keys: with Sk even they are one element pair = one hash (common.h)
+            // registers 2j, 2j+1 are ADJACENT keys = one element pair = one hash (common.h; Sk even is checked on the host)
             const unsigned long rowbase = (((unsigned long)b * p.Hq + h) * p.Sq + min(qcol, p.Sq - 1)) * p.Sk;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const unsigned long i0 = rowbase + (kt * 64 + kb * 32 + acc_row(r, lane));
-                    bool k0, k1;
-                    if ((p.Sk & 1) == 0) {
-                        const unsigned hsh = desta_rng32(p.seed_lo, p.seed_hi, i0 >> 1);
-                        k0 = (hsh & 0xffffu) >= p.drop_thresh;
-                        k1 = (hsh >> 16) >= p.drop_thresh;
-                    } else {
-                        k0 = desta_keep(p.seed_lo, p.seed_hi, i0, p.drop_thresh);
-                        k1 = desta_keep(p.seed_lo, p.seed_hi, i0 + 1, p.drop_thresh);
-                    }
-                    st[kb][r] = k0 ? st[kb][r] * p.drop_scale : 0.f;
-                    st[kb][r + 1] = k1 ? st[kb][r + 1] * p.drop_scale : 0.f;
+                    const unsigned hsh = desta_rng32(p.seed_lo, p.seed_hi, i0 >> 1);     // Sk is even (host check): i0 is even
+                    st[kb][r] = (hsh & 0xffffu) >= p.drop_thresh ? st[kb][r] * p.drop_scale : 0.f;
+                    st[kb][r + 1] = (hsh >> 16) >= p.drop_thresh ? st[kb][r + 1] * p.drop_scale : 0.f;
                 }
         }
         if (__any(mnew != m)) {                            // rescale only when some row's max moved
@@ -348,7 +340,7 @@ __global__ __launch_bounds__(256) void attn_delta_k(AttnArgs p, float* __restric
 #define ATTN_DQ_BLOCKS 2
 #endif
 template <int D, bool DROP, int NW = 4>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? ATTN_DQ_BLOCKS : 3) void attn_bwd_dq_k(AttnArgs p) {
+__global__ __launch_bounds__(64 * NW, NW == 4 ? ATTN_DQ_BLOCKS : 2) void attn_bwd_dq_k(AttnArgs p) {
     constexpr int NT = 64 * NW, QB = 32 * NW;
     __shared__ __attribute__((aligned(16))) char lds[2 * 64 * D * 2];
     char* kimg = lds;
@@ -415,20 +407,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? ATTN_DQ_BLOCKS : 3) void attn_bw
                                    (p.causal && kt * 64 + kb * 32 + 31 > q0 + coff);
             unsigned keep = 0xffffu;                                          // bit r: probability r of this lane survived dropout
             if constexpr (DROP) {
-                // registers 2j, 2j+1 hold adjacent keys = one element pair = one hash when Sk is even (common.h)
+                // registers 2j, 2j+1 hold adjacent keys = one element pair = one hash (common.h; Sk even: host check)
                 const unsigned long rowbase = (((unsigned long)b * p.Hq + h) * p.Sq + qc) * p.Sk;
                 keep = 0;
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const unsigned long i0 = rowbase + (kt * 64 + kb * 32 + acc_row(r, lane));
-                    if ((p.Sk & 1) == 0) {
-                        const unsigned hsh = desta_rng32(p.seed_lo, p.seed_hi, i0 >> 1);
-                        keep |= ((hsh & 0xffffu) >= p.drop_thresh ? 1u : 0u) << r;
-                        keep |= ((hsh >> 16) >= p.drop_thresh ? 1u : 0u) << (r + 1);
-                    } else {
-                        keep |= (desta_keep(p.seed_lo, p.seed_hi, i0, p.drop_thresh) ? 1u : 0u) << r;
-                        keep |= (desta_keep(p.seed_lo, p.seed_hi, i0 + 1, p.drop_thresh) ? 1u : 0u) << (r + 1);
-                    }
+                    const unsigned hsh = desta_rng32(p.seed_lo, p.seed_hi, i0 >> 1);
+                    keep |= ((hsh & 0xffffu) >= p.drop_thresh ? 1u : 0u) << r;
+                    keep |= ((hsh >> 16) >= p.drop_thresh ? 1u : 0u) << (r + 1);
                 }
             }
 #pragma unroll
@@ -604,27 +591,21 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_k(AttnArgs p) {
             if constexpr (DROP) {
                 const unsigned long hb = ((unsigned long)b * p.Hq + (hk * group + it / nq)) * p.Sq;
                 keep = 0;
-                if ((p.Sk & 1) == 0) {
-                    // lanes 2j, 2j+1 hold ADJACENT keys = one element pair = one hash (common.h): the even lane hashes query
-                    // rows 0..7 of the slice, the odd lane rows 8..15, and they swap through DPP (half the integer multiplies)
-                    const int half = lane & 1, kpair = k0 + (lane & 30);
-                    unsigned hh[8];
+                // lanes 2j, 2j+1 hold ADJACENT keys = one element pair = one hash (common.h; Sk even: host check): the even lane
+                // hashes query rows 0..7 of the slice, the odd lane rows 8..15, and they swap through DPP (half the integer multiplies)
+                const int half = lane & 1, kpair = k0 + (lane & 30);
+                unsigned hh[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int ql = (j & 3) + 8 * (2 * half + (j >> 2)) + 4 * h2;           // acc_row(8 * half + j, lane)
-                        hh[j] = desta_rng32(p.seed_lo, p.seed_hi, ((hb + min(qb + ql, p.Sq - 1)) * p.Sk + kpair) >> 1);
-                    }
+                for (int j = 0; j < 8; ++j) {
+                    const int ql = (j & 3) + 8 * (2 * half + (j >> 2)) + 4 * h2;               // acc_row(8 * half + j, lane)
+                    hh[j] = desta_rng32(p.seed_lo, p.seed_hi, ((hb + min(qb + ql, p.Sq - 1)) * p.Sk + kpair) >> 1);
+                }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const unsigned oth = (unsigned)__builtin_amdgcn_mov_dpp((int)hh[j], 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
-                        const unsigned mine = half ? (hh[j] >> 16) : (hh[j] & 0xffffu), theirs = half ? (oth >> 16) : (oth & 0xffffu);
-                        keep |= (mine >= p.drop_thresh ? 1u : 0u) << (8 * half + j);
-                        keep |= (theirs >= p.drop_thresh ? 1u : 0u) << (8 * (1 - half) + j);
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        keep |= (desta_keep(p.seed_lo, p.seed_hi, (hb + min(qb + acc_row(r, lane), p.Sq - 1)) * p.Sk + kc, p.drop_thresh) ? 1u : 0u) << r;
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned oth = (unsigned)__builtin_amdgcn_mov_dpp((int)hh[j], 0xB1, 0xf, 0xf, true);       // quad_perm [1,0,3,2]
+                    const unsigned mine = half ? (hh[j] >> 16) : (hh[j] & 0xffffu), theirs = half ? (oth >> 16) : (oth & 0xffffu);
+                    keep |= (mine >= p.drop_thresh ? 1u : 0u) << (8 * half + j);
+                    keep |= (theirs >= p.drop_thresh ? 1u : 0u) << (8 * (1 - half) + j);
                 }
             }
 #pragma unroll
@@ -699,6 +680,7 @@ int fill_args(const desta_attn_desc* d, AttnArgs& a) {
     a.scale = d->scale; a.scale_log2 = d->scale * 1.44269504088896340736f;
     DESTA_CHECK_ARG(d->dropout_p >= 0.f && d->dropout_p < 1.f, "attention: dropout_p must be in [0,1)");
     DESTA_CHECK_ARG(d->dropout_p == 0.f || d->head_dim == 64, "attention: dropout is built for head_dim 64 (the Q-Former) only");
+    DESTA_CHECK_ARG(d->dropout_p == 0.f || d->seq_k % 2 == 0, "attention: dropout needs an even seq_k (adjacent keys share one hash)");
     a.drop_thresh = d->dropout_p > 0.f ? desta_drop_thresh(d->dropout_p) : 0u;
     a.drop_scale = 1.0f / (1.0f - d->dropout_p);
     a.seed_lo = (unsigned)d->dropout_seed; a.seed_hi = (unsigned)(d->dropout_seed >> 32);

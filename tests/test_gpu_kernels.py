@@ -393,7 +393,7 @@ def test_adafactor_connector_shapes(hip):
     """Shapes of the real connector tensors (largest: 1280x3072, 4096x1280) incl. the 3-D prompts."""
     shapes = [(64, 4), (1, 64, 1280), (3072, 1280), (3072,), (1280, 3072), (1280,), (4096, 1280), (4096,)]
     _, opt = _run_adafactor_case(hip, shapes, steps=2, gscale=[0.02, 3.0])
-    assert opt.plan.n_groups >= 2                      # 13 M gradient floats: two (sum u^2, apply) launch pairs
+    assert opt.plan.n_groups >= 1 and opt.plan.max_chunks_per_tensor == 320
 
 
 def test_adafactor_ragged_rows_take_the_two_launch_path(hip):

@@ -35,11 +35,13 @@ for name, (B, Hq, Hkv, S, D, causal) in {"llm S=640 D=128 causal GQA": (8, 32, 8
         do = torch.randn(B * Sq, wq, generator=g, device="cuda").to(torch.bfloat16)
         lse = torch.zeros(B, Hq, Sq, device="cuda")
         dq, dkv = torch.zeros_like(q), torch.zeros_like(kv)
-        d = hip.attn_desc(q, kv, kv, o, lse, batch=B, hq=Hq, hkv=Hkv, sq=Sq, sk=Sk, hd=D, scale=D ** -0.5, q_off=0, k_off=0, v_off=wkv)
-        f = t_us(lambda: hip.attention_fwd(d))
-        bw = t_us(lambda: hip.attention_bwd(d, do, dq, dkv, dkv, dk_off=0, dv_off=wkv))
-        fl = 4.0 * B * Hq * Sq * Sk * D
-        print(f"{name:30s} fwd {f:7.1f} us ({fl / f / 1e6:6.0f} TF/s)   bwd {bw:7.1f} us ({2.5 * fl / bw / 1e6:6.0f} TF/s)", flush=True)
+        for pd in (0.0, 0.1):                             # training runs the probability-dropout variants (BertConfig default 0.1)
+            d = hip.attn_desc(q, kv, kv, o, lse, batch=B, hq=Hq, hkv=Hkv, sq=Sq, sk=Sk, hd=D, scale=D ** -0.5, q_off=0, k_off=0, v_off=wkv,
+                              dropout_p=pd, dropout_seed=1234)
+            f = t_us(lambda: hip.attention_fwd(d))
+            bw = t_us(lambda: hip.attention_bwd(d, do, dq, dkv, dkv, dk_off=0, dv_off=wkv))
+            fl = 4.0 * B * Hq * Sq * Sk * D
+            print(f"{name + f' p={pd}':38s} fwd {f:7.1f} us ({fl / f / 1e6:6.0f} TF/s)   bwd {bw:7.1f} us ({2.5 * fl / bw / 1e6:6.0f} TF/s)", flush=True)
         continue
     qkv = torch.randn(B * S, wq + 2 * wkv, generator=g, device="cuda").to(torch.bfloat16)
     o = torch.zeros(B * S, wq, dtype=torch.bfloat16, device="cuda")
