@@ -239,6 +239,14 @@ def rope_inv_freq(c: LLMConfig) -> torch.Tensor:
     return inv.float()
 
 
+@dataclass
+class GenerationOutput:
+    """modeling_desta25.py:492-496"""
+    audios: list
+    generated_ids: list
+    text: list
+
+
 class _Out:
     """`CausalLMOutputWithPast`-shaped result (`.loss` 0-d fp32 tensor, `.logits` [B,S,V])."""
 
@@ -1136,12 +1144,98 @@ class DeSTA25AudioModel:
         finally:
             self.training = was_training
 
-    def generate(self, messages, *args, **kwargs):
-        """The reference's chat-level `generate` (modeling_desta25.py:1491-1730) also runs the tokenizer, the
-        Whisper processor, optional VAD and Whisper ASR on audio FILES; none of that is on the MI355X hot path.
-        Build the batch with the reference's processor/collate code and call `_generate_step(batch, …)`."""
-        raise NotImplementedError("chat-level generate() (tokenizer + audio-file front end) is out of scope of the MI355X hot path; "
-                                  "use _generate_step(inputs, pad_token_id, do_sample=False, max_new_tokens=…) on a collated batch")
+    def _setup_generation(self, tokenizer=None, processor=None, vad=None, asr=None):
+        """The reference builds these from hub names (modeling_desta25.py:1465-1487): AutoTokenizer of the LLM (+ the audio locator
+        token), the Whisper AutoProcessor, silero VAD from torch.hub and Whisper's own decoder for ASR.  Offline they are
+        injected: `tokenizer` any object with the HF tokenizer call protocol, `processor` defaults to the device log-mel
+        (`HipLogMelProcessor`), `vad(samples) -> truthy when the clip has speech` (default: every clip has speech), `asr(list of
+        waveforms) -> list of str` (default: none — the Whisper DECODER is not on the hot path, so an audio with speech needs
+        its "text" in the message)."""
+        if tokenizer is not None:
+            self.tokenizer = tokenizer
+        if not hasattr(self, "tokenizer"):
+            raise RuntimeError("generate() needs a tokenizer: model._setup_generation(tokenizer=...) (no hub access to build one by name)")
+        tok = self.tokenizer
+        tok.pad_token, tok.pad_token_id = tok.eos_token, tok.eos_token_id              # reference :1468-1469, unconditionally
+        tok.padding_side = "left"
+        if hasattr(tok, "add_tokens"):
+            tok.add_tokens([self.audio_locator])
+        assert len(tok.tokenize(self.audio_locator)) == 1, "audio_locator must be a single token"
+        assert len(tok.tokenize(self.placeholder_token)) == 1, "placeholder_token must be a single token in the tokenizer"
+        if processor is not None or not hasattr(self, "processor"):
+            from ..utils.audio import HipLogMelProcessor
+            self.processor = processor or HipLogMelProcessor(self.config.encoder_config.num_mel_bins, self.device)
+        if vad is not None or not hasattr(self, "get_speech_timestamps"):
+            self.get_speech_timestamps = vad
+        if asr is not None or not hasattr(self, "asr"):
+            self.asr = asr
+
+    def generate(self, messages, temperature=0.7, top_p=0.9, do_sample=True, max_new_tokens=512, seed=0):
+        """The reference's chat-level `generate` (modeling_desta25.py:1491-1721): messages -> audio decode -> log-mel -> placeholder
+        expansion of every `<|AUDIO|>` -> left-padded tokenisation, pad-shifted start positions, transcription ids ->
+        `_generate_step` -> `GenerationOutput(text, audios, generated_ids)`.  Same messages schema, same errors; the front-end
+        models (tokenizer / VAD / ASR) are injected through `_setup_generation`."""
+        from ..trainer.data.simple_dataset import prepare_audio_context_and_start_positions
+        from ..utils.audio import AudioSegment
+        if not hasattr(self, "tokenizer") or not hasattr(self, "processor"):
+            self._setup_generation()
+        tok = self.tokenizer
+        if not isinstance(messages, list):
+            raise ValueError("messages should be a list of dictionaries or a list of lists.")
+        conversations = [messages] if isinstance(messages[0], dict) else messages
+        audios, texts = [], []
+        for conv in conversations:
+            for m in conv:
+                au = m.get("audios", [])
+                assert len(au) == m["content"].count(self.audio_locator), "audio count does not match (<|AUDIO|>) count"
+                audios += [a["audio"] for a in au]
+                texts += [a.get("text") for a in au]
+        if not audios:
+            # no audio: plain LLM generation on the chat template; stops on eos or <|eot_id|>
+            enc = tok(tok.apply_chat_template(conversations, tokenize=False, add_generation_prompt=True), return_tensors="pt", padding=True)
+            inputs = {"context_input_ids": enc["input_ids"], "context_attention_mask": enc["attention_mask"],
+                      "context_batch_start_positions": [], "batch_transcription_ids": [], "batch_features": None}
+            ids = self._generate_step(inputs, pad_token_id=tok.pad_token_id, temperature=temperature, top_p=top_p, max_new_tokens=max_new_tokens,
+                                      do_sample=do_sample, eos_token_id=[tok.eos_token_id, tok.convert_tokens_to_ids("<|eot_id|>")], seed=seed)
+            rows = [r.tolist() for r in ids]
+            return GenerationOutput(text=tok.batch_decode(rows, skip_special_tokens=True), audios=[], generated_ids=rows)
+        waves, need_asr = [], []
+        for i, (a, t) in enumerate(zip(audios, texts)):
+            if isinstance(a, str) and not os.path.exists(a):
+                raise ValueError(f"Audio file {a} does not exist.")
+            w = AudioSegment.from_file(a, target_sr=16000, channel_selector="average").samples
+            waves.append(w)
+            speech = True if self.get_speech_timestamps is None else bool(self.get_speech_timestamps(w))
+            if speech and t is None:
+                need_asr.append(i)
+            if not speech:
+                texts[i] = " "
+        if need_asr:
+            if self.asr is None:
+                raise NotImplementedError("an audio with speech and no 'text' needs ASR; the Whisper decoder is not on the MI355X hot path: "
+                                          "pass the transcription in the message or inject asr= through _setup_generation")
+            for i, t in zip(need_asr, self.asr([waves[i] for i in need_asr])):
+                texts[i] = t.strip()
+        feats = self.processor(waves, sampling_rate=16000, return_tensors="pt").input_features
+        n = len(waves)
+        audio_sizes, tr_sizes = [self.config.prompt_size] * n, [len(tok.tokenize(t, add_special_tokens=False)) for t in texts]
+        contexts, starts = [], []
+        for conv in conversations:
+            ctx = tok.apply_chat_template(conv, tokenize=False, add_generation_prompt=True)
+            ctx = ctx.replace(self.audio_locator, f"<start_audio>{self.audio_locator}<end_audio>")      # the training-time indicator
+            toks, st = prepare_audio_context_and_start_positions(tok.tokenize(ctx), self.audio_locator, audio_sizes, tr_sizes, self.placeholder_token)
+            contexts.append(tok.convert_tokens_to_string(toks))
+            starts.append(st)
+        enc = tok(contexts, truncation=True, padding="longest", return_tensors="pt", return_length=True, add_special_tokens=False)
+        pad = torch.as_tensor(enc["length"], dtype=torch.long) - enc["attention_mask"].sum(dim=1)
+        inputs = {"batch_features": feats,
+                  "batch_transcription_ids": [tok.encode(t, add_special_tokens=False, return_tensors="pt").long() for t in texts],
+                  "context_input_ids": enc["input_ids"], "context_attention_mask": enc["attention_mask"],
+                  "context_batch_start_positions": [(i, s + pad[i]) for i in range(len(starts)) for s in starts[i]]}
+        self._last_generate_inputs = inputs
+        ids = self._generate_step(inputs, pad_token_id=tok.pad_token_id, temperature=temperature, top_p=top_p, max_new_tokens=max_new_tokens,
+                                  do_sample=do_sample, seed=seed)
+        return GenerationOutput(text=tok.batch_decode(ids, skip_special_tokens=True), audios=list(zip(audios, texts)), generated_ids=ids.tolist())
 
     def _target_rows(self, labels, B: int, S: int, s_major: bool = False):
         """Index list / compact labels / host-visible count of the rows that carry a target, on a side stream: it waits for

@@ -13,6 +13,13 @@
  *   - every call only ENQUEUES work on `stream` (no allocation, no host sync: graph-capturable);
  *   - return value: 0 = ok, <0 = error (DESTA_EINVAL -1, DESTA_ELAUNCH -2); nothing throws across
  *     the ABI; `desta_last_error()` returns a thread-local message for the last failure;
+ *   - state: the data path has none besides what the caller passes in (buffers, descriptors, plans, stream).  The only
+ *     process-wide variables are (a) the thread-local error text, (b) TUNING / DIAGNOSTIC switches for A/B runs
+ *     (`desta_gemm_set_option`, `desta_gemm_force_variant`, `desta_attention_set_concurrent_bwd`,
+ *     `desta_gemm_last_kernel`): defaults are what every test and benchmark runs, a data path never needs to touch them,
+ *     and they are not synchronised (set them before launching work from several threads, or not at all), and (c) one
+ *     internal side stream + two events per DEVICE for the attention backward's dQ / dK,dV fork (created on first use,
+ *     joined before the call returns to the caller's stream);
  *   - caller owns every buffer including workspaces (`*_workspace_bytes` helpers say how much);
  *   - bf16 tensors are `uint16_t` bit patterns; "rows" are always the slow index, row-major.
  */

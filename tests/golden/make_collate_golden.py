@@ -120,6 +120,50 @@ def main():
                             rec["metadata_ids"] = [os.path.basename(m["processed_audios"][0]["audio"]) for m in b["metadata"]]
                         case["collate"].append(rec)
                 out[f"{name}|system={'yes' if system_prompt else 'no'}"] = case
+    # chat-level generate() (modeling_desta25.py:1491-1721): the reference's own method on an object assembled with __new__, the
+    # front-end models stubbed (toy tokenizer, recording processor, a VAD that finds speech only in g1 / g2, an ASR stand-in
+    # for the Whisper decoder), `_generate_step` replaced by a recorder -> the `inputs` dict it is handed is the golden
+    from helpers import GENERATE_MESSAGES
+    from desta.models import modeling_desta25 as M
+
+    def wave(path, **kw):
+        return types.SimpleNamespace(samples=wave_for(os.path.basename(path)))
+    M.AudioSegment = types.SimpleNamespace(from_file=wave)
+    with tempfile.TemporaryDirectory() as root:
+        msgs = json.loads(json.dumps(GENERATE_MESSAGES))
+        for conv in msgs:
+            for m in conv:
+                for a in m.get("audios", []):
+                    a["audio"] = os.path.join(root, a["audio"])
+                    open(a["audio"], "wb").close()
+        captured = {}
+
+        class R(M.DeSTA25AudioModel):
+            device = torch.device("cpu")
+
+            def _generate_step(self, inputs, **kw):
+                captured["inputs"], captured["kw"] = inputs, kw
+                return torch.tensor([[11, 12, 2], [13, 2, 0]])
+        ref = R.__new__(R)
+        torch.nn.Module.__init__(ref)
+        tok = ToyTokenizer()
+        tok.pad_token, tok.pad_token_id = tok.eos_token, tok.eos_token_id
+        ref.tokenizer, ref.processor = tok, StubProcessor()
+        ref.config = types.SimpleNamespace(prompt_size=64, connector_mode="qformer_1")
+        ref.audio_locator, ref.placeholder_token = "<|AUDIO|>", "<|video_pad|>"
+        ref.vad_model = object()
+        ref.get_speech_timestamps = lambda feat, model: [1] if len(feat) != len(wave_for("g3.wav")) else []
+        ref.perception = types.SimpleNamespace(whisper=types.SimpleNamespace(generate=lambda **kw: torch.tensor([[7, 8, 9]])))
+        ref.processor.batch_decode = lambda ids, skip_special_tokens=True: [" spoken words "]
+        outg = M.DeSTA25AudioModel.generate(ref, msgs, do_sample=False, max_new_tokens=3)
+        gi = captured["inputs"]
+        out["generate_with_audio"] = {
+            "context_input_ids": gi["context_input_ids"].tolist(), "context_attention_mask": gi["context_attention_mask"].tolist(),
+            "context_batch_start_positions": [[int(i), int(sp)] for i, sp in gi["context_batch_start_positions"]],
+            "batch_transcription_ids": [t.tolist() for t in gi["batch_transcription_ids"]],
+            "n_features": int(gi["batch_features"].shape[0]), "processor_calls": ref.processor.calls,
+            "kw": {k: v for k, v in captured["kw"].items()}, "text": outg.text, "generated_ids": outg.generated_ids,
+            "audios": [[os.path.basename(a), t] for a, t in outg.audios]}
     # placeholder expansion helper on its own (modeling_desta25.py:99-123), incl. two audios + transcription sizes
     from desta.models.modeling_desta25 import _prepare_audio_context_and_start_positions as prep
     toks = "a <|AUDIO|> b c <|AUDIO|> d".split()

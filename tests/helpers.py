@@ -52,6 +52,15 @@ class ToyTokenizer:
     eos_token_id = 2
     _SPLIT = __import__("re").compile(r"<\|[^|\s]*\|>|<[a-z_]+>|[A-Za-z0-9']+|[^\sA-Za-z0-9]")
 
+    pad_token = None
+
+    class _Enc(dict):
+        def to(self, device):
+            return self
+
+    def add_tokens(self, toks):
+        return 0
+
     def __init__(self, vocab_size: int = 512):
         self.vocab_size = vocab_size
         self._fixed = {"<|pad|>": 0, "<|bos|>": 1, "<|eos|>": 2, "<|AUDIO|>": 3, "<|video_pad|>": 4, "<|start|>": 5, "<|end|>": 6}
@@ -84,18 +93,26 @@ class ToyTokenizer:
             if r:
                 ids[i, L - len(r):] = torch.tensor(r)
                 am[i, L - len(r):] = 1
-        out = {"input_ids": ids, "attention_mask": am}
+        out = self._Enc({"input_ids": ids, "attention_mask": am})
         if return_length:
             out["length"] = torch.full((len(rows),), L, dtype=torch.long)   # HF: length of each PADDED sequence
         return out
 
     def apply_chat_template(self, messages, tokenize=False, add_generation_prompt=True, **kw):
+        if messages and isinstance(messages[0], list):                 # a batch of conversations -> list of strings
+            return [self.apply_chat_template(m, tokenize, add_generation_prompt) for m in messages]
         s = "".join(f"<|start|>{m['role']}\n{m['content']}<|end|>\n" for m in messages)
         return s + ("<|start|>assistant\n" if add_generation_prompt else "")
 
     def batch_decode(self, ids, skip_special_tokens=False):
         return [" ".join(str(int(t)) for t in row if not (skip_special_tokens and int(t) < 8)) for row in ids]
 
+
+GENERATE_MESSAGES = [
+    [{"role": "system", "content": "Focus on the audio clips and instructions."},
+     {"role": "user", "content": "Hello! this is my audio <|AUDIO|>. Help me transcribe.", "audios": [{"audio": "g1.wav", "text": "hello world"}]}],
+    [{"role": "user", "content": "Compare <|AUDIO|> with <|AUDIO|> please", "audios": [{"audio": "g2.wav", "text": None}, {"audio": "g3.wav", "text": ""}]}],
+]
 
 COLLATE_CASES = {
     # name: (records, batches as index lists, audio keys that fail to decode)

@@ -105,3 +105,62 @@ def test_padding_side_and_missing_audio_errors(tmp_path):
     assert resolve_audio_filepath(str(tmp_path / "x.flac")) == str(tmp_path / "x.wav")   # falls back to the .wav twin
     with pytest.raises(FileNotFoundError, match="Audio file not found"):
         resolve_audio_filepath(str(tmp_path / "y.flac"))
+
+
+def test_chat_level_generate_builds_the_reference_inputs(golden, tmp_path):
+    """`DeSTA25AudioModel.generate(messages)` host logic (no device: `_generate_step` is replaced by a recorder, as in the golden
+    script, where the REFERENCE's own generate() ran with the same stubs): audio decode order, VAD -> " " rule, ASR fill-in,
+    `<start_audio><|AUDIO|><end_audio>` + placeholder expansion, left-padded context, pad-shifted start positions, transcription
+    ids, the generation kwargs, and the GenerationOutput it returns."""
+    import types
+    from helpers import GENERATE_MESSAGES
+    from desta.models.modeling_desta25 import DeSTA25AudioModel, GenerationOutput
+    g = golden["generate_with_audio"]
+    msgs = json.loads(json.dumps(GENERATE_MESSAGES))
+    for conv in msgs:
+        for m in conv:
+            for a in m.get("audios", []):
+                key = a["audio"]
+                a["audio"] = str(tmp_path / key)
+                # a decodable stand-in: 16 kHz float WAVE with the golden script's seeded waveform
+                x = _wave_for(key)
+                import struct
+                hdr = b"RIFF" + struct.pack("<I", 36 + x.nbytes) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 3, 1, 16000, 64000, 4, 32) + b"data" + struct.pack("<I", x.nbytes)
+                (tmp_path / key).write_bytes(hdr + x.tobytes())
+    captured = {}
+
+    class R(DeSTA25AudioModel):
+        def _generate_step(self, inputs, **kw):
+            captured["inputs"], captured["kw"] = inputs, kw
+            return torch.tensor([[11, 12, 2], [13, 2, 0]])
+    m = R.__new__(R)
+    m.config = types.SimpleNamespace(prompt_size=64, encoder_config=types.SimpleNamespace(num_mel_bins=80))
+    m.audio_locator, m.placeholder_token, m.device = "<|AUDIO|>", "<|video_pad|>", torch.device("cpu")
+    proc = StubProcessor()
+    n3 = len(_wave_for("g3.wav"))
+    m._setup_generation(tokenizer=ToyTokenizer(), processor=proc, vad=lambda w: len(w) != n3, asr=lambda ws: [" spoken words "] * len(ws))
+    out = m.generate(msgs, do_sample=False, max_new_tokens=3)
+    gi = captured["inputs"]
+    assert gi["context_input_ids"].tolist() == g["context_input_ids"] and gi["context_attention_mask"].tolist() == g["context_attention_mask"]
+    assert [[int(i), int(s)] for i, s in gi["context_batch_start_positions"]] == g["context_batch_start_positions"]
+    assert [t.tolist() for t in gi["batch_transcription_ids"]] == g["batch_transcription_ids"]
+    assert int(gi["batch_features"].shape[0]) == g["n_features"] and proc.calls[0] == g["processor_calls"][0]
+    assert {k: captured["kw"][k] for k in g["kw"]} == g["kw"]
+    assert isinstance(out, GenerationOutput) and out.text == g["text"] and out.generated_ids == g["generated_ids"]
+    assert [[os.path.basename(a), t] for a, t in out.audios] == g["audios"]
+    # error behaviour of the reference
+    with pytest.raises(AssertionError, match="audio count does not match"):
+        m.generate([{"role": "user", "content": "two <|AUDIO|> <|AUDIO|>", "audios": [{"audio": str(tmp_path / "g1.wav"), "text": "x"}]}])
+    with pytest.raises(ValueError, match="does not exist"):
+        m.generate([{"role": "user", "content": "<|AUDIO|>", "audios": [{"audio": str(tmp_path / "nope.wav"), "text": "x"}]}])
+    with pytest.raises(ValueError, match="list of dictionaries"):
+        m.generate("hi")
+    m.asr = None
+    with pytest.raises(NotImplementedError, match="needs ASR"):
+        m.generate([{"role": "user", "content": "<|AUDIO|>", "audios": [{"audio": str(tmp_path / "g1.wav"), "text": None}]}])
+    # no audio: the chat template goes straight to the LLM with eos + <|eot_id|> as terminators
+    out = m.generate([[{"role": "user", "content": "plain text"}], [{"role": "user", "content": "another , longer one"}]], do_sample=False, max_new_tokens=3)
+    gi = captured["inputs"]
+    assert gi["context_batch_start_positions"] == [] and gi["batch_features"] is None and gi["context_input_ids"].shape[0] == 2
+    assert (gi["context_attention_mask"][0] == 0).sum() > 0 and gi["context_attention_mask"][0, -1] == 1           # left padded
+    assert captured["kw"]["eos_token_id"] == [2, ToyTokenizer().convert_tokens_to_ids("<|eot_id|>")] and out.audios == []
