@@ -19,6 +19,11 @@
 #include "common.h"
 #include "desta_hip.h"
 
+#ifndef ATTN_ABL
+#define ATTN_ABL 0     /* forward-kernel timing ablations for tools/attn_bench.py (results are garbage): 1 no LDS stores, 2 no global
+                          loads in the loop, 3 no exp, 4 one S MFMA step, 5 one P.V MFMA column block */
+#endif
+
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (D == 64 ? ATTN_FWD64_WAVES : 2)
     __shared__ __attribute__((aligned(16))) char lds[2 * 64 * D * 2];
     char* kimg = lds;
     char* vimg = lds + 64 * D * 2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h2 = lane >> 5;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h2 = lane >> 5;    // wave index in an SGPR: everything derived from it (q0, mask tests) is scalar -> real branches
     int qblk, h, b;
     attn_work_item(p, (p.Sq + QB - 1) / QB, qblk, h, b);
     const int qb0 = qblk * QB, q0 = qb0 + wave * 32;
@@ -199,17 +204,31 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (D == 64 ? ATTN_FWD64_WAVES : 2)
         if (kt * 64 > wave_kmax) return;                   // wave-uniform: nothing visible in this tile
         f32x16 st[2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+        {
+            // K fragments of the first 32 keys are all read before the first MFMA; those of the second 32 keys are read while
+            // the first chain runs (hipcc otherwise emits read -> wait -> MFMA pairs: one exposed LDS latency per MFMA)
+            constexpr int NS = (ATTN_ABL == 4 ? 1 : D / 16);
+            bf16x8 ka[NS], kbf[NS];
 #pragma unroll
-            for (int ds = 0; ds < D / 16; ++ds)
-                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(kimg, kb * 32, ds, lane), qf[ds], st[kb], 0, 0, 0);
+            for (int ds = 0; ds < NS; ++ds) ka[ds] = frag_rows<D>(kimg, 0, ds, lane);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ds = 0; ds < NS; ++ds) {
+                st[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ds], qf[ds], st[0], 0, 0, 0);
+                kbf[ds] = frag_rows<D>(kimg, 32, ds, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ds = 0; ds < NS; ++ds) st[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kbf[ds], qf[ds], st[1], 0, 0, 0);
         }
         // masks only on boundary tiles (wave-uniform): ragged Sk, left padding, causal diagonal
         const bool need_mask = (kt * 64 + 63 >= p.Sk) || (kt * 64 < kv_lo) || (p.causal && kt * 64 + 63 > q0 + coff);
         if (need_mask) {
-#pragma unroll
+            asm volatile("; boundary tile" ::: "memory");          // keeps this a BRANCH: hipcc otherwise if-converts the 128 compares
+#pragma unroll                                                      // + selects into every tile's straight-line code
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -232,7 +251,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (D == 64 ? ATTN_FWD64_WAVES : 2)
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(fmaf(st[kb][r], p.scale_log2, -muse));
+                const float pv = ATTN_ABL == 3 ? st[kb][r] : __builtin_amdgcn_exp2f(fmaf(st[kb][r], p.scale_log2, -muse));
                 st[kb][r] = pv;
                 rs += pv;
             }
@@ -265,17 +284,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (D == 64 ? ATTN_FWD64_WAVES : 2)
             for (int s = 0; s < 2; ++s) {
                 const bf16x8 pb = acc_frag(st[kb], s);
 #pragma unroll
-                for (int i = 0; i < D / 32; ++i)
+                for (int i = 0; i < (ATTN_ABL == 5 ? 1 : D / 32); ++i)
                     oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(vimg, kb * 32 + 16 * s, i * 32, lane), pb, oacc[i], 0, 0, 0);
             }
     };
 #define DESTA_KV_STAGE(KT, KR, VR)                                                   \
     __syncthreads(); /* previous tile's LDS reads are done */                        \
     asm volatile("; stage " #KR ::: "memory"); /* distinct text: keeps the two halves from being tail-merged */ \
+    if (ATTN_ABL != 1 || (KT) == t_lo) {                                             \
     tile_store<D, 64, NT>(kimg, KR);                                                     \
     tile_store<D, 64, NT>(vimg, VR);                                                     \
+    }                                                                                \
     __syncthreads();                                                                 \
-    if ((KT) + PF < t_hi) {                                                          \
+    if (ATTN_ABL != 2 && (KT) + PF < t_hi) {                                         \
         KR = tile_load<D, 64, NT>(kbase, p.k_rs, ((KT) + PF) * 64, p.Sk - 1);            \
         VR = tile_load<D, 64, NT>(vbase, p.v_rs, ((KT) + PF) * 64, p.Sk - 1);            \
     }
@@ -345,7 +366,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? ATTN_DQ_BLOCKS : 2) void attn_bw
     __shared__ __attribute__((aligned(16))) char lds[2 * 64 * D * 2];
     char* kimg = lds;
     char* vimg = lds + 64 * D * 2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h2 = lane >> 5;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h2 = lane >> 5;    // wave index in an SGPR: everything derived from it (q0, mask tests) is scalar -> real branches
     int qblk, h, b;
     attn_work_item(p, (p.Sq + QB - 1) / QB, qblk, h, b);
     const int qb0 = qblk * QB, q0 = qb0 + wave * 32;
@@ -418,14 +439,18 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? ATTN_DQ_BLOCKS : 2) void attn_bw
                     keep |= ((hsh >> 16) >= p.drop_thresh ? 1u : 0u) << (r + 1);
                 }
             }
+            if (need_mask) {                                           // boundary tiles only (scalar branch, outside the element loop)
+                asm volatile("; boundary tile" ::: "memory");
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float pv = __builtin_amdgcn_exp2f(fmaf(st[r], p.scale_log2, -lse));
-                if (need_mask) {
+                for (int r = 0; r < 16; ++r) {
                     const int key = kt * 64 + kb * 32 + acc_row(r, lane);
                     const bool ok = key < p.Sk && key >= kv_lo && (!p.causal || key <= q_abs);
-                    pv = ok ? pv : 0.f;
+                    st[r] = ok ? st[r] : -INFINITY;                   // exp2(-inf) = 0
                 }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(fmaf(st[r], p.scale_log2, -lse));
                 float dpr = dp[r];
                 if constexpr (DROP) dpr = ((keep >> r) & 1u) ? dpr * p.drop_scale : 0.f;
                 st[r] = pv * (dpr - dlt) * p.scale;        // dS^T
@@ -491,7 +516,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_k(AttnArgs p) {
     char* gimg = lds + QR * D * 2;
     float* lse_s = (float*)(lds + 2 * QR * D * 2);
     float* dlt_s = lse_s + QR;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h2 = lane >> 5;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h2 = lane >> 5;    // wave index in an SGPR: everything derived from it (q0, mask tests) is scalar -> real branches
     // 1-D grid with the key block as the SLOWEST index: under the causal mask low key blocks sweep the
     // most query tiles, so the heaviest work items are dispatched first (longest-processing-time order)
     const int nhb = p.Hkv * p.B;
@@ -608,15 +633,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_k(AttnArgs p) {
                     keep |= (theirs >= p.drop_thresh ? 1u : 0u) << (8 * (1 - half) + j);
                 }
             }
+            if (need_mask) {                                           // boundary slices only (scalar branch, outside the element loop)
+                asm volatile("; boundary slice" ::: "memory");
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int q = qb + acc_row(r, lane);
+                    const bool ok = key_ok && q < p.Sq && (!p.causal || kcol <= q + coff);
+                    st[r] = ok ? st[r] : -INFINITY;                   // exp2(-inf) = 0
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ql = acc_row(r, lane);
-                float pv = __builtin_amdgcn_exp2f(fmaf(st[r], p.scale_log2, -lsv[r]));
-                if (need_mask) {
-                    const int q = qb + ql;
-                    const bool ok = key_ok && q < p.Sq && (!p.causal || kcol <= q + coff);
-                    pv = ok ? pv : 0.f;
-                }
+                const float pv = __builtin_amdgcn_exp2f(fmaf(st[r], p.scale_log2, -lsv[r]));
                 float ms = 1.0f;
                 if constexpr (DROP) ms = ((keep >> r) & 1u) ? p.drop_scale : 0.f;
                 st[r] = pv * ms;                                             // (dropped) P for dV

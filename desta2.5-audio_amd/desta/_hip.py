@@ -12,7 +12,7 @@ import os
 import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the runtime we bind to)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdesta_hip.so")
+LIB_PATH = os.environ.get("DESTA_HIP_LIB") or os.path.join(_HERE, "lib", "libdesta_hip.so")     # env override: kernel A/B builds
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
