@@ -172,7 +172,6 @@ def main():
     ap.add_argument("--no-dw-overlap", action="store_true", help="A/B: Q-Former weight gradients on the main stream")
     ap.add_argument("--gemm-4phase", action="store_true", help="A/B: the 4-phase (16 MFMAs per phase) GEMM schedule")
     ap.add_argument("--splitk-inkernel", action="store_true", help="A/B: reduce the K-slices of tail tiles inside the GEMM launch (scattered, ticketed) instead of by the fix-up launch")
-    ap.add_argument("--no-ring3", action="store_true", help="A/B: the 128x128 GEMM kernel keeps its double buffer on small grids (no three-slot ring)")
     ap.add_argument("--full-lm-head", action="store_true", help="A/B: lm_head / CE over the whole token grid, not only the target rows")
     a = ap.parse_args()
 
@@ -214,8 +213,6 @@ def main():
         H.gemm_set_option(4, 0)
     if a.splitk_inkernel:
         H.gemm_set_option(5, 1)
-    if a.no_ring3:
-        H.gemm_set_option(6, 0)
     cfg = DeSTA25Config(**FULL_CONFIGS[a.config])
     t0 = time.time()
     model = DeSTA25AudioModel(cfg, weights=RandomWeights(cfg, dev, seed=0), device=dev)

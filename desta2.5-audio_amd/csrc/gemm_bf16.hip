@@ -222,13 +222,9 @@ __device__ __forceinline__ bf16x8 frag_trans(const char* img, int out0, int kk, 
     return o;
 }
 
-// STAGES = 2: double buffer, 64 KiB of LDS, two blocks per CU (grids of more than one block per CU: the second block covers the
-// first one's DMA waits).  STAGES = 3: three-slot ring, K-tile t+2 in flight while t is multiplied, counted `s_waitcnt vmcnt(8)`
-// + one raw barrier per K-tile, 96 KiB = one block per CU — for grids of <= 256 tiles (the Q-Former's 2048-row GEMMs: 100-240
-// tiles), where a block has its CU to itself and the double buffer paid one exposed DMA latency per K-tile (45 us for 31 K-tiles).
-template <bool TA, bool TB, int STAGES = 2>
-__global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void gemm_bf16_nt_kernel(GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) char lds[STAGES * 2 * TILE_BYTES];   // [buf][A|B]
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * 2 * TILE_BYTES];   // [buf][A|B]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -300,22 +296,10 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void gemm_bf16_nt_kernel(
 
     const int nk = p.K / BK;
     stage(0, 0);
-    if (STAGES == 3 && nk > 1) stage(1, 1);
-    if (STAGES == 2) __syncthreads();
+    __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-        int cur;
-        if (STAGES == 2) {
-            cur = kt & 1;
-            if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-        } else {
-            // tile kt has landed once all but the 8 youngest LDS-DMA ops of this wave (= tile kt+1) are done; the barrier makes
-            // that true for every wave's share and also says everybody finished reading slot (kt+2) % 3 (tile kt-1)
-            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            cur = kt % 3;
-            if (kt + 2 < nk) stage((kt + 2) % 3, kt + 2);
-        }
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
         const char* la = lds + cur * 2 * TILE_BYTES;
         const char* lb = la + TILE_BYTES;
 #pragma unroll
@@ -335,8 +319,7 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void gemm_bf16_nt_kernel(
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
-        if (STAGES == 2) __syncthreads();
-        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // this wave's LDS reads of the slot are complete
+        __syncthreads();
     }
 
     // epilogue: lane holds C[m][n0..n0+3], m = ..+fr, n0 = ..+fq*4
@@ -1093,7 +1076,6 @@ extern "C" int desta_gemm_force_variant(int v) { g_force_variant = v; return DES
 static int g_persistent = 0;      // automatic choice may use the persistent kernel (in-situ A/B: no gain)
 static int g_stagger = 1;         // automatic choice uses the staggered schedule
 static int g_inkernel_splitk = 0; // option 5: K-slices of tail tiles reduced inside the GEMM launch instead of by the fix-up launch (measured: no gain)
-static int g_small_ring3 = 1;     // option 6: three-slot LDS ring in the 128x128 kernel for grids of <= 256 tiles
 static int g_phases2 = 1;         // automatic choice uses the 2-phase (32 MFMAs per phase) staggered schedule (+5-16 % on every shape)
 extern "C" int desta_gemm_set_persistent(int on) { g_persistent = on; return DESTA_OK; }
 static int g_skinny = 0;          // 0 auto, else COLS*10 + U of the skinny (M <= 16) kernel (tuning)
@@ -1110,7 +1092,6 @@ extern "C" int desta_gemm_set_option(int option, int value) {
     }
     else if (option == 4) g_phases2 = value;
     else if (option == 5) g_inkernel_splitk = value;
-    else if (option == 6) g_small_ring3 = value;
     else if (option == 3) {
         if (value < 1 || value > 65535) { desta_set_error("gemm_set_option: skinny grid %d out of range", value); return DESTA_EINVAL; }
         g_skinny_blocks = value;
@@ -1234,14 +1215,7 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
         a.tilesM = (d->M + BM - 1) / BM; a.tilesN = (d->N + BN - 1) / BN;
         a.full_tiles = a.tilesM * a.tilesN; a.split = 1; a.ws = nullptr; a.tickets = nullptr;
         dim3 grid(a.tilesM * a.tilesN, d->batch);
-        // three-slot ring when every block has a CU to itself anyway (option 6 = 0 turns it off for A/B runs)
-        const bool ring3 = g_small_ring3 && (long)a.tilesM * a.tilesN * d->batch <= NCU && d->K / BK >= 4;
-        if (ring3) {
-            if (d->trans_a && d->trans_b) hipLaunchKernelGGL((gemm_bf16_nt_kernel<true, true, 3>), grid, dim3(256), 0, (hipStream_t)stream, a);
-            else if (d->trans_b) hipLaunchKernelGGL((gemm_bf16_nt_kernel<false, true, 3>), grid, dim3(256), 0, (hipStream_t)stream, a);
-            else if (d->trans_a) hipLaunchKernelGGL((gemm_bf16_nt_kernel<true, false, 3>), grid, dim3(256), 0, (hipStream_t)stream, a);
-            else hipLaunchKernelGGL((gemm_bf16_nt_kernel<false, false, 3>), grid, dim3(256), 0, (hipStream_t)stream, a);
-        } else if (d->trans_a && d->trans_b) hipLaunchKernelGGL((gemm_bf16_nt_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        if (d->trans_a && d->trans_b) hipLaunchKernelGGL((gemm_bf16_nt_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
         else if (d->trans_b) hipLaunchKernelGGL((gemm_bf16_nt_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
         else if (d->trans_a) hipLaunchKernelGGL((gemm_bf16_nt_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((gemm_bf16_nt_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
