@@ -449,3 +449,43 @@ def test_training_fast_path_vs_reference_golden(golden_dir, name):
     a = torch.cat([model.arena.grad(n).reshape(-1).double().cpu() for n in names])
     b = torch.cat([g["grad::" + n].reshape(-1).double() for n in names])
     assert float((a @ b) / (a.norm() * b.norm())) > 0.999
+
+
+def test_prefetch_hit_needs_the_same_tensor_object_and_training_empty_batch():
+    """(a) ADVICE r1: a prefetched encoder output is reused only for the very tensor object that was prefetched — a NEW tensor of the
+    same shape (possibly at the freed tensor's address) must recompute, a modified-in-place tensor too.  (b) `_empty_batch` in
+    `training_step` on one device: zero loss, no update, the step still counts (HF loop semantics)."""
+    from desta.trainer.desta_trainer import DeSTA25Trainer, TrainingArguments
+    d = O.tiny_dims(False)
+    model, w = _model(d)
+    model.eval()
+    b1 = O.synthetic_batch(d, B=2, S_ctx=4, S_tgt=8, seed=31)
+    b2 = O.synthetic_batch(d, B=2, S_ctx=4, S_tgt=8, seed=32)
+    f1 = b1["batch_features"].cuda()
+    b1["batch_features"] = f1
+    ref1 = float(model(**b1).loss)
+    b2["batch_features"] = b2["batch_features"].cuda()
+    ref2 = float(model(**b2).loss)
+    assert abs(ref1 - ref2) > 1e-4
+    model.prefetch_encoder(f1)
+    assert float(model(**b1).loss) == ref1                                  # hit: same object
+    model.prefetch_encoder(f1)
+    del f1, b1["batch_features"]
+    torch.cuda.empty_cache()
+    b2n = dict(b2, batch_features=b2["batch_features"].clone())              # same shape, new object (may reuse the freed address)
+    assert float(model(**b2n).loss) == ref2                                 # miss -> recomputed, not the stale states of b1
+    f3 = b2["batch_features"].clone()
+    model.prefetch_encoder(f3)
+    f3.mul_(0.5)                                                            # modified after the prefetch: version counter moved
+    half = float(model(**dict(b2, batch_features=f3)).loss)
+    model.drop_prefetched()
+    assert half == float(model(**dict(b2, batch_features=f3.clone())).loss) and half != ref2
+    # (b)
+    tr = DeSTA25Trainer(model, args=TrainingArguments(learning_rate=1e-3, warmup_steps=0, max_steps=5, logging_steps=1))
+    before = model.arena.params.clone()
+    loss = tr.training_step({"_empty_batch": True})
+    tr.wait_update()
+    assert float(loss) == 0.0 and tr.global_step == 1 and tr.optimizer.step_count == 0 and torch.equal(before, model.arena.params)
+    tr.training_step(b2)
+    tr.wait_update()
+    assert tr.global_step == 2 and tr.optimizer.step_count == 1 and not torch.equal(before, model.arena.params)
