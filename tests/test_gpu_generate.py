@@ -98,8 +98,14 @@ def test_generate_early_stop_and_no_audio():
     out1 = model._generate_step(inputs, pad_token_id=0, max_new_tokens=24, do_sample=False, eos_token_id=first, forced_tokens=ref)
     ref1, _ = O.greedy_generate(w, d, x, am, 24, 0, eos_token_ids=first, forced_tokens=ref)
     assert out1.cpu().tolist() == ref1.tolist() and out1.shape[1] == 1
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="needs a tokenizer"):           # chat-level generate(): the front end is injected
         model.generate([{"role": "user", "content": "hi"}])
+    # ... and with one, a text-only conversation goes through the KV-cached decoder (no audio: plain LLM generation)
+    from helpers import ToyTokenizer
+    model._setup_generation(tokenizer=ToyTokenizer(vocab_size=d.vocab), processor=object())
+    out = model.generate([[{"role": "user", "content": "hi there"}], [{"role": "user", "content": "a somewhat longer question , please"}]],
+                         do_sample=False, max_new_tokens=5)
+    assert len(out.text) == 2 and len(out.generated_ids) == 2 and out.audios == [] and all(len(r) <= 5 for r in out.generated_ids)
 
 
 def test_argmax_kernel():
