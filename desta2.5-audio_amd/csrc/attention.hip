@@ -508,10 +508,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? ATTN_DQ_BLOCKS : 2) void attn_bw
 #define ATTN_DKDV_QR 32
 #endif
 
+// D = 64: two blocks per CU (<= 256 VGPR + AGPR; the dropout variant took 284 and ran ONE block per CU: 250 us per cross-attention
+// launch); D = 128 keeps its 384 registers and one block per CU
 template <int D, bool DROP>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_k(AttnArgs p) {
+__global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkdv_k(AttnArgs p) {
     constexpr int QR = (D == 128) ? ATTN_DKDV_QR : 32;
-    __shared__ __attribute__((aligned(16))) char lds[2 * QR * D * 2 + 2 * QR * 4];
+    constexpr int LDS_LOOP = 2 * QR * D * 2 + 2 * QR * 4, LDS_EPI = 4 * 32 * 64 * 4;     // epilogue: a 32 x 64 fp32 transpose tile per wave
+    __shared__ __attribute__((aligned(16))) char lds[LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI];
     char* qimg = lds;
     char* gimg = lds + QR * D * 2;
     float* lse_s = (float*)(lds + 2 * QR * D * 2);
@@ -674,6 +677,37 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_k(AttnArgs p) {
     // dk[i][r]: dK[key = k0 + acc_row(r)][d = i*32 + (lane&31)]
     bf16_t* dkp = p.dK + (long)b * p.dk_bs + (long)hk * D;
     bf16_t* dvp = p.dV + (long)b * p.dv_bs + (long)hk * D;
+    const bool wide = ((p.dk_rs | p.dv_rs | p.dk_bs | p.dv_bs) & 7) == 0 && (((size_t)p.dK | (size_t)p.dV) & 15) == 0;
+    if (wide) {
+        // A lane owns ONE column of 16 keys: stored directly that is 64 two-byte store instructions per tensor and wave (the
+        // cross-attention dK / dV are 245 MB per layer).  Transposed through a wave-private 32 x 64 fp32 LDS tile a lane owns 8
+        // CONSECUTIVE columns of one key: 4 x 16-byte stores per 64 columns, 128-byte row segments.
+        __syncthreads();                                                     // every wave is done with the Q / dO images
+        float* tb = (float*)lds + wave * (32 * 64);
+        auto emit = [&](const f32x16 (&acc)[D / 32], bf16_t* base, long rs) __attribute__((always_inline)) {
+#pragma unroll
+            for (int hf = 0; hf < D / 64; ++hf) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tb[acc_row(r, lane) * 64 + ii * 32 + (lane & 31)] = acc[hf * 2 + ii][r];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // same wave: LDS ops complete in order, keep the compiler in order too
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = (lane >> 3) + 8 * j, key = k0 + row;
+                    const float4 x0 = *(const float4*)(tb + row * 64 + (lane & 7) * 8), x1 = *(const float4*)(tb + row * 64 + (lane & 7) * 8 + 4);
+                    u16x8 o;
+                    o[0] = f2bf(x0.x); o[1] = f2bf(x0.y); o[2] = f2bf(x0.z); o[3] = f2bf(x0.w);
+                    o[4] = f2bf(x1.x); o[5] = f2bf(x1.y); o[6] = f2bf(x1.z); o[7] = f2bf(x1.w);
+                    if (key < p.Sk) *(u16x8*)(base + (long)key * rs + hf * 64 + (lane & 7) * 8) = o;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // reads done before the next half overwrites the tile
+            }
+        };
+        emit(dk, dkp, p.dk_rs);
+        emit(dv, dvp, p.dv_rs);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < D / 32; ++i)
 #pragma unroll
