@@ -246,15 +246,25 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (D == 64 ? ATTN_FWD64_WAVES : 2)
         const float mnew = fmaxf(m, tmax);
         const float muse = (mnew == -INFINITY) ? 0.f : mnew;
         const float alpha = __builtin_amdgcn_exp2f(m - muse);
-        float rs = 0.f;
+        // score -> exponent argument and the row sum on register PAIRS (v_pk_fma_f32 / v_pk_add_f32: half the VALU instructions
+        // of the two passes; the kernel is bound by instruction issue)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 rs2 = {0.f, 0.f};
+        const f32x2 sc2 = {p.scale_log2, p.scale_log2}, nm2 = {-muse, -muse};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = ATTN_ABL == 3 ? st[kb][r] : __builtin_amdgcn_exp2f(fmaf(st[kb][r], p.scale_log2, -muse));
-                st[kb][r] = pv;
-                rs += pv;
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 sv = {st[kb][r], st[kb][r + 1]};
+                const f32x2 av = sv * sc2 + nm2;
+                f32x2 pv;
+                pv.x = ATTN_ABL == 3 ? sv.x : __builtin_amdgcn_exp2f(av.x);
+                pv.y = ATTN_ABL == 3 ? sv.y : __builtin_amdgcn_exp2f(av.y);
+                st[kb][r] = pv.x;
+                st[kb][r + 1] = pv.y;
+                rs2 += pv;
             }
+        float rs = rs2.x + rs2.y;
         rs += __shfl_xor(rs, 32, 64);
         l = l * alpha + rs;
         if constexpr (DROP) {
