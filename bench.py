@@ -171,6 +171,7 @@ def main():
     ap.add_argument("--repeat", type=int, default=1, help="repeat the timed region (reports the best), for A/B runs")
     ap.add_argument("--no-dw-overlap", action="store_true", help="A/B: Q-Former weight gradients on the main stream")
     ap.add_argument("--gemm-4phase", action="store_true", help="A/B: the 4-phase (16 MFMAs per phase) GEMM schedule")
+    ap.add_argument("--small-gemm-ring", type=int, default=None, help="A/B: option 6 of desta_gemm_set_option (0 = the 128x128 GEMM never takes its four-slot ring form, 1 = default, 2 = always)")
     ap.add_argument("--splitk-inkernel", action="store_true", help="A/B: reduce the K-slices of tail tiles inside the GEMM launch (scattered, ticketed) instead of by the fix-up launch")
     ap.add_argument("--full-lm-head", action="store_true", help="A/B: lm_head / CE over the whole token grid, not only the target rows")
     a = ap.parse_args()
@@ -211,6 +212,8 @@ def main():
         H.gemm_set_option(1, 0)
     if a.gemm_4phase:
         H.gemm_set_option(4, 0)
+    if a.small_gemm_ring is not None:
+        H.gemm_set_option(6, a.small_gemm_ring)
     if a.splitk_inkernel:
         H.gemm_set_option(5, 1)
     cfg = DeSTA25Config(**FULL_CONFIGS[a.config])

@@ -22,6 +22,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast",
          "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-Wno-unused-result"]
 FLAGS += os.environ.get("DESTA_EXTRA_HIPCC_FLAGS", "").split()      # kernel A/B experiments (-DNAME=value)
+# gemm_bf16.hip: accumulators stay in VGPRs for every kernel of the file.  The one-block-per-CU ring kernel would otherwise get
+# AGPR accumulators (512-register budget) and, with two MFMA groups per loop iteration, ~110 v_accvgpr copies per K-tile; the
+# other kernels of the file already compile to the VGPR form (identical code with and without the flag).
+FILE_FLAGS = {"gemm_bf16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _digest(paths):
@@ -44,7 +48,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     objs, todo = [], []
     for s in srcs:
         o = os.path.join(OBJ_DIR, os.path.basename(s)[:-4] + ".o")
-        dig = _digest([s]) + hdr_dig
+        dig = _digest([s]) + hdr_dig + " ".join(FILE_FLAGS.get(os.path.basename(s), []))
         dfile = o + ".sha"
         objs.append(o)
         if force or not os.path.exists(o) or not os.path.exists(dfile) or open(dfile).read() != dig:
@@ -54,7 +58,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def cc(job):
         s, o, dfile, dig = job
-        cmd = [HIPCC, *FLAGS, "-c", s, "-o", o]
+        cmd = [HIPCC, *FLAGS, *FILE_FLAGS.get(os.path.basename(s), []), "-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {s}:\n{r.stderr[-6000:]}")

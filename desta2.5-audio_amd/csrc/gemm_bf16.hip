@@ -337,6 +337,209 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs p) {
 }
 
 
+// frag_trans for the ring kernel below.  The compiler orders the `ds_read_tr` BUILTIN behind every LDS-DMA in flight (it puts
+// an `s_waitcnt vmcnt(0)` in front: no alias information on the intrinsic), which would drain the ring on every K-tile; as
+// inline asm the read is invisible to its counters, so the consumer waits itself (`landed()`: explicit lgkmcnt(0)).
+__device__ __forceinline__ bf16x8 frag_trans_raw(const char* img, int out0, int kk, int fr, int fq) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+    const int col = out0 + 4 * (fr & 3);
+    bf16x8 o;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const int k = kk * 32 + 8 * fq + 4 * s2 + (fr >> 2);
+        const int off = k * 256 + (((col >> 3) ^ tr_swz(k)) << 4) + ((col & 4) << 1);
+        bf16x4_t v;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"((unsigned)(unsigned long)(img + off)) : "memory");   // low 32 bits of a flat LDS address = the LDS offset
+        o[4 * s2 + 0] = v[0]; o[4 * s2 + 1] = v[1]; o[4 * s2 + 2] = v[2]; o[4 * s2 + 3] = v[3];
+    }
+    return o;
+}
+
+// The same 128x128x64 tile and 4 waves, software-pipelined for grids that leave a block alone on its CU (the Q-Former's
+// 2048-row GEMMs: 100-640 tiles of 20-80 K-tiles).  With one wave per SIMD the double buffer above serialises, per K-tile,
+// the fragment reads (64 KiB of ds_read per block), the 32 MFMAs of a wave and the wait for the next tile's DMA: 0.72 us per
+// K-tile measured (tools/qformer_gemm_bench.py) against 0.21 us of MFMA time.  Here:
+//   * FOUR-slot ring (128 KiB, one block per CU), K-tiles t+1..t+3 in flight behind a counted `s_waitcnt vmcnt(16)`
+//     (8 LDS-DMA ops per thread and K-tile), ONE raw barrier per K-tile; past the last K-tile the stream re-loads the last tile
+//     into dead slots so the count stays constant;
+//   * fragments double-buffered in registers: the ds_reads of half K-tile h+1 are issued before the 16 MFMAs of half h, so the
+//     LDS pipe and the matrix pipe run side by side inside one wave.
+// Same accumulation order per output element as the double-buffered kernel (K-tiles, then halves, in order): bit-identical.
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_ring_kernel(GemmArgs p) {
+    constexpr int NS = 4;
+    __shared__ __attribute__((aligned(16))) char lds[NS * 2 * TILE_BYTES];   // [slot][A|B]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const int ntile = p.tilesM * p.tilesN;
+    const int L = xcd_remap(blockIdx.x, ntile);
+    constexpr int GROUP_M = 8;
+    const int gspan = GROUP_M * p.tilesN;
+    const int first_m = (L / gspan) * GROUP_M;
+    const int gsz = min(p.tilesM - first_m, GROUP_M);
+    const int tm = first_m + (L % gspan) % gsz;
+    const int tn = (L % gspan) / gsz;
+    const int brow = tm * BM, bcol = tn * BN;
+    const int z = blockIdx.y;
+
+    const bf16_t* A = p.A + (long)z * p.sA;
+    const bf16_t* B = p.B + (long)z * p.sB;
+
+    const bf16_t* srcA[4];
+    const bf16_t* srcB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = i * 256 + tid;
+        if (TA) {
+            const int k = idx >> 4, c = (idx & 15) ^ tr_swz(k);
+            srcA[i] = A + (long)k * p.lda + min(brow + c * 8, p.M - 8);
+        } else {
+            const int r = idx >> 3, c = (idx & 7) ^ (r & 7);
+            srcA[i] = A + (long)min(brow + r, p.M - 1) * p.lda + c * 8;
+        }
+        if (TB) {
+            const int k = idx >> 4, c = (idx & 15) ^ tr_swz(k);
+            srcB[i] = B + (long)k * p.ldb + min(bcol + c * 8, p.N - 8);
+        } else {
+            const int r = idx >> 3, c = (idx & 7) ^ (r & 7);
+            srcB[i] = B + (long)min(bcol + r, p.N - 1) * p.ldb + c * 8;
+        }
+    }
+    const long stepA = TA ? (long)BK * p.lda : BK, stepB = TB ? (long)BK * p.ldb : BK;
+    const int nk = p.K / BK;
+    auto stage = [&](int kt) {                                       // K-tile kt -> slot kt & 3
+        const int kc = min(kt, nk - 1);
+        char* la = lds + (kt & (NS - 1)) * 2 * TILE_BYTES;
+        char* lb = la + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int wbase = (i * 256 + wave * 64) * 16;
+            glds16(srcA[i] + kc * stepA, la + wbase);
+            glds16(srcB[i] + kc * stepB, lb + wbase);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    int offA[4], offB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ra = wr * 64 + i * 16 + fr;
+        const int rb = wc * 64 + i * 16 + fr;
+        offA[i] = ra * 128 + ((fq ^ (ra & 7)) << 4);
+        offB[i] = rb * 128 + ((fq ^ (rb & 7)) << 4);
+    }
+    auto rd_a = [&](int kt, int kk, int i) __attribute__((always_inline)) -> bf16x8 {
+        const char* la = lds + (kt & (NS - 1)) * 2 * TILE_BYTES;
+        if (TA) return frag_trans_raw(la, wr * 64 + i * 16, kk, fr, fq);
+        return *(const bf16x8*)(la + (offA[i] ^ (kk << 6)));
+    };
+    auto rd_b = [&](int kt, int kk, int i) __attribute__((always_inline)) -> bf16x8 {
+        const char* lb = lds + (kt & (NS - 1)) * 2 * TILE_BYTES + TILE_BYTES;
+        if (TB) return frag_trans_raw(lb, wc * 64 + i * 16, kk, fr, fq);
+        return *(const bf16x8*)(lb + (offB[i] ^ (kk << 6)));
+    };
+    // transposed-storage variants: the inline-asm reads are invisible to sched_group_barrier, so the (MFMA, memory op) pairs are
+    // fenced one by one instead
+    auto fence = [&]() __attribute__((always_inline)) { if (TA || TB) __builtin_amdgcn_sched_barrier(0); };
+    auto landed = [&](bf16x8 (&af)[4], bf16x8 (&bfr)[4]) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(bfr[0]), "+v"(bfr[1]), "+v"(bfr[2]), "+v"(bfr[3]) :: "memory");
+    };
+
+    stage(0); stage(1); stage(2);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                // K-tile 0 of this wave's share has landed ...
+    __builtin_amdgcn_s_barrier();                                    // ... and everybody else's
+    bf16x8 a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a0[i] = rd_a(0, 0, i); b0[i] = rd_b(0, 0, i); }
+    landed(a0, b0);                                                  // (both ways into the loop header agree: no pending reads)
+    for (int kt = 0; kt < nk; ++kt) {
+        // first half: the 16 MFMAs of fragments (kt, 0) with one memory instruction behind each, inside the issue slack an MFMA
+        // leaves (8 of its 16 cycles): alternately a DMA op of K-tile kt+3 (into the slot of K-tile kt-1, which every wave left
+        // before the last barrier) and a read of fragments (kt, 1).  (Reads first / DMA last measured the same on the row-major
+        // form and 15 % slower on the transposed-storage form.)
+        {
+            const int kc = min(kt + 3, nk - 1);
+            char* la = lds + ((kt + 3) & (NS - 1)) * 2 * TILE_BYTES;
+            char* lb = la + TILE_BYTES;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int wbase = (i * 256 + wave * 64) * 16;
+                acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[0], a0[i], acc[i][0], 0, 0, 0);
+                glds16(srcA[i] + kc * stepA, la + wbase);
+                fence();
+                acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[1], a0[i], acc[i][1], 0, 0, 0);
+                a1[i] = rd_a(kt, 1, i);
+                fence();
+                acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[2], a0[i], acc[i][2], 0, 0, 0);
+                glds16(srcB[i] + kc * stepB, lb + wbase);
+                fence();
+                acc[i][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[3], a0[i], acc[i][3], 0, 0, 0);
+                b1[i] = rd_b(kt, 1, i);
+                fence();
+            }
+            if (!TA && !TB) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // VMEM read (the LDS-DMA)
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // `landed` puts the wait for a fragment set HERE, after the MFMAs that cover its reads were issued.  K-tile kt+1 has
+        // landed when all but the 16 youngest DMA ops (tiles kt+2, kt+3) are done; this wave's reads of slot kt are complete,
+        // so after the barrier the slot may be re-staged
+        landed(a1, b1);
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // second half: the MFMAs of (kt, 1) with the reads of (kt+1, 0) between them (past the end: a landed, unused tile)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[0], a1[i], acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[1], a1[i], acc[i][1], 0, 0, 0);
+            a0[i] = rd_a(kt + 1, 0, i);
+            fence();
+            acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[2], a1[i], acc[i][2], 0, 0, 0);
+            acc[i][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[3], a1[i], acc[i][3], 0, 0, 0);
+            b0[i] = rd_b(kt + 1, 0, i);
+            fence();
+        }
+        if (!TA && !TB) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        landed(a0, b0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // no LDS-DMA may outlive the block
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = brow + wr * 64 + i * 16 + fr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n0 = bcol + wc * 64 + j * 16 + fq * 4;
+            if (n0 >= p.N) continue;
+            epilogue4(p, z, m, n0, acc[i][j]);
+        }
+    }
+}
+
+
 // ---------------------------------------------------------------------------------------------------
 // 256x256x64 tile, 8 waves (2M x 4N, 128x64 per wave), 4 phases per K-tile, one 16-KiB half-tile staged
 // per phase by LDS-DMA, five half-tiles (80 KiB) in flight behind a COUNTED s_waitcnt vmcnt(10) and raw
@@ -1076,6 +1279,7 @@ extern "C" int desta_gemm_force_variant(int v) { g_force_variant = v; return DES
 static int g_persistent = 0;      // automatic choice may use the persistent kernel (in-situ A/B: no gain)
 static int g_stagger = 1;         // automatic choice uses the staggered schedule
 static int g_inkernel_splitk = 0; // option 5: K-slices of tail tiles reduced inside the GEMM launch instead of by the fix-up launch (measured: no gain)
+static int g_small_ring = 1;      // option 6: 0 never, 1 the four-slot ring form of the 128x128 kernel when its grid leaves one block per CU, 2 always (A/B runs)
 static int g_phases2 = 1;         // automatic choice uses the 2-phase (32 MFMAs per phase) staggered schedule (+5-16 % on every shape)
 extern "C" int desta_gemm_set_persistent(int on) { g_persistent = on; return DESTA_OK; }
 static int g_skinny = 0;          // 0 auto, else COLS*10 + U of the skinny (M <= 16) kernel (tuning)
@@ -1092,6 +1296,7 @@ extern "C" int desta_gemm_set_option(int option, int value) {
     }
     else if (option == 4) g_phases2 = value;
     else if (option == 5) g_inkernel_splitk = value;
+    else if (option == 6) g_small_ring = value;
     else if (option == 3) {
         if (value < 1 || value > 65535) { desta_set_error("gemm_set_option: skinny grid %d out of range", value); return DESTA_EINVAL; }
         g_skinny_blocks = value;
@@ -1215,7 +1420,14 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
         a.tilesM = (d->M + BM - 1) / BM; a.tilesN = (d->N + BN - 1) / BN;
         a.full_tiles = a.tilesM * a.tilesN; a.split = 1; a.ws = nullptr; a.tickets = nullptr;
         dim3 grid(a.tilesM * a.tilesN, d->batch);
-        if (d->trans_a && d->trans_b) hipLaunchKernelGGL((gemm_bf16_nt_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        const long nblk = (long)a.tilesM * a.tilesN * d->batch;
+        const bool ring = d->K / BK >= 4 && (g_small_ring == 2 || (g_small_ring == 1 && nblk <= NCU));
+        if (ring) {
+            if (d->trans_a && d->trans_b) hipLaunchKernelGGL((gemm_bf16_nt_ring_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+            else if (d->trans_b) hipLaunchKernelGGL((gemm_bf16_nt_ring_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+            else if (d->trans_a) hipLaunchKernelGGL((gemm_bf16_nt_ring_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+            else hipLaunchKernelGGL((gemm_bf16_nt_ring_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        } else if (d->trans_a && d->trans_b) hipLaunchKernelGGL((gemm_bf16_nt_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
         else if (d->trans_b) hipLaunchKernelGGL((gemm_bf16_nt_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
         else if (d->trans_a) hipLaunchKernelGGL((gemm_bf16_nt_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((gemm_bf16_nt_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, a);

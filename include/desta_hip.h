@@ -97,7 +97,9 @@ int desta_gemm_last_kernel(void);
 int desta_gemm_set_persistent(int on);   /* 1: the automatic choice uses the persistent kernel when a block owns > 1 item */
 /* A/B switches of the automatic choice: option 0 = persistent, 1 = staggered, 2 = skinny (M <= 16) kernel variant
  * (0 auto, else COLS*10 + U: 162 164 322 641), 3 = persistent grid size of the skinny kernel (default 512 = 2 blocks per CU),
- * 4 = two-phase schedule of the 256x256 kernel (default 1; 0 = the four-phase schedule) */
+ * 4 = two-phase schedule of the 256x256 kernel (default 1; 0 = the four-phase schedule), 5 = K-slices of tail tiles reduced inside
+ * the GEMM launch instead of by the fix-up launch (default 0), 6 = four-slot software-pipelined ring form of the 128x128 kernel:
+ * 0 never, 1 (default) when the grid leaves one block per CU (<= 256 tiles), 2 always; bit-identical results in every setting */
 int desta_gemm_set_option(int option, int value);
 
 /* ------------------------------------------------------------------------------------------

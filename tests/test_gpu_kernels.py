@@ -201,7 +201,7 @@ def test_rope_kv_append(hip):
         assert bool((cache[:, 8] == 0).all()) and torch.equal(cache[:, :S], ref.view(B, S, ld)[:, :, hq * hd:])
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (3840, 1280, 2048), (1280, 3072, 2048), (200, 136, 192), (2048, 1280, 3840), (8, 8, 64)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (3840, 1280, 2048), (1280, 3072, 2048), (200, 136, 192), (200, 136, 320), (2048, 1280, 3840), (8, 8, 64), (8, 8, 256)])
 def test_gemm_transposed_operands(hip, M, N, K):
     """trans_a / trans_b: operands stored [K,M] / [K,N] (autograd's dW = dY^T X, dX = dY W) == the NT kernel on
     materialised transposes, bit for bit (same products, same order), incl. ragged tile edges and padded leading dims."""
@@ -213,15 +213,21 @@ def test_gemm_transposed_operands(hip, M, N, K):
     bias = torch.randn(N, generator=g).cuda()
     try:
         hip.gemm_force_variant(1)
+        hip.gemm_set_option(6, 0)                                      # the double-buffered 128x128 kernel
         ref = torch.empty(M, N, dtype=torch.float32, device="cuda")
         hip.gemm(A, B, ref, M, N, K, bias=bias)
+        torch.testing.assert_close(ref, A.float() @ B.float().T + bias, rtol=1e-4, atol=2e-3)
+        # ring = 2: the four-slot software-pipelined form of the same tile (what small grids run by default): same
+        # accumulation order, so every storage combination is bit-identical in both kernels
+        for ring in (0, 2):
+            hip.gemm_set_option(6, ring)
+            for ta, tb in ((False, False), (True, True), (False, True), (True, False)):
+                out = torch.empty(M, N, dtype=torch.float32, device="cuda")
+                hip.gemm(At if ta else A, Bt if tb else B, out, M, N, K, bias=bias, trans_a=ta, trans_b=tb, lda=(M + 8) if ta else K)
+                assert torch.equal(out, ref), (ring, ta, tb)
     finally:
         hip.gemm_force_variant(0)
-    torch.testing.assert_close(ref, A.float() @ B.float().T + bias, rtol=1e-4, atol=2e-3)
-    for ta, tb in ((True, True), (False, True), (True, False)):
-        out = torch.empty(M, N, dtype=torch.float32, device="cuda")
-        hip.gemm(At if ta else A, Bt if tb else B, out, M, N, K, bias=bias, trans_a=ta, trans_b=tb, lda=(M + 8) if ta else K)
-        assert torch.equal(out, ref), (ta, tb)
+        hip.gemm_set_option(6, 1)
 
 
 def test_gemm_256_identity_and_k64(hip):

@@ -1,6 +1,6 @@
 """Time the GEMM shapes of the Q-Former connector / projector (the launches that fall to the 128x128 kernel)
 one by one: normal and transposed-storage (dW) forms, back-to-back launches between two events.
-  python tools/qformer_gemm_bench.py [variant]"""
+  python tools/qformer_gemm_bench.py [variant] [ring]      (ring: option 6 of desta_gemm_set_option, 0 / 1 / 2)"""
 import os
 import sys
 
@@ -23,6 +23,8 @@ def main():
     variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     dev = "cuda"
     H.gemm_force_variant(variant)
+    if len(sys.argv) > 2:
+        H.gemm_set_option(6, int(sys.argv[2]))
     tot = 0.0
     for M, N, K, ta, tb, what in SHAPES:
         A = (torch.rand((K, M) if ta else (M, K), device=dev) * 2 - 1).to(torch.bfloat16)
