@@ -60,7 +60,11 @@ def worker(out_dir):
 
 @pytest.mark.gpu
 def test_two_rank_trainer_bit_identical_and_equals_single_process_mean(tmp_path):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 2000), WORLD_SIZE="2",
+    import socket
+    with socket.socket() as sk:                          # a port nobody holds right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", str(tmp_path)], env=dict(env, RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
