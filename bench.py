@@ -276,11 +276,15 @@ def main():
     # untimed extra pass: HIP events around every HBM-bound / attention launch (algorithmic bytes / FLOP per call from the wrappers)
     kprof, kp_steps = {}, 3
     if not a.no_kernel_pass:                             # every rank steps (the all-reduce is collective); rank 0 records
+        # ... with the optimizer tail on the MAIN stream for these steps: beside the next Whisper forward (the timed region's
+        # overlap) the two time-share the chip and every per-kernel duration of either stream reads long
+        side, trainer._side = trainer._side, None
         if rank == 0:
             H.kernel_profile_start()
         run(kp_steps, a.warmup + a.steps)
         if rank == 0:
             kprof = H.kernel_profile_stop()
+        trainer._side = side
     fence()
     n_launch, flops, gemm_ms = prof.get(2, (0, 0.0, 0.0))                 # the dominant kernel: gemm_bf16_nt_256_kernel
     n_other = sum(v[0] for k, v in prof.items() if k != 2)

@@ -6,8 +6,10 @@ Host-side mirror of the reference's `desta/trainer/data/simple_dataset.py`:
   `<|AUDIO|>` locator (`modeling_desta25.py:99-123`, `simple_dataset.py:42-101`);
 * `BaseCollateFn` — left-padded tokenisation, labels, `start_answer_position`, pad-shifted `batch_start_positions`, the
   `[1, n]` transcription ids, the context-only copy for evaluation and the `_empty_batch` marker (`:116-301`);
-* `BaseAudioTextDataset` — prompt-only preprocessing of JSONL manifests (`:574-743`), without the HF `datasets` disk cache
-  and the rank-0 lock-file protocol (control plane, out of scope): the manifest is read and preprocessed in memory.
+* `BaseAudioTextDataset` — prompt-only preprocessing of JSONL manifests (`:574-743`) behind the reference's disk cache
+  (`:361-452`): `$HF_HOME/desta_preprocessed/<md5 of the manifest paths>` written with `datasets.save_to_disk` by rank 0
+  under a `.lock` file and published by a `.ready` file, the other ranks wait at the barrier and load it; `records=` (tests)
+  or `disk_cache=False` preprocess in memory.
 
 All of it is integer / index / string work on the host; it takes ANY object with the tokenizer call protocol (`__call__`
 with padding / truncation, `tokenize`, `encode`, `convert_tokens_to_string`, `apply_chat_template`, `padding_side`,
@@ -19,17 +21,42 @@ reference, tests/golden/make_collate_golden.py).
 """
 from __future__ import annotations
 
+import hashlib
 import json
 import logging
 import os
 import re
+import time
 from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import torch
+import torch.distributed as dist
 
 from ...utils.audio import AudioSegment
 
 START_TAG, END_TAG = "<start_audio>", "<end_audio>"
+
+
+def _get_rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def _is_main_process() -> bool:
+    return _get_rank() == 0
+
+
+def _barrier() -> None:
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def resolve_manifest_filepath(fp: str) -> str:
+    """The reference resolves manifests with `lulutils.resolve_filepath` (third-party, absent offline: parity of the resolved
+    STRING, and with it of the cache key, is unpinned).  Here: `~` / environment variables expanded, absolute, must exist."""
+    out = os.path.abspath(os.path.expandvars(os.path.expanduser(fp)))
+    if not os.path.isfile(out):
+        raise FileNotFoundError(f"manifest not found: {fp}")
+    return out
 
 
 def prepare_audio_context_and_start_positions(token_list: Sequence[str], audio_locator: str, audio_size_list: List[int],
@@ -165,7 +192,10 @@ class BaseAudioTextDataset:
     `target`, `length`).  Training is prompt-only (hazard H9): `messages` / `seed_description` are ignored, the audio locator is
     appended to the prompt when missing, transcriptions are always "" so an audio span is exactly `prompt_size` tokens."""
 
-    def __init__(self, cfg, data_cfg, tokenizer, processor, records: Optional[List[Dict[str, Any]]] = None):
+    READY_POLL_S, READY_TIMEOUT_S = 5, 7200                                         # `simple_dataset.py:438-452`
+
+    def __init__(self, cfg, data_cfg, tokenizer, processor, records: Optional[List[Dict[str, Any]]] = None,
+                 disk_cache: bool = True):
         g = (lambda o, k, d=None: (o.get(k, d) if hasattr(o, "get") else getattr(o, k, d)))
         model_cfg = g(cfg, "model")
         self.audio_locator, self.placeholder_token = g(model_cfg, "audio_locator"), g(model_cfg, "placeholder_token")
@@ -177,20 +207,84 @@ class BaseAudioTextDataset:
         self.tokenizer, self.processor = tokenizer, processor
         if records is None:
             paths = g(data_cfg, "manifest_filepaths")
-            records = []
-            for fp in ([paths] if isinstance(paths, str) else list(paths)):
+            self.manifest_filepaths = [paths] if isinstance(paths, str) else list(paths)
+            for fp in self.manifest_filepaths:
                 logging.info(f"Loading manifest: {fp}")
-                with open(fp) as f:
-                    records += [json.loads(line) for line in f if line.strip()]
+            data_files = [resolve_manifest_filepath(fp) for fp in self.manifest_filepaths]
+            if disk_cache:
+                rows = self._load_or_preprocess_on_disk(data_files)
+            else:
+                records = []
+                for fp in data_files:
+                    with open(fp) as f:
+                        records += [json.loads(line) for line in f if line.strip()]
+        if records is not None:
+            rows = self._preprocess_records(records)
+        n = len(rows)
+        valid = (lambda r: r["length"] > 0 and len(r["audio_context"]) > 0 and len(r["processed_audios"]) > 0)
+        self.dataset = rows.filter(valid) if hasattr(rows, "filter") else [r for r in rows if valid(r)]
+        logging.info(f"Dataset: {n} samples, {len(self.dataset)} valid, {n - len(self.dataset)} skipped")
+        self.collate_fn = BaseCollateFn(data_cfg=data_cfg, tokenizer=tokenizer, processor=processor)
+
+    def _preprocess_records(self, records: List[Dict[str, Any]]) -> List[Dict[str, Any]]:
         cols = {k: [r.get(k) for r in records] for k in ("id", "prompt", "response")}
         cols["prompt"] = [p or "" for p in cols["prompt"]]
         cols["response"] = [r or "" for r in cols["response"]]
         pre = self._preprocess_function(cols)
-        n = len(records)
-        rows = [{k: pre[k][i] for k in pre} for i in range(n)]
-        self.dataset = [r for r in rows if r["length"] > 0 and len(r["audio_context"]) > 0 and len(r["processed_audios"]) > 0]
-        logging.info(f"Dataset: {n} samples, {len(self.dataset)} valid, {n - len(self.dataset)} skipped")
-        self.collate_fn = BaseCollateFn(data_cfg=data_cfg, tokenizer=tokenizer, processor=processor)
+        return [{k: pre[k][i] for k in pre} for i in range(len(records))]
+
+    @staticmethod
+    def cache_paths(data_files: List[str]) -> Tuple[str, str, str]:
+        """(cache_dir, lock_file, ready_file) of a manifest set — the reference's layout (`simple_dataset.py:367-376`)."""
+        key = hashlib.md5("_".join(sorted(data_files)).encode()).hexdigest()[:12]
+        cache_dir = os.path.join(os.environ.get("HF_HOME", os.path.expanduser("~/.cache/huggingface")), "desta_preprocessed", key)
+        return cache_dir, cache_dir + ".lock", cache_dir + ".ready"
+
+    def _load_or_preprocess_on_disk(self, data_files: List[str]):
+        """`simple_dataset.py:361-452`: a ready cache is loaded by every rank; otherwise rank 0 preprocesses under a lock file,
+        saves with `datasets.save_to_disk`, publishes the `.ready` file and removes the lock; everybody meets at the barrier and
+        the other ranks poll for `.ready` (5 s steps, 2 h) and load.  A cache that fails to load is re-made."""
+        import datasets
+        cache_dir, lock_file, ready_file = self.cache_paths(data_files)
+        ds = None
+        if os.path.exists(ready_file) and os.path.isdir(cache_dir):
+            logging.info(f"[Rank {_get_rank()}] Loading preprocessed dataset from disk cache: {cache_dir}")
+            try:
+                ds = datasets.load_from_disk(cache_dir)
+            except Exception as e:                                                    # noqa: BLE001 (the reference re-makes on ANY failure)
+                logging.warning(f"[Rank {_get_rank()}] Cache load failed: {e}. Will reprocess.")
+                if os.path.exists(ready_file):
+                    os.remove(ready_file)
+        if ds is not None:
+            return ds
+        if _is_main_process():
+            os.makedirs(os.path.dirname(lock_file), exist_ok=True)
+            with open(lock_file, "w") as f:
+                f.write(f"rank0_processing_{os.getpid()}")
+            try:
+                # the JSON builder's own arrow cache next to ours, under the HF_HOME of THIS call (`datasets` froze its default
+                # at import time)
+                raw = datasets.load_dataset("json", data_files=data_files,
+                                            cache_dir=os.path.join(os.path.dirname(os.path.dirname(cache_dir)), "datasets"))["train"]
+                ds = raw.map(self._preprocess_function, batched=True, batch_size=128, num_proc=1, load_from_cache_file=False,
+                             keep_in_memory=False)
+                ds.save_to_disk(cache_dir)
+                with open(ready_file, "w") as f:
+                    f.write("ready")
+                logging.info(f"[Rank {_get_rank()}] Preprocessing complete. Saved {len(ds)} samples.")
+            finally:
+                if os.path.exists(lock_file):
+                    os.remove(lock_file)
+        _barrier()
+        if not _is_main_process():
+            waited = 0
+            while not os.path.exists(ready_file) and waited < self.READY_TIMEOUT_S:
+                time.sleep(self.READY_POLL_S)
+                waited += self.READY_POLL_S
+            if not os.path.exists(ready_file):
+                raise RuntimeError(f"[Rank {_get_rank()}] Timeout waiting for preprocessed dataset!")
+            ds = datasets.load_from_disk(cache_dir)
+        return ds
 
     def _preprocess_function(self, examples: Dict[str, List]) -> Dict[str, List]:
         tok = self.tokenizer
@@ -225,7 +319,7 @@ class BaseAudioTextDataset:
         examples["audio_context"], examples["start_positions"] = ctxs, starts_l
         examples["transcription_list"], examples["processed_audios"] = trans_l, audios_l
         targets, lengths = [], []
-        for ctx, resp in zip(ctxs, examples["response"]):
+        for ctx, resp in zip(ctxs, examples.get("response", [""] * n)):
             ok = bool(ctx) and bool(resp)
             targets.append(resp + tok.eos_token if ok else "")
             lengths.append(len(tok.tokenize(ctx + resp)) if ok else 0)

@@ -45,6 +45,8 @@ class TrainingArguments:
     overlap_encoder: bool = False                  # next batch's frozen Whisper forward on its own HIP stream beside the LLM (A/B: -1.2 % step time, see DESIGN)
     save_strategy: str = "no"                      # "epoch" (train_desta.py:146, enable_checkpointing) | "no"
     steps_per_epoch: Optional[int] = None          # len(train dataloader) when the dataset is not sized (synthetic streams)
+    seed: int = 42                                 # map-style datasets: the epoch's sample order is randperm(seed + epoch)
+    shuffle: bool = True                           # (HF: RandomSampler unless group_by_length); False = manifest order
 
 
 def allreduce_mean_(flat: torch.Tensor) -> None:
@@ -252,8 +254,24 @@ class DeSTA25Trainer:
             return ds.batches(epoch) if len(inspect.signature(ds.batches).parameters) >= 1 else ds.batches()
         if self.data_collator is None:
             raise ValueError("train() needs a data_collator for a map-style train_dataset")
+        # torch DistributedSampler(shuffle, seed, drop_last=False) semantics: one permutation per epoch from seed + epoch, wrapped
+        # to a multiple of the world size so EVERY rank draws the same number of batches (a rank that ran out early would leave
+        # its peers in the gradient all-reduce), rank r takes every world-th sample.  (The HF / accelerate pipeline shards
+        # BATCHES of a seeded RandomSampler instead: the sample -> rank assignment differs, the per-epoch coverage and
+        # `steps_per_epoch` agree.)
         bs, n = self.args.per_device_train_batch_size, len(ds)
-        idx = list(range(self.rank, n, self.world))                           # DistributedSampler(shuffle=False) share
+        if n == 0:
+            return iter(())
+        if self.args.shuffle:
+            g = torch.Generator()
+            g.manual_seed(self.args.seed + epoch)
+            order = torch.randperm(n, generator=g).tolist()
+        else:
+            order = list(range(n))
+        total = math.ceil(n / self.world) * self.world
+        while len(order) < total:
+            order += order[:total - len(order)]
+        idx = order[self.rank:total:self.world]
         return (self.data_collator([ds[i] for i in idx[s:s + bs]]) for s in range(0, len(idx), bs))
 
     def _train_pass(self, it, max_steps: Optional[int]) -> List[torch.Tensor]:

@@ -11,8 +11,10 @@ Hydra/OmegaConf are not installed here, so the few features the reference uses a
 the `???` mandatory marker.  `create_model` / `create_training_args` read exactly the keys the reference
 reads (train_desta.py:96-162).  Checkpoints are HF `checkpoint-<step>/` directories written at every epoch end
 (save_strategy="epoch", :146) and `resume_from_checkpoint` is handed to `trainer.train` (:231), which restores the
-parameters, Adafactor moments, schedule position and step.  Datasets: `synthetic: true` streams, or a manifest of
-decoded waveforms through `desta.trainer.data.simple_dataset` (audio FILE decode is out of scope).
+parameters, Adafactor moments, schedule position and step.  Datasets: `synthetic: true` streams (benchmarks, tests), or
+the reference's JSONL manifests through `desta.trainer.data.simple_dataset` (`BaseAudioTextDataset` + `BaseCollateFn`, WAV
+decode + device log-mel) — that path needs the LLM's tokenizer, which is loaded by NAME from the local HF cache
+(`create_tokenizer`; there is no hub access here, tests inject one).
 """
 import argparse
 import logging
@@ -140,13 +142,32 @@ def load_pretrained_weights(model, path: str) -> None:
     model.load_state_dict(sd, strict=False)
 
 
+def create_tokenizer(cfg: "Cfg"):
+    """reference `_setup_generation` (modeling_desta25.py:1465-1470): AutoTokenizer of the LLM by name; offline that is the local
+    HF cache (`HF_HOME`), with `HF_HUB_OFFLINE=1` semantics."""
+    from transformers import AutoTokenizer
+    return AutoTokenizer.from_pretrained(cfg.model.llm.model_id, cache_dir=os.getenv("HF_HOME"), local_files_only=True)
+
+
+def create_datasets(cfg: "Cfg", model, rank: int):
+    """(train_dataset, eval_dataset, data_collator, tokenizer) as the reference builds them (train_desta.py:196-214)."""
+    if cfg.dataset.train_ds.get("synthetic", False):
+        return SyntheticAudioTextDataset(cfg, cfg.dataset.train_ds, model, rank), None, None, None
+    from desta.trainer.data.simple_dataset import BaseAudioTextDataset
+    model._setup_generation(tokenizer=create_tokenizer(cfg))
+    tok, proc = model.tokenizer, model.processor
+    train_ds = BaseAudioTextDataset(cfg, cfg.dataset.train_ds, tok, proc)
+    val_cfg = cfg.dataset.get("validation_ds")
+    eval_ds = BaseAudioTextDataset(cfg, val_cfg, tok, proc) if val_cfg and val_cfg.get("manifest_filepaths") else None
+    return train_ds, eval_ds, train_ds.collate_fn, tok
+
+
 class SyntheticAudioTextDataset:
     """Stands in for BaseAudioTextDataset: yields collated batches (simple_dataset.py:248-264 layout)."""
 
     def __init__(self, cfg: Cfg, data_cfg: Cfg, model, rank: int = 0):
         if not data_cfg.get("synthetic", False):
-            raise NotImplementedError("only `synthetic: true` datasets: manifest loading / audio decode are out of "
-                                      "scope of the MI355X hot path (SURVEY.md §2 rows 3-4)")
+            raise ValueError("SyntheticAudioTextDataset needs `synthetic: true` (manifests go through create_datasets / BaseAudioTextDataset)")
         self.data_cfg, self.model, self.rank = data_cfg, model, rank
         S = data_cfg.context_tokens + model.config.prompt_size + data_cfg.target_tokens
         if S > data_cfg.max_seq_length:
@@ -181,8 +202,9 @@ def main(argv=None):
     model = create_model(cfg, device=f"cuda:{local}")
     if cfg.get("init_from_pretrained_weights"):
         load_pretrained_weights(model, cfg.init_from_pretrained_weights)
-    train_ds = SyntheticAudioTextDataset(cfg, cfg.dataset.train_ds, model, rank)
-    trainer = DeSTA25Trainer(model=model, args=create_training_args(cfg), cfg=cfg, train_dataset=train_ds)
+    train_ds, eval_ds, collate, tok = create_datasets(cfg, model, rank)
+    trainer = DeSTA25Trainer(model=model, args=create_training_args(cfg), cfg=cfg, train_dataset=train_ds, eval_dataset=eval_ds,
+                             data_collator=collate, processing_class=tok)
     if rank == 0:
         with open(os.path.join(cfg.exp_dir, "config.yaml"), "w") as f:
             yaml.safe_dump(dict(cfg), f)

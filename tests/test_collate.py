@@ -3,6 +3,7 @@ the integer / index / string fields the REFERENCE's own classes produced on the 
 (fixture tests/golden/ref_collate.json, made by tests/golden/make_collate_golden.py importing the reference)."""
 import json
 import os
+import sys
 import types
 
 import numpy as np
@@ -10,6 +11,8 @@ import pytest
 import torch
 
 from helpers import COLLATE_CASES, ToyTokenizer
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -164,3 +167,102 @@ def test_chat_level_generate_builds_the_reference_inputs(golden, tmp_path):
     assert gi["context_batch_start_positions"] == [] and gi["batch_features"] is None and gi["context_input_ids"].shape[0] == 2
     assert (gi["context_attention_mask"][0] == 0).sum() > 0 and gi["context_attention_mask"][0, -1] == 1           # left padded
     assert captured["kw"]["eos_token_id"] == [2, ToyTokenizer().convert_tokens_to_ids("<|eot_id|>")] and out.audios == []
+
+
+def _manifest_dataset(tmp_path, records, **kw):
+    import json
+    from desta.trainer.data.simple_dataset import BaseAudioTextDataset
+    root = tmp_path / "audio"
+    root.mkdir(exist_ok=True)
+    for r in records:
+        if not r["id"].startswith("missing"):
+            open(root / r["id"], "wb").close()
+    man = tmp_path / "train.jsonl"
+    man.write_text("".join(json.dumps(r) + "\n" for r in records))
+    cfg = {"model": {"audio_locator": "<|AUDIO|>", "placeholder_token": "<|video_pad|>", "system_prompt": None,
+                     "connector": {"prompt_size": 64, "mode": "qformer_1"}}}
+    return BaseAudioTextDataset(cfg, {"data_root": str(root), "max_seq_length": 4096, "manifest_filepaths": [str(man)]},
+                                ToyTokenizer(), StubProcessor(), **kw), str(man)
+
+
+def test_manifest_disk_cache_protocol(tmp_path, monkeypatch):
+    """`simple_dataset.py:361-452`: first construction preprocesses and publishes `$HF_HOME/desta_preprocessed/<md5>` +
+    `.ready` (lock file gone); the second loads it WITHOUT preprocessing; a broken cache is re-made; rows equal the in-memory path."""
+    import hashlib
+    from desta.trainer.data.simple_dataset import BaseAudioTextDataset
+    monkeypatch.setenv("HF_HOME", str(tmp_path / "hf"))
+    records = COLLATE_CASES["basic"][0]
+    ds, man = _manifest_dataset(tmp_path, records)
+    cache_dir, lock, ready = BaseAudioTextDataset.cache_paths([man])
+    assert cache_dir == str(tmp_path / "hf" / "desta_preprocessed" / hashlib.md5(man.encode()).hexdigest()[:12])
+    assert os.path.isdir(cache_dir) and os.path.exists(ready) and not os.path.exists(lock)
+    mem, _ = _manifest_dataset(tmp_path, records, disk_cache=False)
+    assert len(ds) == len(mem) == 4
+    keys = ("id", "audio_context", "start_positions", "transcription_list", "processed_audios", "target", "length")
+    for i in range(len(ds)):
+        assert {k: ds[i][k] for k in keys} == {k: mem[i][k] for k in keys}, i
+    # collate works on cache rows as on in-memory rows (same integer fields)
+    b1 = ds.collate_fn.__class__(data_cfg={"max_seq_length": 4096}, tokenizer=ToyTokenizer(), processor=StubProcessor(),
+                                 audio_loader=lambda p: _wave_for(os.path.basename(p)))([ds[0], ds[2]])
+    b2 = ds.collate_fn.__class__(data_cfg={"max_seq_length": 4096}, tokenizer=ToyTokenizer(), processor=StubProcessor(),
+                                 audio_loader=lambda p: _wave_for(os.path.basename(p)))([mem[0], mem[2]])
+    assert torch.equal(b1["input_ids"], b2["input_ids"]) and torch.equal(b1["labels"], b2["labels"])
+    assert b1["batch_start_positions"] == b2["batch_start_positions"]
+
+    def boom(self, examples):
+        raise AssertionError("a ready cache must be loaded, not re-made")
+    monkeypatch.setattr(BaseAudioTextDataset, "_preprocess_function", boom)
+    again, _ = _manifest_dataset(tmp_path, records)
+    assert len(again) == 4 and again[1]["audio_context"] == ds[1]["audio_context"]
+    monkeypatch.undo()
+    monkeypatch.setenv("HF_HOME", str(tmp_path / "hf"))
+    for f in os.listdir(cache_dir):                                           # break the cache: load fails -> .ready dropped -> re-made
+        os.remove(os.path.join(cache_dir, f))
+    remade, _ = _manifest_dataset(tmp_path, records)
+    assert len(remade) == 4 and os.path.exists(ready) and not os.path.exists(lock)
+
+
+def _cache_rank(rank, port, tmp, q):
+    import pathlib
+    import torch.distributed as dist
+    sys.path[:0] = [os.path.join(ROOT, "oracle"), os.path.join(ROOT, "desta2.5-audio_amd"), os.path.join(ROOT, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HF_HOME=os.path.join(tmp, "hf"))
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    from desta.trainer.data.simple_dataset import BaseAudioTextDataset
+    BaseAudioTextDataset.READY_POLL_S = 0.2
+    orig = BaseAudioTextDataset._preprocess_function
+    mark = os.path.join(tmp, f"preprocess_calls_rank{rank}")                  # a file: `datasets.map` may run the function in a worker process
+
+    def counting(self, examples):
+        with open(mark, "a") as f:
+            f.write("x")
+        return orig(self, examples)
+    BaseAudioTextDataset._preprocess_function = counting
+    ds, _ = _manifest_dataset(pathlib.Path(tmp), COLLATE_CASES["basic"][0])
+    calls = os.path.getsize(mark) if os.path.exists(mark) else 0
+    q.put((rank, len(ds), calls, [ds[i]["audio_context"] for i in range(len(ds))]))
+    dist.barrier()
+    dist.destroy_process_group()
+    q.close()
+    q.join_thread()
+    os._exit(0)                                                              # skip interpreter teardown (pyarrow / gloo threads): the result is out
+
+
+def test_manifest_disk_cache_two_ranks(tmp_path):
+    """Rank 0 preprocesses, rank 1 preprocesses NOTHING: it waits at the barrier / for `.ready` and loads rank 0's cache."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cache_rank, args=(r, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0, p.exitcode
+    assert res[0][1] == res[1][1] == 4 and res[0][3] == res[1][3]
+    assert res[0][2] >= 1 and res[1][2] == 0

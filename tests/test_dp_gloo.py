@@ -44,6 +44,9 @@ def _worker(rank, world, port, q, empty_rank=-1):
     q.put((rank, float(loss.detach()), arena.grads.clone()))
     dist.barrier()
     dist.destroy_process_group()
+    q.close()
+    q.join_thread()
+    os._exit(0)                                                              # skip interpreter teardown: the result is out
 
 
 @pytest.mark.parametrize("empty_rank", [-1, 1])

@@ -57,3 +57,48 @@ def test_interrupted_6_plus_6_equals_12_steps_through_main(tmp_path):
     assert any(not torch.equal(p6[k], pa[k]) for k in pa)
     with pytest.raises(AssertionError, match="Cannot provide both"):
         m.main(common + [f"exp_dir={tmp_path}/c", f"resume_from_checkpoint={tmp_path}/a/checkpoint-6", "init_from_pretrained_weights=/x.ckpt"])
+
+
+def test_manifest_dataset_through_main(tmp_path, monkeypatch):
+    """Non-synthetic datasets: JSONL manifest + WAVE files -> `BaseAudioTextDataset` (disk cache under HF_HOME) -> seeded
+    DistributedSampler order -> `BaseCollateFn` (device log-mel) -> the trainer, through `main([...])` like the reference's
+    entry point builds them (train_desta.py:196-214).  The tokenizer is injected (no hub access)."""
+    import sys
+    import wave
+
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import ToyTokenizer
+    monkeypatch.setenv("HF_HOME", str(tmp_path / "hf"))
+    rng = np.random.default_rng(0)
+    audio = tmp_path / "audio"
+    audio.mkdir()
+    recs = []
+    for i in range(5):
+        x = 0.1 * rng.standard_normal(16000 + 4000 * i)
+        with wave.open(str(audio / f"clip{i}.wav"), "wb") as w:
+            w.setnchannels(1)
+            w.setsampwidth(2)
+            w.setframerate(16000)
+            w.writeframes((np.clip(x, -1, 1) * 32767).astype("<i2").tobytes())
+        recs.append(dict(id=f"clip{i}.wav", prompt=f"describe clip number {i}", response="some noise " * (1 + i % 3)))
+    recs.append(dict(id="clip0.wav", prompt="", response="skipped: empty prompt"))
+    man = tmp_path / "train.jsonl"
+    man.write_text("".join(json.dumps(r) + "\n" for r in recs))
+    m = _mod()
+    monkeypatch.setattr(m, "create_tokenizer", lambda cfg: ToyTokenizer(vocab_size=512))
+    tr = m.main(["--config-name", "desta25_debug", "+dataset=debug", f"exp_dir={tmp_path}/exp", "trainer.max_epochs=2", "trainer.max_steps=-1",
+                 "optim.sched.warmup_steps=0", "optim.lr=1e-3", "dataset.train_ds.synthetic=false", f"dataset.train_ds.data_root={audio}",
+                 f"dataset.train_ds.manifest_filepaths=[{man}]", "dataset.validation_ds.synthetic=false"])
+    assert len(tr.train_dataset) == 5                                          # the empty-prompt record is filtered
+    assert tr.steps_per_epoch() == 3 and tr.total_steps == 6 and tr.global_step == 6          # ceil(5 / 2) steps x 2 epochs
+    assert os.path.isdir(tmp_path / "exp" / "checkpoint-3") and os.path.isdir(tmp_path / "exp" / "checkpoint-6")
+    assert os.path.exists(str(tr.train_dataset.cache_paths([str(man)])[2]))    # the `.ready` file of the disk cache
+    losses = [h["train/loss"] if "train/loss" in h else h.get("loss") for h in tr.log_history if ("train/loss" in h or "loss" in h)]
+    assert all(l is None or (l == l and l > 0) for l in losses)
+    # epoch order: a permutation from seed + epoch, every sample once per epoch
+    seen = []
+    tr.data_collator = lambda rows: [r["id"] if "id" in r else r["processed_audios"][0]["audio"] for r in rows]
+    for ep in (0, 1):
+        seen.append([x for b in tr._epoch_batches(ep) for x in b])
+    assert sorted(seen[0]) == sorted(seen[1]) and len(set(seen[0])) == 5 and seen[0] != seen[1]
