@@ -12,6 +12,7 @@ step t run on a side HIP stream concurrently with the frozen Whisper forward of 
 """
 from __future__ import annotations
 
+import json
 import logging
 import math
 import os
@@ -89,6 +90,8 @@ class DeSTA25Trainer:
         self.model, self.cfg, self.args = model, cfg, args or TrainingArguments()
         self.train_dataset, self.eval_dataset, self.data_collator = train_dataset, eval_dataset, data_collator
         self.processing_class = processing_class
+        from ..utils.metrics import ConsecutiveWordsAccuracyMetric
+        self.metrics = ConsecutiveWordsAccuracyMetric()                       # desta_trainer.py:36
         if self.args.optim != "adafactor":
             raise NotImplementedError("only optim='adafactor' (train_desta.py:149) is implemented")
         if self.args.gradient_accumulation_steps != 1:
@@ -314,9 +317,78 @@ class DeSTA25Trainer:
         finally:
             self.model.train(was_training)
         ls = torch.stack(losses).double() if losses else torch.zeros(1, dtype=torch.float64, device=self.model.device)
-        metrics = {f"{metric_key_prefix}_loss": float(ls.mean()), f"{metric_key_prefix}_ppl": float(torch.exp(ls).mean())}
+        metrics = {f"{metric_key_prefix}_loss": float(ls.mean()) if losses else 0.0,
+                   f"{metric_key_prefix}_ppl": float(torch.exp(ls).mean()) if losses else 0.0}
+        # desta_trainer.py:134-152: predictions JSONL + accuracy report under <exp_dir>/results/val, accuracy metrics
+        exp_dir = self._cfg_get("exp_dir")
+        decoded = bool(self.prediction_step_outputs) and all("prediction" in r and "label" in r for r in self.prediction_step_outputs)
+        if exp_dir and (decoded or not self.prediction_step_outputs):
+            spe = self.steps_per_epoch()
+            epoch = (self.global_step / spe) if spe else 0.0
+            ckpt = f"ep={epoch}-{self.global_step}"
+            report = self._save_results(self.prediction_step_outputs, os.path.join(exp_dir, "results", "val", f"val@{ckpt}.jsonl"), ckpt)
+            metrics[f"{metric_key_prefix}_accuracy"] = report.get("accuracy_by_sample", 0)
+            metrics[f"{metric_key_prefix}_accuracy_by_category"] = report.get("avg_accuracy_by_category", 0)
+            for category, acc in report.get("categories_accuracy", {}).items():
+                metrics[f"{metric_key_prefix}_acc/{category}"] = acc
         self.log_history.append(dict(metrics))
         return metrics
+
+    def _cfg_get(self, key: str, default=None):
+        c = self.cfg
+        if c is None:
+            return default
+        return c.get(key, default) if hasattr(c, "get") else getattr(c, key, default)
+
+    def _save_results(self, results: List[Dict[str, Any]], filepath, ckpt: Optional[str] = None) -> Dict[str, Any]:
+        """desta_trainer.py:191-251: `<dir>/preds/<name>.jsonl` (one row per prediction with `correct` and `index`; an existing
+        file is never overwritten: `-1`, `-2`, ... — the reference's `lulutils.get_unique_filepath` is third-party and absent,
+        its suffix rule is unpinned) and `<dir>/<name>-report.json` with per-sample / per-category accuracy."""
+        import subprocess
+        from collections import defaultdict
+        from ..utils.metrics import ConsecutiveWordsAccuracyMetric
+        metric = getattr(self, "metrics", None) or ConsecutiveWordsAccuracyMetric()
+        filepath = str(filepath)
+        d, name = os.path.join(os.path.dirname(filepath), "preds"), os.path.basename(filepath)
+        os.makedirs(d, exist_ok=True)
+        stem, ext = os.path.splitext(name)
+        jsonl_path, k = os.path.join(d, name), 0
+        while os.path.exists(jsonl_path):
+            k += 1
+            jsonl_path = os.path.join(d, f"{stem}-{k}{ext}")
+        by_cat = defaultdict(list)
+        with open(jsonl_path, "w") as f:
+            for i, r in enumerate(results):
+                r["correct"] = bool(metric(r["prediction"], r["label"]))
+                r["index"] = i
+                f.write(json.dumps(r, ensure_ascii=False) + "\n")
+                by_cat[r.get("category", "all")].append(r["correct"])
+        try:
+            commit = subprocess.check_output("git rev-parse HEAD", shell=True, text=True, stderr=subprocess.DEVNULL).strip()
+        except subprocess.SubprocessError:
+            commit = None
+        cfg = self.cfg
+        if cfg is not None and not isinstance(cfg, dict) and hasattr(cfg, "items"):
+            cfg = dict(cfg.items())
+        exp_dir = (self.cfg.get("exp_dir") if hasattr(self.cfg, "get") else getattr(self.cfg, "exp_dir", None)) if self.cfg is not None else None
+        report = {
+            "metric": metric.metric_name,
+            "preds_path": jsonl_path,
+            "accuracy_by_sample": sum(r["correct"] for r in results) / (len(results) or 1),
+            "avg_accuracy_by_category": (sum(sum(v) / len(v) for v in by_cat.values()) / len(by_cat)) if by_cat else 0,
+            "categories_accuracy": {c: sum(v) / len(v) for c, v in by_cat.items()},
+            "ckpt": str(ckpt),
+            "results": [{k_: v for k_, v in r.items() if k_ not in {"context", "audio_context"}} for r in results],
+            "exp_dir": exp_dir,
+            "config": cfg if isinstance(cfg, dict) else None,
+            "commit": commit,
+            "name": "DeSTA2.5-Audio",
+        }
+        report_path = os.path.join(os.path.dirname(d), os.path.basename(jsonl_path).replace(".jsonl", "-report.json"))
+        with open(report_path, "w") as f:
+            json.dump(report, f, indent=2, ensure_ascii=False, default=str)
+        logging.info(f"Report saved to {report_path}")
+        return report
 
     def _predict_step(self, batch: Dict[str, Any], generation_kwargs: Optional[Dict[str, Any]] = None) -> torch.Tensor:
         """desta_trainer.py:160-189: generate from the context part of the batch; decode when a tokenizer is attached."""

@@ -89,13 +89,22 @@ def test_manifest_dataset_through_main(tmp_path, monkeypatch):
     monkeypatch.setattr(m, "create_tokenizer", lambda cfg: ToyTokenizer(vocab_size=512))
     tr = m.main(["--config-name", "desta25_debug", "+dataset=debug", f"exp_dir={tmp_path}/exp", "trainer.max_epochs=2", "trainer.max_steps=-1",
                  "optim.sched.warmup_steps=0", "optim.lr=1e-3", "dataset.train_ds.synthetic=false", f"dataset.train_ds.data_root={audio}",
-                 f"dataset.train_ds.manifest_filepaths=[{man}]", "dataset.validation_ds.synthetic=false"])
+                 f"dataset.train_ds.manifest_filepaths=[{man}]", "dataset.validation_ds.synthetic=false",
+                 f"dataset.validation_ds.manifest_filepaths=[{man}]", f"dataset.validation_ds.data_root={audio}"])
     assert len(tr.train_dataset) == 5                                          # the empty-prompt record is filtered
     assert tr.steps_per_epoch() == 3 and tr.total_steps == 6 and tr.global_step == 6          # ceil(5 / 2) steps x 2 epochs
     assert os.path.isdir(tmp_path / "exp" / "checkpoint-3") and os.path.isdir(tmp_path / "exp" / "checkpoint-6")
     assert os.path.exists(str(tr.train_dataset.cache_paths([str(man)])[2]))    # the `.ready` file of the disk cache
     losses = [h["train/loss"] if "train/loss" in h else h.get("loss") for h in tr.log_history if ("train/loss" in h or "loss" in h)]
     assert all(l is None or (l == l and l > 0) for l in losses)
+    # the reference's validation loop (desta_trainer.py:104-158): loss / ppl, generation, predictions JSONL + accuracy report
+    ev = tr.evaluate(generation_kwargs={"max_new_tokens": 3})
+    assert {"eval_loss", "eval_ppl", "eval_accuracy", "eval_accuracy_by_category", "eval_acc/all"} <= set(ev) and ev["eval_loss"] > 0
+    assert len(tr.prediction_step_outputs) == 5 and 0.0 <= ev["eval_accuracy"] <= 1.0
+    val = tmp_path / "exp" / "results" / "val"
+    assert len(os.listdir(val / "preds")) == 1 and any(f.endswith("-report.json") for f in os.listdir(val))
+    rows = [json.loads(l) for l in open(val / "preds" / os.listdir(val / "preds")[0])]
+    assert len(rows) == 5 and all({"prediction", "label", "context", "correct", "index"} <= set(r) for r in rows)
     # epoch order: a permutation from seed + epoch, every sample once per epoch
     seen = []
     tr.data_collator = lambda rows: [r["id"] if "id" in r else r["processed_audios"][0]["audio"] for r in rows]
