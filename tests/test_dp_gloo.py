@@ -41,7 +41,7 @@ def _worker(rank, world, port, q, empty_rank=-1):
         for n in names:
             arena.grad(n).copy_(w[n].grad)
     allreduce_mean_(arena.grads)
-    q.put((rank, float(loss.detach()), arena.grads.clone()))
+    q.put((rank, float(loss.detach()), arena.grads.clone().numpy()))       # by value: a torch tensor travels as a shared-memory handle the parent must fetch while this process is alive
     dist.barrier()
     dist.destroy_process_group()
     q.close()
@@ -62,6 +62,7 @@ def test_two_rank_gradient_mean_matches_single_process(empty_rank):
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    res = [(r, l, torch.from_numpy(g)) for r, l, g in res]
     for p in procs:
         p.join(120)
         assert p.exitcode == 0, p.exitcode
