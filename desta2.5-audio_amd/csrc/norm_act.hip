@@ -255,37 +255,43 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_k(const bf16_t* __restrict__ 
     const int lane = threadIdx.x & 63, row = blockIdx.x * RPB + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float rstd = rstd_in[row];
-    float xh[MAXV][8], gy[MAXV][8];
+    // every load of the row is issued up front and kept as raw bf16 (12 registers per 8 columns instead of 16 floats + a
+    // second, dependent residual load after the reduction): a one-row wave exposes ONE memory latency and three waves fit a SIMD
+    u16x8 xr[MAXV], dyr[MAXV], rres[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < cols) {
+            xr[i] = *(const u16x8*)(x + (long)row * cols + c);
+            dyr[i] = *(const u16x8*)(dy + (long)row * cols + c);
+            if (dres) rres[i] = *(const u16x8*)(dres + (long)row * cols + c);
+        }
+    }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = (i * 64 + lane) * 8;
         if (c < cols) {
-            float xv[8], dyv[8], g[8];
-            load8(x, (long)row * cols + c, 0, xv);
-            load8(dy, (long)row * cols + c, 0, dyv);
+            float g[8];
             load8(w, c, 1, g);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                xh[i][e] = xv[e] * rstd;
-                gy[i][e] = dyv[e] * g[e];
-                s += gy[i][e] * xh[i][e];
-            }
+            for (int e = 0; e < 8; ++e) s += (bf2f(dyr[i][e]) * g[e]) * (bf2f(xr[i][e]) * rstd);
         }
     }
     s = wave_sum(s) / (float)cols;
 #pragma unroll
+    for (int i = 0; i < MAXV; ++i) asm volatile("" : "+v"(xr[i]), "+v"(dyr[i]));        // opaque: convert again below instead of keeping 16 floats per vector alive
+#pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = (i * 64 + lane) * 8;
         if (c < cols) {
-            float o[8];
+            float g[8], o[8];
+            load8(w, c, 1, g);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = rstd * (gy[i][e] - xh[i][e] * s);
+            for (int e = 0; e < 8; ++e) o[e] = rstd * (bf2f(dyr[i][e]) * g[e] - (bf2f(xr[i][e]) * rstd) * s);
             if (dres) {
-                float r[8];
-                load8(dres, (long)row * cols + c, 0, r);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] += r[e];
+                for (int e = 0; e < 8; ++e) o[e] += bf2f(rres[i][e]);
             }
             store8_bf16(dx, (long)row * cols + c, o);
         }
