@@ -171,6 +171,7 @@ def main():
     ap.add_argument("--repeat", type=int, default=1, help="repeat the timed region (reports the best), for A/B runs")
     ap.add_argument("--no-dw-overlap", action="store_true", help="A/B: Q-Former weight gradients on the main stream")
     ap.add_argument("--gemm-4phase", action="store_true", help="A/B: the 4-phase (16 MFMAs per phase) GEMM schedule")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the process group and run the gradient all-reduce even at WORLD_SIZE 1 (one-GPU rehearsal of the N > 1 path over RCCL)")
     ap.add_argument("--small-gemm-ring", type=int, default=None, help="A/B: option 6 of desta_gemm_set_option (0 = the 128x128 GEMM never takes its four-slot ring form, 1 = default, 2 = always)")
     ap.add_argument("--splitk-inkernel", action="store_true", help="A/B: reduce the K-slices of tail tiles inside the GEMM launch (scattered, ticketed) instead of by the fix-up launch")
     ap.add_argument("--full-lm-head", action="store_true", help="A/B: lm_head / CE over the whole token grid, not only the target rows")
@@ -189,7 +190,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.single_device:
         local = 0
-    if world > 1:
+    if a.force_dist:                                     # rehearsal of the N > 1 plumbing on ONE GPU: RCCL communicator, AVG all-reduce of
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")  # the gradient arena on the side stream, barrier fences, MAX over ranks
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ["DESTA_ALLREDUCE_WORLD1"] = "1"
+    if world > 1 or a.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
         if a.backend == "nccl":
@@ -260,7 +267,7 @@ def main():
         return loss
 
     def fence():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -290,7 +297,7 @@ def main():
     n_other = sum(v[0] for k, v in prof.items() if k != 2)
     ms_other = sum(v[2] for k, v in prof.items() if k != 2)
     flops_other = sum(v[1] for k, v in prof.items() if k != 2)
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
@@ -371,7 +378,7 @@ def main():
             except Exception as ex:                                   # noqa: BLE001
                 out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": 0, "kind": "port", "sample": f"failed: {ex}"}
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -53,7 +53,9 @@ class TrainingArguments:
 def allreduce_mean_(flat: torch.Tensor) -> None:
     """Mean over data-parallel ranks of ONE flat buffer (what DDP's bucketed reducer does for the
     reference, accelerate `accelerator.py:1892`): RCCL AVG over xGMI on GPUs, SUM + scale on gloo."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    if dist.get_world_size() == 1 and not os.environ.get("DESTA_ALLREDUCE_WORLD1"):      # (set by `bench.py --force-dist`: rehearsal of the collective on one GPU)
         return
     if dist.get_backend() == "nccl":
         dist.all_reduce(flat, op=dist.ReduceOp.AVG)

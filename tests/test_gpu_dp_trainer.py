@@ -46,11 +46,16 @@ def worker(out_dir):
     _setup_paths()
     import torch.distributed as dist
     rank = int(os.environ["RANK"])
-    dist.init_process_group("gloo", rank=rank, world_size=int(os.environ["WORLD_SIZE"]))
+    world = int(os.environ["WORLD_SIZE"])
+    if os.environ.get("DESTA_TEST_BACKEND") == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from desta.trainer.desta_trainer import DeSTA25Trainer, TrainingArguments
     d, model = _model()
     tr = DeSTA25Trainer(model, args=TrainingArguments(learning_rate=LR, warmup_steps=WARM, max_steps=TOTAL, logging_steps=1, overlap_comm=True))
-    assert tr.world == 2 and tr._side is not None and model.dropout_seed == 1 + rank
+    assert tr.world == world and tr._side is not None and model.dropout_seed == 1 + rank
     losses = tr.train(_batches(d, rank))
     assert tr.global_step == STEPS and tr.optimizer.step_count == STEPS
     torch.save({"params": model.arena.params.cpu(), "state": tr.optimizer.state.cpu(), "losses": losses}, os.path.join(out_dir, f"rank{rank}.pt"))
@@ -102,6 +107,31 @@ def test_two_rank_trainer_bit_identical_and_equals_single_process_mean(tmp_path)
     torch.cuda.synchronize()
     assert torch.equal(model.arena.params.cpu(), r0["params"]), float((model.arena.params.cpu() - r0["params"]).abs().max())
     assert torch.equal(opt.state.cpu(), r0["state"])
+
+
+@pytest.mark.gpu
+def test_rccl_branch_at_world_size_one_is_the_identity(tmp_path):
+    """The `nccl` (= RCCL) branch of `allreduce_mean_` — `all_reduce(AVG)` of the flat fp32 arena on the trainer's side stream —
+    needs one device per rank, so on a one-GPU box it runs at world size 1 (forced through the collective): RCCL communicator
+    with `device_id`, the AVG op on this ROCm build, stream ordering against the fused optimizer.  AVG over one rank is the
+    identity: parameters / optimizer state equal an undistributed trainer bit for bit."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="1", RANK="0", DESTA_TEST_BACKEND="nccl",
+               DESTA_ALLREDUCE_WORLD1="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", str(tmp_path)], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:]
+    r0 = torch.load(tmp_path / "rank0.pt", weights_only=True)
+    _setup_paths()
+    from desta.trainer.desta_trainer import DeSTA25Trainer, TrainingArguments
+    d, model = _model()
+    tr = DeSTA25Trainer(model, args=TrainingArguments(learning_rate=LR, warmup_steps=WARM, max_steps=TOTAL, logging_steps=1, overlap_comm=True))
+    losses = tr.train(_batches(d, 0))
+    assert losses == r0["losses"]
+    assert torch.equal(model.arena.params.cpu(), r0["params"]) and torch.equal(tr.optimizer.state.cpu(), r0["state"])
 
 
 if __name__ == "__main__" and len(sys.argv) >= 3 and sys.argv[1] == "--worker":
