@@ -12,8 +12,8 @@
 //   C  af_usq      : per 16384-element CHUNK of one tensor: u = c g r[row] c[col], sum u^2 of the chunk      (g read)
 //   D  af_apply    : rms(u) of the WHOLE tensor from its chunk sums in chunk order, then
 //                    p = p (1 - wd lr) - lr u / max(1, rms(u) / clip_thr)                     (g re-read, p read + write)
-//      C and D are launched per GROUP of whole tensors (<= 64 MB of g): D's re-read of the group's g is served by the
-//      256 MB Infinity Cache, not HBM.  Every thread issues all 16 float4 loads of its chunk before the first use
+//      C and D run per GROUP of whole tensors (<= 64 MB of g): D's re-read of the group's g is served by the 256 MB
+//      Infinity Cache, not HBM; D of group i and C of group i+1 share one launch.  Every thread issues all 16 float4 loads of its chunk before the first use
 //      (64 KB in flight per block).  1-D tensors ride in the last D launch, one work item per vector.
 //
 // HBM traffic: g twice (A, C) + p read + p write = 16 N bytes (N = trainable fp32 values); the algorithm's floor
@@ -290,14 +290,24 @@ __global__ __launch_bounds__(256, 3) void af_usq(Tab tb, Ws ws, const float* __r
     if (threadIdx.x == 0) ws.chunk_usq[item] = tot;
 }
 
-// D: apply; blocks past the group's chunks handle the 1-D tensors (last group only)
+// D: apply of one group; the blocks past its chunks run C (sum u^2) of the NEXT group in the same launch (independent work: one
+// launch boundary less per group and twice the blocks to fill the chip), and after those the 1-D tensors (last group only)
 __global__ __launch_bounds__(256, 3) void af_apply(Tab tb, Ws ws, const float* __restrict__ g, float* __restrict__ p,
                                                    float* __restrict__ state, float beta2t, float eps1, float lr, float clip_thr,
-                                                   int chunk0, int nchunks) {
+                                                   int chunk0, int nchunks, int usq_chunk0, int usq_n) {
     __shared__ float red[4];
     const float c = ws.scalars[1];
     if ((int)blockIdx.x >= nchunks) {
-        vec_item(tb, ws, blockIdx.x - nchunks, g, p, state, c, beta2t, eps1, lr, clip_thr, red);
+        const int j = blockIdx.x - nchunks;
+        if (j < usq_n) {
+            float4 u[CHUNK_V4];
+            int t, cnt; long pbase;
+            float tot = chunk_u(tb, ws, g, usq_chunk0 + j, c, u, t, pbase, cnt);
+            tot = block_sum<256>(tot, red);
+            if (threadIdx.x == 0) ws.chunk_usq[usq_chunk0 + j] = tot;
+            return;
+        }
+        vec_item(tb, ws, j - usq_n, g, p, state, c, beta2t, eps1, lr, clip_thr, red);
         return;
     }
     const int item = chunk0 + blockIdx.x;
@@ -452,10 +462,14 @@ extern "C" int desta_clip_adafactor_step(const desta_opt_plan* pl, float* params
                         "adafactor: bad group table");
         for (int gi = 0; gi < pl->n_groups; ++gi) {
             const int c0 = pl->group_bounds[gi], n = pl->group_bounds[gi + 1] - c0;
-            const int nv = (gi == pl->n_groups - 1) ? tb.V : 0;
+            const bool last = gi == pl->n_groups - 1;
+            const int nv = last ? tb.V : 0;
+            const int c1 = last ? 0 : pl->group_bounds[gi + 1], n1 = last ? 0 : pl->group_bounds[gi + 2] - c1;
             DESTA_CHECK_ARG(n > 0, "adafactor: empty group");
-            hipLaunchKernelGGL(af_usq, dim3(n), dim3(256), 0, st, tb, ws, grads, c0);
-            hipLaunchKernelGGL(af_apply, dim3(n + nv), dim3(256), 0, st, tb, ws, grads, params, state, beta2t, eps1, lr, clip_threshold, c0, n);
+            if (gi == 0) hipLaunchKernelGGL(af_usq, dim3(n), dim3(256), 0, st, tb, ws, grads, c0);
+            // apply(group gi) + sum u^2 of group gi+1 (whole tensors per group: a tensor's chunk sums are complete before its apply)
+            hipLaunchKernelGGL(af_apply, dim3(n + n1 + nv), dim3(256), 0, st, tb, ws, grads, params, state, beta2t, eps1, lr, clip_threshold,
+                               c0, n, c1, n1);
         }
     } else {
         hipLaunchKernelGGL(k34_update<false>, dim3(tb.U), dim3(256), 0, st, tb, ws, grads, params, lr, clip_threshold, ws.chunk_usq);
