@@ -1338,6 +1338,17 @@ class DeSTA25AudioModel:
 
     def backward(self) -> None:
         """Gradients of the last forward's loss w.r.t. every connector tensor -> arena.grads (overwritten)."""
+        self.backward_connector(self.backward_llm())
+
+    def backward_connector(self, d_af: torch.Tensor) -> None:
+        """Second half of `backward`: d_af = dL/d audio_features -> every connector gradient.  Its ~600 small launches (2048-row
+        GEMMs, LayerNorms, cross-attention) leave most of the chip idle, and nothing of the NEXT batch's frozen Whisper forward
+        depends on them: the trainer runs this half on its side stream beside that forward (`overlap_comm`)."""
+        with torch.cuda.device(self.device):
+            self.connector.backward(d_af)
+
+    def backward_llm(self) -> torch.Tensor:
+        """First half of `backward`: dX through the frozen LLM down to the audio rows; returns dL/d audio_features [N_audio*K, h]."""
         f = self._fwd
         if not f or not f["has_grad"]:
             raise RuntimeError("backward() needs a training-mode forward with labels and at least one audio")
@@ -1351,5 +1362,5 @@ class DeSTA25AudioModel:
                 idx = torch.cat([torch.arange(r * S + s, r * S + s + K, dtype=torch.int32) for r, s in f["starts"]]).to(self.device)
             d_af = torch.empty(f["N_audio"] * K, self.config.llm_config.hidden_size, dtype=BF16, device=self.device)
             H.gather_rows(dx0, idx, f["N_audio"] * K, self.config.llm_config.hidden_size, d_af)
-            self.connector.backward(d_af)
         self._fwd = None
+        return d_af

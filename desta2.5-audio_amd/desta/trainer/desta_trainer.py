@@ -43,6 +43,7 @@ class TrainingArguments:
     optim: str = "adafactor"
     bf16: bool = True
     overlap_comm: bool = True
+    overlap_connector_backward: bool = False       # with overlap_comm: the connector's backward ALSO runs on the side stream beside the next batch's Whisper forward (A/B: -0.4 ms per step, and it inflates the per-kernel durations of both streams: off)
     overlap_encoder: bool = False                  # next batch's frozen Whisper forward on its own HIP stream beside the LLM (A/B: -1.2 % step time, see DESIGN)
     save_strategy: str = "no"                      # "epoch" (train_desta.py:146, enable_checkpointing) | "no"
     steps_per_epoch: Optional[int] = None          # len(train dataloader) when the dataset is not sized (synthetic streams)
@@ -196,8 +197,12 @@ class DeSTA25Trainer:
             # collective forever and step counts diverge (under DDP the reference deadlocks here).  It contributes zeros: the
             # update is the mean over ranks with this rank's share empty.
             model.arena.grads.zero_()
+            d_af = None
+        elif self._side is not None and self.args.overlap_connector_backward:
+            d_af = model.backward_llm()                                       # dX through the frozen LLM: main stream
         else:
             model.backward()
+            d_af = None
         self.global_step += 1
         lr = linear_warmup_lr(self.global_step - 1, self.args.learning_rate, self.args.warmup_steps, self.total_steps)
         if self._side is None:
@@ -207,6 +212,12 @@ class DeSTA25Trainer:
             main = torch.cuda.current_stream(model.device)
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
+                if d_af is not None:
+                    # the connector's backward (hundreds of small launches that leave most CUs idle) joins the tail on the side
+                    # stream: the main stream goes straight on to the next batch's frozen Whisper forward, which reads nothing
+                    # this half writes (its tapped states go to the OTHER encoder buffer)
+                    d_af.record_stream(self._side)                            # allocated on the main stream, last read here
+                    model.backward_connector(d_af)
                 self._reduce_and_update(lr)
                 ev = torch.cuda.Event()
                 ev.record(self._side)

@@ -3,6 +3,12 @@ import sys
 
 import pytest
 
+# there is no network here or on the GPU box: keep `datasets` / `huggingface_hub` (imported by the dataset-cache tests, also in
+# their spawned ranks, which inherit the environment) from probing the hub with their retry / back-off loops
+os.environ.setdefault("HF_HUB_OFFLINE", "1")
+os.environ.setdefault("HF_DATASETS_OFFLINE", "1")
+os.environ.setdefault("TRANSFORMERS_OFFLINE", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "desta2.5-audio_amd")):
     if p not in sys.path:
