@@ -8,10 +8,10 @@
 //   clamp to (per-clip global max - 8); (x + 4) / 4.
 //
 // K1: one block = 32 frames of one clip.  The 32 windowed frames are staged in LDS as x[n][frame]
-//     (coalesced HBM read of the 5.3 K-sample span, LDS-staged frames), then every thread owns one
-//     DFT bin x 16 frames and runs the 400-point DFT as broadcast LDS reads + FMAs with a 400-entry
-//     twiddle table (index (k*n) mod 400 kept incrementally).  Power -> LDS -> dense mel product
-//     -> log10 -> raw store + per-block max.
+//     (coalesced HBM read of the 5.3 K-sample span), folded in place into their even / odd parts, then every
+//     thread owns the bin PAIR (k, 200-k) x 8 frames and runs the real-input DFT as broadcast LDS reads + FMAs
+//     with a 400-entry twiddle table (index (k*n) mod 400 kept incrementally): a quarter of the multiplies of the
+//     plain 400-point sum.  Power -> LDS -> dense mel product -> log10 -> raw store + per-block max.
 // K2: per-clip max from the block maxima, clamp + affine in place.
 #include "common.h"
 #include "desta_hip.h"
@@ -39,6 +39,7 @@ __global__ __launch_bounds__(NT) void logmel_k1(const float* __restrict__ wave, 
     const float* w = wave + (long)b * wave_stride;
     const float* win = tables;
     const float* fb = tables + 3 * N_FFT;              // [201][n_mels]
+    const float* krange = fb + N_BINS * n_mels;        // [n_mels][2]: non-zero DFT-bin range of every mel filter
 
     for (int i = threadIdx.x; i < 2 * N_FFT; i += NT) tw[i] = tables[N_FFT + i];
     // stage windowed frames: idx -> (f, n), n fastest: coalesced global reads
@@ -52,33 +53,66 @@ __global__ __launch_bounds__(NT) void logmel_k1(const float* __restrict__ wave, 
     }
     __syncthreads();
 
-    // DFT: worker (k, half) owns bin k for frames half*16 .. half*16+15
-    const int k = threadIdx.x % N_BINS, half = threadIdx.x / N_BINS;
-    float re[16], im[16];
+    // Real-input symmetries cut the 400-point DFT to a quarter of its multiplies:
+    //   * fold: with e[n] = x[n] + x[400-n], o[n] = x[n] - x[400-n] (n = 1..199; e[0] = x[0], e[200] = x[200]),
+    //       Re X[k] = sum_{n=0..200} e[n] cos(2 pi k n / 400),   Im X[k] = -sum_{n=1..199} o[n] sin(2 pi k n / 400);
+    //   * bins k and 200-k share every twiddle up to (-1)^n: accumulating even and odd n apart gives both,
+    //       Re X[k] = Ee + Eo, Re X[200-k] = Ee - Eo;  |Im X[k]| = |Oe + Oo|, |Im X[200-k]| = |Oe - Oo|.
+    // The fold is done in place in LDS (row n <- e, row 400-n <- o).
+    for (int idx = threadIdx.x; idx < 199 * FT; idx += NT) {
+        const int n = 1 + (idx >> 5), f = idx & (FT - 1);
+        const float u = xs[n * XS + f], v = xs[(N_FFT - n) * XS + f];
+        xs[n * XS + f] = u + v;
+        xs[(N_FFT - n) * XS + f] = u - v;
+    }
+    __syncthreads();
+    // worker (k in 0..100, quarter): bins k and 200-k for frames quarter*8 .. +7; 404 of the 448 threads
+    constexpr int NK = 101, FQ = 8;
+    const int k = threadIdx.x % NK, quarter = threadIdx.x / NK;
+    const bool worker = quarter < FT / FQ;
+    float ee[FQ], eo[FQ], oe[FQ], oo[FQ];
 #pragma unroll
-    for (int f = 0; f < 16; ++f) { re[f] = 0.f; im[f] = 0.f; }
-    if (half < 2) {
-        int ti = 0;
-        const float* xrow = xs + half * 16;
-        for (int n = 0; n < N_FFT; ++n) {
-            const float c = tw[ti], s = tw[N_FFT + ti];
-            ti += k;
-            if (ti >= N_FFT) ti -= N_FFT;
-            const float4* xv = (const float4*)(xrow + n * XS);
+    for (int f = 0; f < FQ; ++f) { ee[f] = 0.f; eo[f] = 0.f; oe[f] = 0.f; oo[f] = 0.f; }
+    if (worker) {
+        const float* xq = xs + quarter * FQ;
+        auto ld8 = [&](int row, float (&x)[FQ]) {
+            const float4 a = *(const float4*)(xq + row * XS), c = *(const float4*)(xq + row * XS + 4);
+            x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = c.x; x[5] = c.y; x[6] = c.z; x[7] = c.w;
+        };
+        auto step = [&](int n, int ti, float (&re)[FQ], float (&im)[FQ]) {
+            const float c = tw[ti], sn = tw[N_FFT + ti];
+            float e[FQ], o[FQ];
+            ld8(n, e);
+            ld8(N_FFT - n, o);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 x = xv[q];
-                re[4 * q + 0] = fmaf(x.x, c, re[4 * q + 0]); im[4 * q + 0] = fmaf(x.x, s, im[4 * q + 0]);
-                re[4 * q + 1] = fmaf(x.y, c, re[4 * q + 1]); im[4 * q + 1] = fmaf(x.y, s, im[4 * q + 1]);
-                re[4 * q + 2] = fmaf(x.z, c, re[4 * q + 2]); im[4 * q + 2] = fmaf(x.z, s, im[4 * q + 2]);
-                re[4 * q + 3] = fmaf(x.w, c, re[4 * q + 3]); im[4 * q + 3] = fmaf(x.w, s, im[4 * q + 3]);
-            }
+            for (int f = 0; f < FQ; ++f) { re[f] = fmaf(e[f], c, re[f]); im[f] = fmaf(o[f], sn, im[f]); }
+        };
+        {                                                                  // n = 0 (cos = 1) and n = 200 (cos = (-1)^k): even n, no sine part
+            float x0[FQ], x200[FQ];
+            ld8(0, x0);
+            ld8(200, x200);
+            const float sg = (k & 1) ? -1.f : 1.f;
+#pragma unroll
+            for (int f = 0; f < FQ; ++f) ee[f] = fmaf(x200[f], sg, x0[f]);
         }
+        int ti = 0;
+        for (int m = 0; m < 99; ++m) {                                     // n = 2m+1 (odd), 2m+2 (even)
+            ti += k; if (ti >= N_FFT) ti -= N_FFT;
+            step(2 * m + 1, ti, eo, oo);
+            ti += k; if (ti >= N_FFT) ti -= N_FFT;
+            step(2 * m + 2, ti, ee, oe);
+        }
+        ti += k; if (ti >= N_FFT) ti -= N_FFT;
+        step(199, ti, eo, oo);
     }
     __syncthreads();                                   // everyone is done reading xs (pw aliases it)
-    if (half < 2) {
+    if (worker) {
 #pragma unroll
-        for (int f = 0; f < 16; ++f) pw[(half * 16 + f) * N_BINS + k] = re[f] * re[f] + im[f] * im[f];
+        for (int f = 0; f < FQ; ++f) {
+            const float r1 = ee[f] + eo[f], i1 = oe[f] + oo[f], r2 = ee[f] - eo[f], i2 = oe[f] - oo[f];
+            pw[(quarter * FQ + f) * N_BINS + k] = r1 * r1 + i1 * i1;
+            pw[(quarter * FQ + f) * N_BINS + (N_BINS - 1 - k)] = r2 * r2 + i2 * i2;      // k = 100 writes bin 100 twice with equal values
+        }
     }
     __syncthreads();
 
@@ -88,7 +122,8 @@ __global__ __launch_bounds__(NT) void logmel_k1(const float* __restrict__ wave, 
         const int f = item & (FT - 1), m = item >> 5;
         const float* pf = pw + f * N_BINS;
         float acc = 0.f;
-        for (int kk = 0; kk < N_BINS; ++kk) acc = fmaf(fb[kk * n_mels + m], pf[kk], acc);
+        const int klo = (int)krange[2 * m], khi = (int)krange[2 * m + 1];
+        for (int kk = klo; kk < khi; ++kk) acc = fmaf(fb[kk * n_mels + m], pf[kk], acc);
         const float lv = log10f(fmaxf(acc, 1e-10f));
         const int t = t0 + f;
         if (t < N_FRAMES) {
@@ -128,10 +163,12 @@ double mel_to_hz(double m) { return m >= 15.0 ? 1000.0 * exp((log(6.4) / 27.0) *
 
 }  // namespace
 
-extern "C" size_t desta_logmel_table_floats(int n_mels) { return (size_t)(3 * N_FFT + N_BINS * n_mels); }
+extern "C" size_t desta_logmel_table_floats(int n_mels) { return (size_t)(3 * N_FFT + N_BINS * n_mels + 2 * n_mels); }
 extern "C" size_t desta_logmel_workspace_floats(int batch) { return (size_t)batch * NBLK; }
 
-// Host helper: window[400] | cos[400] | sin[400] | slaney filter bank [201][n_mels] (computed in double).
+// Host helper: window[400] | cos[400] | sin[400] | slaney filter bank [201][n_mels] (computed in double) | per mel bin the
+// [first, last + 1) range of DFT bins with a non-zero weight (the triangles cover 2-30 of the 201 bins; the kernel sums only those
+// — the same terms in the same order as the dense product, minus exact zeros).
 extern "C" int desta_logmel_fill_tables(int n_mels, float* host_out) {
     DESTA_CHECK_ARG(host_out && n_mels > 0 && n_mels <= 256, "logmel tables: bad n_mels %d", n_mels);
     const double PI = 3.14159265358979323846;
@@ -153,6 +190,15 @@ extern "C" int desta_logmel_fill_tables(int n_mels, float* host_out) {
             if (v < 0.0) v = 0.0;
             fb[k * n_mels + m] = (float)(v * 2.0 / (ff[m + 2] - ff[m]));
         }
+    }
+    float* rng = fb + N_BINS * n_mels;
+    for (int m = 0; m < n_mels; ++m) {
+        int lo = N_BINS, hi = 0;
+        for (int k = 0; k < N_BINS; ++k)
+            if (fb[k * n_mels + m] != 0.0f) { if (k < lo) lo = k; hi = k + 1; }
+        if (lo > hi) lo = hi = 0;                                       // an empty filter: sum of nothing = 0, as in the dense product
+        rng[2 * m] = (float)lo;
+        rng[2 * m + 1] = (float)hi;
     }
     return DESTA_OK;
 }

@@ -149,7 +149,8 @@ int desta_clip_adafactor_step(const desta_opt_plan* plan, float* params, const f
  * desta/trainer/data/simple_dataset.py:239-243 and modeling_desta25.py:1570
  * (TF:models/whisper/feature_extraction_whisper.py:135-168, TF:audio_utils.py:638-729).
  * `tables` = device copy of the buffer desta_logmel_fill_tables() writes on the host
- * (hann window | cos | sin | slaney filter bank [201][n_mels]); workspace: batch*94 floats. */
+ * (hann window | cos | sin | slaney filter bank [201][n_mels] | non-zero DFT-bin range [n_mels][2] of every filter: an opaque
+ * blob of desta_logmel_table_floats(n_mels) floats); workspace: batch*94 floats. */
 size_t desta_logmel_table_floats(int n_mels);
 size_t desta_logmel_workspace_floats(int batch);
 int desta_logmel_fill_tables(int n_mels, float* host_out);

@@ -40,8 +40,12 @@ def test_host_side_table_helper_runs_without_gpu():
         n = _hip.lib.desta_logmel_table_floats(n_mels)
         host = torch.empty(n, dtype=torch.float32)
         assert _hip._logmel_fill(n_mels, host.data_ptr()) == 0
-        fb = host[1200:].view(201, n_mels).numpy()
+        fb = host[1200:1200 + 201 * n_mels].view(201, n_mels).numpy()
         np.testing.assert_allclose(fb, O.mel_filter_bank(n_mels), rtol=2e-6, atol=1e-9)
+        rng = host[1200 + 201 * n_mels:].view(n_mels, 2).numpy().astype(int)          # [first, last + 1) non-zero DFT bin of every filter
+        for m in range(n_mels):
+            nz = np.nonzero(fb[:, m])[0]
+            assert (rng[m, 0], rng[m, 1]) == (nz[0], nz[-1] + 1) and rng[m, 1] - rng[m, 0] <= 40, m
         np.testing.assert_allclose(host[:400].numpy(), torch.hann_window(400, dtype=torch.float64).numpy(), atol=1e-7)
 
 
