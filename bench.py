@@ -318,6 +318,14 @@ def main():
                 tj = json.load(f)
             traffic = tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"]
         ms_step = 1e3 * elapsed / a.steps
+        # reference point measured on the same hardware with tools/hf_step_bench.py (the step composed from stock PyTorch-ROCm /
+        # transformers modules, as the reference composes it); NOT `vs_baseline` (BASELINE.md publishes no number for this metric)
+        torch_ref = None
+        rpath = os.path.join(ROOT, "profiles", "r02_hf_pytorch_step.json")
+        if a.config == "desta25_llama31-8B_Qformer6L" and world == 1 and os.path.isfile(rpath):
+            with open(rpath) as f:
+                torch_ref = json.load(f)
+            torch_ref["speedup_of_this_run"] = torch_ref["ms_per_step"] / ms_step
         mean_ps = sum(per_step) / max(1, len(per_step))
         sd_ps = (sum((x - mean_ps) ** 2 for x in per_step) / max(1, len(per_step) - 1)) ** 0.5
         # executed FLOP per step: every GEMM launch of the timed region (HIP-event records carry 2MNK) + the attention kernels'
@@ -354,6 +362,7 @@ def main():
                                               "(rows whose logits the loss ignores / whose gradient nothing consumes are not computed; "
                                               "loss and every parameter gradient identical to the full grid, tests/test_gpu_model.py)")},
             "final_loss": final_loss,
+            "pytorch_rocm_reference_point": torch_ref,
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_256_kernel", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
                          "launches_per_step": n_launch / a.steps, "avg_launch_us": 1e3 * gemm_ms / max(n_launch, 1),
