@@ -47,6 +47,8 @@ class TrainingArguments:
     overlap_encoder: bool = False                  # next batch's frozen Whisper forward on its own HIP stream beside the LLM (A/B: -1.2 % step time, see DESIGN)
     save_strategy: str = "no"                      # "epoch" (train_desta.py:146, enable_checkpointing) | "no"
     steps_per_epoch: Optional[int] = None          # len(train dataloader) when the dataset is not sized (synthetic streams)
+    eval_strategy: str = "no"                      # "steps" (every eval_steps optimizer steps) | "epoch" | "no" (train_desta.py:147-148)
+    eval_steps: Optional[int] = None
     seed: int = 42                                 # map-style datasets: the epoch's sample order is randperm(seed + epoch)
     shuffle: bool = True                           # (HF: RandomSampler unless group_by_length); False = manifest order
 
@@ -255,6 +257,8 @@ class DeSTA25Trainer:
                 if self.global_step == before:
                     break                                                     # empty dataset
                 epoch += 1
+                if self.args.eval_strategy == "epoch" and self._can_evaluate():
+                    self.evaluate()
                 if self.args.save_strategy == "epoch" and (spe is None or self.global_step % spe == 0 or self.global_step >= total):
                     self.save_checkpoint(os.path.join(self.args.output_dir, f"checkpoint-{self.global_step}"))
         self.wait_update()
@@ -298,7 +302,13 @@ class DeSTA25Trainer:
             nxt = next(it, None) if more else None
             losses.append(self.training_step(cur, nxt))
             cur = nxt
+            if (self.args.eval_strategy == "steps" and self.args.eval_steps and self.global_step % self.args.eval_steps == 0
+                    and self._can_evaluate()):
+                self.evaluate()                                               # HF `_maybe_log_save_evaluate`: evaluate, then (epoch end) save
         return losses
+
+    def _can_evaluate(self) -> bool:
+        return self.eval_dataset is not None and self.data_collator is not None
 
     # -- evaluation (desta_trainer.py:104-189): eval loss / perplexity + generation through `_generate_step` ----------
     def evaluate(self, eval_batches: Optional[Iterable[Dict[str, Any]]] = None, metric_key_prefix: str = "eval",

@@ -127,6 +127,9 @@ def create_training_args(cfg: Cfg):
         warmup_steps=cfg.optim.sched.warmup_steps, logging_steps=cfg.trainer.log_every_n_steps,
         max_steps=cfg.trainer.get("max_steps", -1), bf16="bf16" in cfg.trainer.precision, optim="adafactor",
         save_strategy="epoch" if cfg.trainer.get("enable_checkpointing", False) else "no",
+        eval_strategy="steps" if isinstance(cfg.trainer.get("val_check_interval"), int) else "epoch",      # reference :147-148
+        eval_steps=cfg.trainer.get("val_check_interval") if isinstance(cfg.trainer.get("val_check_interval"), int) else None,
+        per_device_eval_batch_size=cfg.dataset.validation_ds.batch_size,
         overlap_comm=bool(cfg.trainer.get("overlap_comm", True)),
         # synthetic streams have no len(): every rank draws num_samples // batch_size batches per epoch
         steps_per_epoch=(cfg.dataset.train_ds.num_samples // cfg.dataset.train_ds.batch_size
@@ -208,7 +211,12 @@ def main(argv=None):
     if rank == 0:
         with open(os.path.join(cfg.exp_dir, "config.yaml"), "w") as f:
             yaml.safe_dump(dict(cfg), f)
-        if not cfg.get("resume_from_checkpoint"):
+    if not cfg.get("resume_from_checkpoint"):
+        # reference :220-228 — "eval before train to catch logic errors early", then checkpoint-initial
+        if eval_ds is not None:
+            logging.info("Running initial evaluation to verify model and trainer logic...")
+            trainer.evaluate()
+        if rank == 0:
             trainer.save_model(os.path.join(cfg.exp_dir, "checkpoint-initial"))
     # reference :231 — trainer.train(resume_from_checkpoint=...): parameters, optimizer.pt, scheduler.pt, step
     losses = trainer.train(resume_from_checkpoint=cfg.get("resume_from_checkpoint") or None)

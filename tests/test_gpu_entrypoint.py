@@ -90,7 +90,8 @@ def test_manifest_dataset_through_main(tmp_path, monkeypatch):
     tr = m.main(["--config-name", "desta25_debug", "+dataset=debug", f"exp_dir={tmp_path}/exp", "trainer.max_epochs=2", "trainer.max_steps=-1",
                  "optim.sched.warmup_steps=0", "optim.lr=1e-3", "dataset.train_ds.synthetic=false", f"dataset.train_ds.data_root={audio}",
                  f"dataset.train_ds.manifest_filepaths=[{man}]", "dataset.validation_ds.synthetic=false",
-                 f"dataset.validation_ds.manifest_filepaths=[{man}]", f"dataset.validation_ds.data_root={audio}"])
+                 f"dataset.validation_ds.manifest_filepaths=[{man}]", f"dataset.validation_ds.data_root={audio}",
+                 "model.generation_kwargs.max_new_tokens=3"])
     assert len(tr.train_dataset) == 5                                          # the empty-prompt record is filtered
     assert tr.steps_per_epoch() == 3 and tr.total_steps == 6 and tr.global_step == 6          # ceil(5 / 2) steps x 2 epochs
     assert os.path.isdir(tmp_path / "exp" / "checkpoint-3") and os.path.isdir(tmp_path / "exp" / "checkpoint-6")
@@ -98,12 +99,17 @@ def test_manifest_dataset_through_main(tmp_path, monkeypatch):
     losses = [h["train/loss"] if "train/loss" in h else h.get("loss") for h in tr.log_history if ("train/loss" in h or "loss" in h)]
     assert all(l is None or (l == l and l > 0) for l in losses)
     # the reference's validation loop (desta_trainer.py:104-158): loss / ppl, generation, predictions JSONL + accuracy report
+    val = tmp_path / "exp" / "results" / "val"
+    # the entry point evaluated BEFORE training (reference :220-224) and, with `val_check_interval: 1.0` (a float -> eval_strategy
+    # "epoch", :147), at both epoch ends: three prediction files, the first at step 0
+    assert sorted(os.listdir(val / "preds")) == ["val@ep=0.0-0.jsonl", "val@ep=1.0-3.jsonl", "val@ep=2.0-6.jsonl"]
+    evals = [h for h in tr.log_history if "eval_loss" in h]
+    assert len(evals) == 3 and all(h["eval_loss"] > 0 for h in evals)
     ev = tr.evaluate(generation_kwargs={"max_new_tokens": 3})
     assert {"eval_loss", "eval_ppl", "eval_accuracy", "eval_accuracy_by_category", "eval_acc/all"} <= set(ev) and ev["eval_loss"] > 0
     assert len(tr.prediction_step_outputs) == 5 and 0.0 <= ev["eval_accuracy"] <= 1.0
-    val = tmp_path / "exp" / "results" / "val"
-    assert len(os.listdir(val / "preds")) == 1 and any(f.endswith("-report.json") for f in os.listdir(val))
-    rows = [json.loads(l) for l in open(val / "preds" / os.listdir(val / "preds")[0])]
+    assert len(os.listdir(val / "preds")) == 4 and any(f.endswith("-report.json") for f in os.listdir(val))     # same step again: a new file, nothing overwritten
+    rows = [json.loads(l) for l in open(val / "preds" / "val@ep=2.0-6-1.jsonl")]
     assert len(rows) == 5 and all({"prediction", "label", "context", "correct", "index"} <= set(r) for r in rows)
     # epoch order: a permutation from seed + epoch, every sample once per epoch
     seen = []
