@@ -99,8 +99,9 @@ class DeSTA25Trainer:
         self.metrics = ConsecutiveWordsAccuracyMetric()                       # desta_trainer.py:36
         if self.args.optim != "adafactor":
             raise NotImplementedError("only optim='adafactor' (train_desta.py:149) is implemented")
-        if self.args.gradient_accumulation_steps != 1:
-            raise NotImplementedError("gradient_accumulation_steps != 1 (every shipped config uses 1)")
+        if self.args.gradient_accumulation_steps < 1:
+            raise ValueError("gradient_accumulation_steps must be >= 1")
+        self._micro, self._acc = 0, None                                      # micro-batches seen in the current accumulation window / their gradient sum
         self.optimizer = FusedAdafactor(model.arena, weight_decay=self.args.weight_decay, max_grad_norm=self.args.max_grad_norm)
         self.global_step = 0
         self._total_steps: Optional[int] = None
@@ -180,6 +181,8 @@ class DeSTA25Trainer:
         Whisper encoder of `next_inputs`."""
         model = self.model
         model.train()
+        if self.args.gradient_accumulation_steps > 1:
+            return self._accumulating_step(inputs, next_inputs)
         empty = self._is_empty_batch(inputs)
         if empty and self.world == 1:
             # HF loop on one device: zero loss, backward leaves every .grad None, Adafactor skips every parameter
@@ -229,6 +232,36 @@ class DeSTA25Trainer:
                 model.prefetch_encoder(next_inputs["batch_features"])
         return loss
 
+    def _accumulating_step(self, inputs: Dict[str, Any], next_inputs: Optional[Dict[str, Any]] = None) -> torch.Tensor:
+        """`trainer.accumulate_grad_batches` > 1 (HF `gradient_accumulation_steps`, TF:trainer.py training loop): every call is one
+        MICRO-batch; its gradient arena is summed into a second arena and the optimizer runs on the mean at every GA-th call
+        (HF scales each micro-loss by 1 / GA; summing and scaling once is the same number for a power-of-two GA).  `global_step`
+        counts optimizer steps.  An empty micro-batch contributes nothing.  No stream overlap on this path."""
+        model, ga = self.model, self.args.gradient_accumulation_steps
+        self.wait_update()
+        loss = self.compute_loss(model, inputs)
+        if self._acc is None:
+            self._acc = torch.zeros_like(model.arena.grads)
+        if not self._is_empty_batch(inputs):
+            model.backward()
+            if self._micro == 0:
+                self._acc.copy_(model.arena.grads)
+            else:
+                from .. import _hip as H
+                H.add_f32(self._acc, model.arena.grads)
+        elif self._micro == 0:
+            self._acc.zero_()
+        self._micro += 1
+        if self._micro < ga:
+            return loss
+        self._micro = 0
+        model.arena.grads.copy_(self._acc).mul_(1.0 / ga)
+        self.global_step += 1
+        lr = linear_warmup_lr(self.global_step - 1, self.args.learning_rate, self.args.warmup_steps, self.total_steps)
+        self._reduce_and_update(lr)
+        model._weights_dirty = False
+        return loss
+
     def train(self, batches: Optional[Iterable[Dict[str, Any]]] = None, max_steps: Optional[int] = None,
               resume_from_checkpoint: Optional[str] = None):
         """`batches` given: ONE pass over that iterable of collated batches (tests, benchmarks).  Otherwise the HF loop shape
@@ -248,7 +281,7 @@ class DeSTA25Trainer:
             epoch, skip = (self.global_step // spe, self.global_step % spe) if spe else (0, 0)
             while self.global_step < total:
                 it = iter(self._epoch_batches(epoch))
-                for _ in range(skip):
+                for _ in range(skip * self.args.gradient_accumulation_steps):        # micro-batches already consumed in this epoch
                     if next(it, None) is None:
                         break
                 skip = 0

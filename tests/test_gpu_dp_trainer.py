@@ -134,5 +134,40 @@ def test_rccl_branch_at_world_size_one_is_the_identity(tmp_path):
     assert torch.equal(model.arena.params.cpu(), r0["params"]) and torch.equal(tr.optimizer.state.cpu(), r0["state"])
 
 
+@pytest.mark.gpu
+def test_gradient_accumulation_equals_the_mean_of_micro_batch_gradients():
+    """`trainer.accumulate_grad_batches: 2` (HF gradient_accumulation_steps): two micro-batches per optimizer step, the update is
+    made from the MEAN of their gradient arenas — bit for bit what one gets by averaging the two arenas by hand; `global_step`
+    counts optimizer steps; an empty micro-batch contributes nothing."""
+    _setup_paths()
+    from desta.optim import FusedAdafactor, linear_warmup_lr
+    from desta.trainer.desta_trainer import DeSTA25Trainer, TrainingArguments
+    d, model = _model()
+    data = [b for b in _batches(d, 0)] + [{"_empty_batch": True}, _batches(d, 1)[0]]          # 4 real micro-batches + (empty, real)
+    tr = DeSTA25Trainer(model, args=TrainingArguments(learning_rate=LR, warmup_steps=WARM, max_steps=TOTAL, logging_steps=1,
+                                                      gradient_accumulation_steps=2, overlap_comm=False))
+    losses = tr.train(data)
+    assert len(losses) == 6 and tr.global_step == 3 and tr.optimizer.step_count == 3 and losses[4] == 0.0
+    got_p, got_s = model.arena.params.clone(), tr.optimizer.state.clone()
+
+    d, ref = _model()
+    opt = FusedAdafactor(ref.arena, weight_decay=0.01, max_grad_norm=1.0)
+    ref.train()
+    ref.dropout_seed = 1                                                       # what the trainer sets on rank 0
+    for stp in range(3):
+        acc = torch.zeros_like(ref.arena.grads)
+        for b in data[2 * stp:2 * stp + 2]:
+            if b.get("_empty_batch"):
+                continue
+            ref(**b)
+            ref.backward()
+            acc += ref.arena.grads
+        ref.arena.grads.copy_(acc * 0.5)
+        opt.step(linear_warmup_lr(stp, LR, WARM, TOTAL))
+        ref.connector.refresh_weights()
+    torch.cuda.synchronize()
+    assert torch.equal(got_p, ref.arena.params) and torch.equal(got_s, opt.state)
+
+
 if __name__ == "__main__" and len(sys.argv) >= 3 and sys.argv[1] == "--worker":
     worker(sys.argv[2])
