@@ -489,3 +489,54 @@ def test_prefetch_hit_needs_the_same_tensor_object_and_training_empty_batch():
     tr.training_step(b2)
     tr.wait_update()
     assert tr.global_step == 2 and tr.optimizer.step_count == 1 and not torch.equal(before, model.arena.params)
+
+
+@pytest.mark.parametrize("flavour", ["llama", "qwen3"])
+def test_local_hf_checkpoint_directories_load_like_transformers_wrote_them(tmp_path, flavour):
+    """The deployment path: `llm_model_id` / `encoder_model_id` are LOCAL Hugging Face directories (config.json + *.safetensors as
+    `save_pretrained` of transformers 5.15 writes them: `rope_parameters`, `model.encoder.*` keys inside a
+    WhisperForConditionalGeneration file, bf16 LLM tensors).  `DeSTA25Config` reads the two config.json files, `_load_base_weights`
+    the tensors; the result equals the oracle fed with the SAME tensors under the reference's key names."""
+    from transformers import LlamaConfig, LlamaForCausalLM, Qwen3Config, Qwen3ForCausalLM, WhisperConfig, WhisperForConditionalGeneration
+    from desta.models.modeling_desta25 import CON, DeSTA25AudioModel, DeSTA25Config
+    qwen = flavour == "qwen3"
+    d = O.tiny_dims(qwen)
+    torch.manual_seed(3)
+    if qwen:
+        lcfg = Qwen3Config(hidden_size=d.llm_h, num_hidden_layers=d.llm_layers, num_attention_heads=d.llm_hq, num_key_value_heads=d.llm_hkv,
+                           head_dim=d.llm_hd, intermediate_size=d.llm_inter, vocab_size=d.vocab, rms_norm_eps=d.rms_eps, rope_theta=d.rope_theta,
+                           tie_word_embeddings=False, max_position_embeddings=4096)
+        llm = Qwen3ForCausalLM(lcfg)
+    else:
+        f, lo, hi, orig = d.rope_llama3
+        lcfg = LlamaConfig(hidden_size=d.llm_h, num_hidden_layers=d.llm_layers, num_attention_heads=d.llm_hq, num_key_value_heads=d.llm_hkv,
+                           head_dim=d.llm_hd, intermediate_size=d.llm_inter, vocab_size=d.vocab, rms_norm_eps=d.rms_eps, rope_theta=d.rope_theta,
+                           rope_scaling={"rope_type": "llama3", "factor": f, "low_freq_factor": lo, "high_freq_factor": hi,
+                                         "original_max_position_embeddings": orig}, tie_word_embeddings=False, max_position_embeddings=4096)
+        llm = LlamaForCausalLM(lcfg)
+    llm.to(torch.bfloat16).save_pretrained(tmp_path / "llm", safe_serialization=True)
+    wcfg = WhisperConfig(num_mel_bins=d.n_mels, d_model=d.enc_d, encoder_layers=d.enc_layers, encoder_attention_heads=d.enc_heads,
+                         encoder_ffn_dim=d.enc_ffn, max_source_positions=d.enc_T, decoder_layers=1, decoder_attention_heads=2, decoder_ffn_dim=64,
+                         vocab_size=64, max_target_positions=8, pad_token_id=0, bos_token_id=1, eos_token_id=2, decoder_start_token_id=1)
+    WhisperForConditionalGeneration(wcfg).save_pretrained(tmp_path / "enc", safe_serialization=True)
+
+    cfg = DeSTA25Config(llm_model_id=str(tmp_path / "llm"), encoder_model_id=str(tmp_path / "enc"), qformer_num_hidden_layers=d.qf_layers,
+                        prompt_size=d.prompt_size, qformer_intermediate_size=d.qf_inter, qformer_dropout=0.0)
+    lc, ec = cfg.llm_config, cfg.encoder_config
+    assert (lc.model_type, lc.hidden_size, lc.num_hidden_layers, lc.num_key_value_heads, lc.head_dim) == (flavour, d.llm_h, d.llm_layers, d.llm_hkv, d.llm_hd)
+    assert abs(lc.rope_theta - d.rope_theta) < 1e-3 and bool(lc.rope_scaling) == (not qwen) and lc.qk_norm == qwen
+    assert (ec.d_model, ec.encoder_layers, ec.max_source_positions, ec.num_mel_bins) == (d.enc_d, d.enc_layers, d.enc_T, d.n_mels)
+    assert cfg.target_layer_ids == [0, 1, 2, 3]
+    model = DeSTA25AudioModel(cfg)                                              # weights=None: read from the two directories
+    w = DeSTA25AudioModel._load_base_weights(cfg)
+    assert any(k.startswith("perception.whisper.model.encoder.layers.0.") for k in w) and not any(".decoder." in k for k in w)
+    w = {k: v.float() for k, v in w.items()}
+    w.update({k: v.float().cpu() for k, v in model.state_dict().items()})
+    assert all(k.startswith(CON) for k in model.state_dict())
+    batch = O.synthetic_batch(d, B=2, S_ctx=5, S_tgt=20, seed=11)
+    loss_o, logits_o = O.model_forward(w, d, batch)
+    model.eval()
+    out = model(**batch)
+    m = batch["attention_mask"].bool()
+    assert abs(float(out.loss) - float(loss_o)) < 2e-2, (float(out.loss), float(loss_o))
+    assert rel_err(out.logits.float().cpu()[m], logits_o[m]) < 3e-2
