@@ -251,9 +251,16 @@ def main():
         return b
 
     step_events = []
+    carried = {}                                         # {index: batch} prefetched by the previous run()'s last step
 
     def run(nsteps, start, mark=False):
-        cur = batch(start)
+        # one continuous training loop cut into warm-up / timed / kernel-pass segments: the batch (and its frozen-encoder
+        # prefetch) that the last step of a segment prepared is the first batch of the next one, so a segment of K steps holds
+        # exactly K log-mel + Whisper forwards (for batch t+1 inside step t), as K steady-state steps of a real run do
+        cur = carried.pop(start, None)
+        carried.clear()
+        if cur is None:
+            cur = batch(start)
         loss = None
         if mark:
             step_events.append(torch.cuda.Event(enable_timing=True))
@@ -265,6 +272,7 @@ def main():
             if mark:                                     # main-stream step boundary (no sync): per-step spread for mean +- sd
                 step_events.append(torch.cuda.Event(enable_timing=True))
                 step_events[-1].record()
+        carried[start + nsteps] = cur
         trainer.wait_update()
         return loss
 
@@ -346,6 +354,7 @@ def main():
             "value": world * a.steps / elapsed, "unit": "steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
             "ms_per_step_mean_sd": [mean_ps, sd_ps], "ms_per_step_min_max": [min(per_step), max(per_step)] if per_step else None,
+            "ms_per_step_each": [round(x, 2) for x in per_step],        # main-stream event deltas, in order
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{a.config}: {os.path.basename(cfg.encoder_model_id)} + {os.path.basename(cfg.llm_model_id)}, "
                                    f"Q-Former {cfg.qformer_num_hidden_layers}L, per-GPU batch {B} x 30 s clips, "
