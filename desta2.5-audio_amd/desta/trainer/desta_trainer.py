@@ -46,7 +46,7 @@ class TrainingArguments:
     overlap_connector_backward: bool = False       # with overlap_comm: the connector's backward ALSO runs on the side stream beside the next batch's Whisper forward (A/B: -0.4 ms per step, and it inflates the per-kernel durations of both streams: off)
     overlap_encoder: bool = False                  # next batch's frozen Whisper forward on its own HIP stream beside the LLM (A/B: -1.2 % step time, see DESIGN)
     save_strategy: str = "no"                      # "epoch" (train_desta.py:146, enable_checkpointing) | "no"
-    steps_per_epoch: Optional[int] = None          # len(train dataloader) when the dataset is not sized (synthetic streams)
+    steps_per_epoch: Optional[int] = None          # len(train dataloader) = MICRO-batches per epoch when the dataset is not sized (synthetic streams)
     eval_strategy: str = "no"                      # "steps" (every eval_steps optimizer steps) | "epoch" | "no" (train_desta.py:147-148)
     eval_steps: Optional[int] = None
     seed: int = 42                                 # map-style datasets: the epoch's sample order is randperm(seed + epoch)
@@ -67,15 +67,25 @@ def allreduce_mean_(flat: torch.Tensor) -> None:
         flat.mul_(1.0 / dist.get_world_size())
 
 
-def steps_per_epoch(args: TrainingArguments, n_samples: Optional[int], world: int) -> Optional[int]:
-    """Optimizer steps per epoch as HF derives them (TF:trainer.py `set_initial_training_values`): len(dataloader) // GA with
-    len(dataloader) = ceil(ceil(N / world) / per_device_batch) (DistributedSampler pads every rank to an equal share)."""
+def micro_batches_per_epoch(args: TrainingArguments, n_samples: Optional[int], world: int) -> Optional[int]:
+    """len(train dataloader) of one rank: `args.steps_per_epoch` for unsized (synthetic) streams, else
+    ceil(ceil(N / world) / per_device_batch) (DistributedSampler pads every rank to an equal share)."""
     if args.steps_per_epoch is not None:
         return max(1, int(args.steps_per_epoch))
     if n_samples is None:
         return None
-    per_rank = math.ceil(n_samples / world)
-    return max(1, math.ceil(per_rank / args.per_device_train_batch_size) // args.gradient_accumulation_steps)
+    return max(1, math.ceil(math.ceil(n_samples / world) / args.per_device_train_batch_size))
+
+
+def steps_per_epoch(args: TrainingArguments, n_samples: Optional[int], world: int) -> Optional[int]:
+    """OPTIMIZER steps per epoch as HF derives them (TF:trainer.py:2356-2360 `set_initial_training_values`):
+    len(dataloader) // GA + (1 if len(dataloader) % GA else 0) — the last window of an epoch may hold fewer micro-batches
+    (TF:trainer.py:1715-1725 `remainder`); windows never straddle an epoch boundary."""
+    mb = micro_batches_per_epoch(args, n_samples, world)
+    if mb is None:
+        return None
+    ga = max(1, args.gradient_accumulation_steps)
+    return max(1, mb // ga + (1 if mb % ga else 0))
 
 
 def resolve_total_steps(args: TrainingArguments, spe: Optional[int]) -> int:
@@ -175,14 +185,15 @@ class DeSTA25Trainer:
             torch.cuda.current_stream(self.model.device).wait_event(self._side_done)
             self._side_done = None
 
-    def training_step(self, inputs: Dict[str, Any], next_inputs: Optional[Dict[str, Any]] = None) -> torch.Tensor:
+    def training_step(self, inputs: Dict[str, Any], next_inputs: Optional[Dict[str, Any]] = None,
+                      close_window: bool = False) -> torch.Tensor:
         """forward -> backward -> (all-reduce mean) -> clip -> Adafactor -> schedule.  With
         `overlap_comm` the tail runs on a side stream while the main stream already runs the frozen
         Whisper encoder of `next_inputs`."""
         model = self.model
         model.train()
         if self.args.gradient_accumulation_steps > 1:
-            return self._accumulating_step(inputs, next_inputs)
+            return self._accumulating_step(inputs, next_inputs, close_window)
         empty = self._is_empty_batch(inputs)
         if empty and self.world == 1:
             # HF loop on one device: zero loss, backward leaves every .grad None, Adafactor skips every parameter
@@ -193,6 +204,10 @@ class DeSTA25Trainer:
         if prefetch and self._enc_stream is not None and not empty:
             # the frozen encoder of batch t+1 starts NOW on its own stream and runs beside this step's LLM forward / backward
             # (it reads nothing the optimizer writes)
+            if self._side_done is not None and self.args.overlap_connector_backward:
+                # the connector backward of step t-1 may still be reading the tapped-state buffer this prefetch is about to
+                # overwrite (it runs on the side stream, which the encoder stream is otherwise not ordered behind)
+                self._enc_stream.wait_event(self._side_done)
             model.prefetch_encoder(next_inputs["batch_features"], stream=self._enc_stream)
             prefetch = False
         self.wait_update()                                                    # connector weights of step t-1 are final
@@ -232,11 +247,16 @@ class DeSTA25Trainer:
                 model.prefetch_encoder(next_inputs["batch_features"])
         return loss
 
-    def _accumulating_step(self, inputs: Dict[str, Any], next_inputs: Optional[Dict[str, Any]] = None) -> torch.Tensor:
-        """`trainer.accumulate_grad_batches` > 1 (HF `gradient_accumulation_steps`, TF:trainer.py training loop): every call is one
-        MICRO-batch; its gradient arena is summed into a second arena and the optimizer runs on the mean at every GA-th call
-        (HF scales each micro-loss by 1 / GA; summing and scaling once is the same number for a power-of-two GA).  `global_step`
-        counts optimizer steps.  An empty micro-batch contributes nothing.  No stream overlap on this path."""
+    def _accumulating_step(self, inputs: Dict[str, Any], next_inputs: Optional[Dict[str, Any]] = None,
+                           close_window: bool = False) -> torch.Tensor:
+        """`trainer.accumulate_grad_batches` > 1 (HF `gradient_accumulation_steps`, TF:trainer.py:1715-1813): every call is one
+        MICRO-batch; its gradient arena is added into a second arena and the optimizer runs at every GA-th call — or earlier
+        when `close_window` says the epoch's data ends here (HF's `remainder` window, TF:trainer.py:1715-1725, and
+        `do_sync_step`, :1742).  The micro-batch gradients are SUMMED, not averaged: the reference's `forward(**kwargs)` makes
+        `model_accepts_loss_kwargs` true (TF:trainer.py:500-505), so HF counts `num_items_in_batch`, hands it to
+        `compute_loss` — which swallows it in **kwargs (desta_trainer.py:48) — and therefore does NOT divide the loss by the
+        window length (TF:trainer.py:1952-1954; SURVEY hazard H8).  `global_step` counts optimizer steps.  An empty
+        micro-batch contributes nothing.  No stream overlap on this path."""
         model, ga = self.model, self.args.gradient_accumulation_steps
         self.wait_update()
         loss = self.compute_loss(model, inputs)
@@ -252,10 +272,10 @@ class DeSTA25Trainer:
         elif self._micro == 0:
             self._acc.zero_()
         self._micro += 1
-        if self._micro < ga:
+        if self._micro < ga and not close_window:
             return loss
         self._micro = 0
-        model.arena.grads.copy_(self._acc).mul_(1.0 / ga)
+        model.arena.grads.copy_(self._acc)
         self.global_step += 1
         lr = linear_warmup_lr(self.global_step - 1, self.args.learning_rate, self.args.warmup_steps, self.total_steps)
         self._reduce_and_update(lr)
@@ -295,10 +315,13 @@ class DeSTA25Trainer:
                 if self.args.save_strategy == "epoch" and (spe is None or self.global_step % spe == 0 or self.global_step >= total):
                     self.save_checkpoint(os.path.join(self.args.output_dir, f"checkpoint-{self.global_step}"))
         self.wait_update()
-        torch.cuda.synchronize(self.model.device)
+        self._sync()
         self.model.drop_prefetched()                                          # a prefetch for a batch that never ran is void
         self._flush_logs()
         return [float(x) for x in losses]
+
+    def _sync(self) -> None:
+        torch.cuda.synchronize(self.model.device)
 
     def _epoch_batches(self, epoch: int):
         ds = self.train_dataset
@@ -328,15 +351,24 @@ class DeSTA25Trainer:
         return (self.data_collator([ds[i] for i in idx[s:s + bs]]) for s in range(0, len(idx), bs))
 
     def _train_pass(self, it, max_steps: Optional[int]) -> List[torch.Tensor]:
-        cur = next(it, None) if (max_steps is None or self.global_step < max_steps) else None
-        losses = []
+        """One pass over an iterator of MICRO-batches (one epoch, or the caller's iterable).  Look-ahead and triggers follow
+        the micro-batch position inside the accumulation window, not `global_step` alone: the batch after the current one is
+        drawn unless the current one closes the window that reaches `max_steps`; a window is closed early only where the data
+        ends (HF's shorter last window of an epoch); the step-driven evaluation fires once, right after an optimizer step."""
+        ga = self.args.gradient_accumulation_steps
+        losses: List[torch.Tensor] = []
+        if max_steps is not None and self.global_step >= max_steps:
+            return losses
+        cur = next(it, None)
         while cur is not None:
-            more = max_steps is None or self.global_step + 1 < max_steps
-            nxt = next(it, None) if more else None
-            losses.append(self.training_step(cur, nxt))
+            closes = self._micro == ga - 1                                    # this micro-batch completes its window
+            final = max_steps is not None and closes and self.global_step + 1 >= max_steps
+            nxt = None if final else next(it, None)
+            before = self.global_step
+            losses.append(self.training_step(cur, nxt, close_window=nxt is None))
             cur = nxt
-            if (self.args.eval_strategy == "steps" and self.args.eval_steps and self.global_step % self.args.eval_steps == 0
-                    and self._can_evaluate()):
+            if (self.global_step != before and self.args.eval_strategy == "steps" and self.args.eval_steps
+                    and self.global_step % self.args.eval_steps == 0 and self._can_evaluate()):
                 self.evaluate()                                               # HF `_maybe_log_save_evaluate`: evaluate, then (epoch end) save
         return losses
 
@@ -349,12 +381,18 @@ class DeSTA25Trainer:
         """Eval-mode forward (no Q-Former dropout) for loss / ppl on every batch, then `_predict_step`.  Metrics keep the
         reference's names (`eval_loss`, `eval_ppl`); accuracy scoring needs the reference's text metrics and a tokenizer
         (`processing_class`) and is reported only when predictions could be decoded (`prediction_step_outputs`)."""
+        dp = self.world > 1 and dist.is_available() and dist.is_initialized()
+        sharded = False
         if eval_batches is None:
             if self.eval_dataset is None or self.data_collator is None:
                 raise ValueError("evaluate() needs `eval_batches` or eval_dataset + data_collator")
             bs = self.args.per_device_eval_batch_size
             n = len(self.eval_dataset)
-            eval_batches = (self.data_collator([self.eval_dataset[i] for i in range(s, min(s + bs, n))]) for s in range(0, n, bs))
+            # data parallel: rank r evaluates the batches r, r + world, ... of the unsharded batch list; losses and predictions
+            # are combined below and only rank 0 writes the result files (HF shards the eval dataloader the same way and gathers)
+            starts = list(range(0, n, bs))[self.rank::self.world] if dp else list(range(0, n, bs))
+            sharded = dp
+            eval_batches = (self.data_collator([self.eval_dataset[i] for i in range(s, min(s + bs, n))]) for s in starts)
         self.wait_update()
         was_training = self.model.training
         self.model.eval()
@@ -372,20 +410,39 @@ class DeSTA25Trainer:
                     self._predict_step(batch, generation_kwargs)
         finally:
             self.model.train(was_training)
-        ls = torch.stack(losses).double() if losses else torch.zeros(1, dtype=torch.float64, device=self.model.device)
-        metrics = {f"{metric_key_prefix}_loss": float(ls.mean()) if losses else 0.0,
-                   f"{metric_key_prefix}_ppl": float(torch.exp(ls).mean()) if losses else 0.0}
+        ls = torch.stack(losses).double() if losses else torch.zeros(0, dtype=torch.float64, device=self.model.device)
+        agg = torch.stack([ls.sum(), torch.exp(ls).sum(), torch.tensor(float(len(losses)), dtype=torch.float64, device=self.model.device)])
+        preds = self.prediction_step_outputs
+        if sharded:
+            if dist.get_backend() != "nccl":
+                agg = agg.cpu()
+            dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+            gathered: List[Any] = [None] * self.world
+            dist.all_gather_object(gathered, preds)
+            nb = max(len(g) for g in gathered)
+            preds = [g[i] for i in range(nb) for g in gathered if i < len(g)]    # back to the unsharded batch order (per-batch rows stay together only for bs == 1; order is informational)
+            self.prediction_step_outputs = preds
+        cnt = float(agg[2])
+        metrics = {f"{metric_key_prefix}_loss": float(agg[0]) / cnt if cnt else 0.0,
+                   f"{metric_key_prefix}_ppl": float(agg[1]) / cnt if cnt else 0.0}
         # desta_trainer.py:134-152: predictions JSONL + accuracy report under <exp_dir>/results/val, accuracy metrics
         exp_dir = self._cfg_get("exp_dir")
-        decoded = bool(self.prediction_step_outputs) and all("prediction" in r and "label" in r for r in self.prediction_step_outputs)
-        if exp_dir and (decoded or not self.prediction_step_outputs):
-            spe = self.steps_per_epoch()
-            epoch = (self.global_step / spe) if spe else 0.0
-            ckpt = f"ep={epoch}-{self.global_step}"
-            report = self._save_results(self.prediction_step_outputs, os.path.join(exp_dir, "results", "val", f"val@{ckpt}.jsonl"), ckpt)
-            metrics[f"{metric_key_prefix}_accuracy"] = report.get("accuracy_by_sample", 0)
-            metrics[f"{metric_key_prefix}_accuracy_by_category"] = report.get("avg_accuracy_by_category", 0)
-            for category, acc in report.get("categories_accuracy", {}).items():
+        decoded = bool(preds) and all("prediction" in r and "label" in r for r in preds)
+        if exp_dir and (decoded or not preds):
+            report: Dict[str, Any] = {}
+            if self.rank == 0 or not sharded:
+                spe = self.steps_per_epoch()
+                epoch = (self.global_step / spe) if spe else 0.0
+                ckpt = f"ep={epoch}-{self.global_step}"
+                report = self._save_results(preds, os.path.join(exp_dir, "results", "val", f"val@{ckpt}.jsonl"), ckpt)
+                report = {k: report.get(k) for k in ("accuracy_by_sample", "avg_accuracy_by_category", "categories_accuracy")}
+            if sharded:
+                box = [report]
+                dist.broadcast_object_list(box, src=0)
+                report = box[0]
+            metrics[f"{metric_key_prefix}_accuracy"] = report.get("accuracy_by_sample") or 0
+            metrics[f"{metric_key_prefix}_accuracy_by_category"] = report.get("avg_accuracy_by_category") or 0
+            for category, acc in (report.get("categories_accuracy") or {}).items():
                 metrics[f"{metric_key_prefix}_acc/{category}"] = acc
         self.log_history.append(dict(metrics))
         return metrics
@@ -408,12 +465,15 @@ class DeSTA25Trainer:
         d, name = os.path.join(os.path.dirname(filepath), "preds"), os.path.basename(filepath)
         os.makedirs(d, exist_ok=True)
         stem, ext = os.path.splitext(name)
-        jsonl_path, k = os.path.join(d, name), 0
-        while os.path.exists(jsonl_path):
-            k += 1
-            jsonl_path = os.path.join(d, f"{stem}-{k}{ext}")
+        jsonl_path, k, f = os.path.join(d, name), 0, None
+        while f is None:
+            try:
+                f = open(jsonl_path, "x")                                    # O_EXCL: two writers can never share a file
+            except FileExistsError:
+                k += 1
+                jsonl_path = os.path.join(d, f"{stem}-{k}{ext}")
         by_cat = defaultdict(list)
-        with open(jsonl_path, "w") as f:
+        with f:
             for i, r in enumerate(results):
                 r["correct"] = bool(metric(r["prediction"], r["label"]))
                 r["index"] = i
@@ -475,16 +535,47 @@ class DeSTA25Trainer:
                 self.prediction_step_outputs.append({**m, "prediction_ids": row})
         return ids
 
-    # -- HF `checkpoint-<step>/` layout (TF:trainer.py:3079-3130): model.safetensors (trainable-only), config.json,
-    #    optimizer.pt (Adafactor state_dict wire format), scheduler.pt (LambdaLR state), trainer_state.json
+    # -- HF `checkpoint-<step>/` layout (TF:trainer.py `_save_checkpoint` / `_save_optimizer_and_scheduler` / `_save_rng_state`):
+    #    model.safetensors (trainable-only) + config.json, optimizer.pt (Adafactor state_dict wire format), scheduler.pt (LambdaLR
+    #    state), trainer_state.json (TrainerState fields ONLY: `TrainerState.load_from_json` does cls(**json)), rng_state.pth
+    #    (rng_state_<rank>.pth under data parallel), training_args.bin; this library's own resume data (forward counter and seed
+    #    of the stateless dropout stream) lives in the sidecar desta_hip_state.json, which HF never opens.
+    def _trainer_state(self) -> Dict[str, Any]:
+        spe = self.steps_per_epoch()
+        total = self._total_steps if self._total_steps is not None else (self.args.max_steps if self.args.max_steps > 0 else 0)
+        return {
+            "epoch": (self.global_step / spe) if spe else 0.0,
+            "global_step": int(self.global_step),
+            "max_steps": int(total),
+            "logging_steps": int(self.args.logging_steps),
+            "eval_steps": int(self.args.eval_steps) if self.args.eval_steps else 500,
+            "save_steps": 500,
+            "train_batch_size": int(self.args.per_device_train_batch_size),
+            "num_train_epochs": int(math.ceil(self.args.num_train_epochs)),
+            "num_input_tokens_seen": 0,
+            "total_flos": 0.0,
+            "log_history": self.log_history,
+            "best_metric": None, "best_global_step": None, "best_model_checkpoint": None,
+            "is_local_process_zero": True, "is_world_process_zero": True, "is_hyper_param_search": False,
+            "trial_name": None, "trial_params": None, "stateful_callbacks": {},
+        }
+
     def save_checkpoint(self, output_dir: str) -> None:
-        import json
+        import random
+        from dataclasses import asdict
+        import numpy as np
         from ..models.modeling_desta25 import reference_parameter_names
         self.wait_update()
-        torch.cuda.synchronize(self.model.device)
+        self._sync()
+        os.makedirs(output_dir, exist_ok=True)
+        # every rank: its own generator states (HF `_save_rng_state`; the sample order itself is a pure function of seed + epoch)
+        rng = {"python": random.getstate(), "numpy": np.random.get_state(), "cpu": torch.random.get_rng_state(),
+               "cuda": torch.cuda.get_rng_state(self.model.device) if torch.cuda.is_available() else None}
+        if rng["cuda"] is None:
+            del rng["cuda"]
+        torch.save(rng, os.path.join(output_dir, "rng_state.pth" if self.world <= 1 else f"rng_state_{self.rank}.pth"))
         if self.rank != 0:
             return
-        os.makedirs(output_dir, exist_ok=True)
         self.model.save_pretrained(output_dir)
         lr = self.get_last_lr()
         torch.save(self.optimizer.hf_state_dict(reference_parameter_names(self.model.config), lr, self.args.weight_decay),
@@ -492,14 +583,17 @@ class DeSTA25Trainer:
         torch.save({"base_lrs": [self.args.learning_rate] * 2, "last_epoch": self.global_step, "_step_count": self.global_step + 1,
                     "_get_lr_called_within_step": False, "_last_lr": [lr, lr], "lr_lambdas": [None, None]},
                    os.path.join(output_dir, "scheduler.pt"))
+        torch.save(asdict(self.args), os.path.join(output_dir, "training_args.bin"))       # HF pickles its TrainingArguments; nothing reads it on resume
         self._flush_logs()
         with open(os.path.join(output_dir, "trainer_state.json"), "w") as f:
-            json.dump({"global_step": self.global_step, "max_steps": self.args.max_steps, "log_history": self.log_history,
-                       "desta_hip": {"forward_count": self.model._fwd_count, "dropout_seed": self.model.dropout_seed}}, f, indent=1)
+            f.write(json.dumps(self._trainer_state(), indent=2, sort_keys=True) + "\n")   # `TrainerState.save_to_json` format
+        with open(os.path.join(output_dir, "desta_hip_state.json"), "w") as f:
+            json.dump({"forward_count": self.model._fwd_count, "dropout_seed": self.model.dropout_seed, "micro": self._micro}, f, indent=1)
 
     def resume_from_checkpoint(self, ckpt_dir: str) -> None:
-        """Restore parameters, optimizer moments, schedule position and the dropout stream position."""
-        import json
+        """Restore parameters, optimizer moments, schedule position, log history and the dropout stream position.  Reads
+        checkpoints written by this trainer AND `checkpoint-<step>/` directories of the reference's HF Trainer (same
+        model.safetensors keys, optimizer.pt / scheduler.pt wire formats, trainer_state.json)."""
         from safetensors.torch import load_file
         from ..models.modeling_desta25 import reference_parameter_names
         self.wait_update()
@@ -512,7 +606,15 @@ class DeSTA25Trainer:
         if os.path.isfile(st_path):
             with open(st_path) as f:
                 st = json.load(f)
-            self.model._fwd_count = int(st.get("desta_hip", {}).get("forward_count", self.model._fwd_count))
+            self.global_step = int(st.get("global_step", self.global_step))
+            self.log_history = list(st.get("log_history") or [])
+            legacy = st.get("desta_hip") or {}                                 # round-2 files kept the sidecar data inside trainer_state.json
+            self.model._fwd_count = int(legacy.get("forward_count", self.model._fwd_count))
+        side = os.path.join(ckpt_dir, "desta_hip_state.json")
+        if os.path.isfile(side):
+            with open(side) as f:
+                self.model._fwd_count = int(json.load(f).get("forward_count", self.model._fwd_count))
+        self._micro = 0                                                       # checkpoints are written at window boundaries only
         self.model.connector.refresh_weights()
         self.model._weights_dirty = False
 

@@ -135,9 +135,11 @@ def test_rccl_branch_at_world_size_one_is_the_identity(tmp_path):
 
 
 @pytest.mark.gpu
-def test_gradient_accumulation_equals_the_mean_of_micro_batch_gradients():
+def test_gradient_accumulation_equals_the_sum_of_micro_batch_gradients():
     """`trainer.accumulate_grad_batches: 2` (HF gradient_accumulation_steps): two micro-batches per optimizer step, the update is
-    made from the MEAN of their gradient arenas — bit for bit what one gets by averaging the two arenas by hand; `global_step`
+    made from the SUM of their gradient arenas — what the reference does: its `forward(**kwargs)` makes HF treat the model as
+    accepting loss kwargs, `compute_loss` drops `num_items_in_batch`, so the loss is never divided by the window length
+    (TF:trainer.py:1952-1954, SURVEY hazard H8) — bit for bit what one gets by adding the two arenas by hand; `global_step`
     counts optimizer steps; an empty micro-batch contributes nothing."""
     _setup_paths()
     from desta.optim import FusedAdafactor, linear_warmup_lr
@@ -162,7 +164,7 @@ def test_gradient_accumulation_equals_the_mean_of_micro_batch_gradients():
             ref(**b)
             ref.backward()
             acc += ref.arena.grads
-        ref.arena.grads.copy_(acc * 0.5)
+        ref.arena.grads.copy_(acc)
         opt.step(linear_warmup_lr(stp, LR, WARM, TOTAL))
         ref.connector.refresh_weights()
     torch.cuda.synchronize()
