@@ -106,15 +106,18 @@ def cpu_baseline(cfg, B, S_ctx, S_tgt, threads):
         t_l0_ac = timed(lambda: llm(0))
     t_layer_ac = max(t_l1_ac - t_l0_ac, 1e-6)
     nt = len(cfg.target_layer_ids)
-    full = B * (t_mel + t_stem + e.encoder_layers * t_enc + nt * cfg.qformer_num_hidden_layers * t_qf
-                + c.num_hidden_layers * min(t_layer, t_layer_ac) + min(t_head, t_l0_ac))
+    fixed = t_mel + t_stem + e.encoder_layers * t_enc + nt * cfg.qformer_num_hidden_layers * t_qf
+    full_fp32 = B * (fixed + c.num_hidden_layers * t_layer + t_head)
+    full_mix = B * (fixed + c.num_hidden_layers * min(t_layer, t_layer_ac) + min(t_head, t_l0_ac))
     sample = (f"oracle fp32 on {threads} threads, B=1: log-mel {t_mel:.2f}s, conv stem {t_stem:.2f}s, 1 Whisper layer fwd {t_enc:.2f}s, "
               f"1 Q-Former layer fwd+bwd on one tap {t_qf:.2f}s, 1 LLM layer fwd+bwd {t_layer:.2f}s (autocast-bf16 policy: {t_layer_ac:.2f}s), "
-              f"final norm+lm_head+CE fwd+bwd {t_head:.2f}s (autocast {t_l0_ac:.2f}s); the faster precision is used; "
+              f"final norm+lm_head+CE fwd+bwd {t_head:.2f}s (autocast {t_l0_ac:.2f}s); `value` is the fp32 extrapolation "
               f"scaled to B={B}, {e.encoder_layers}+{nt}x{cfg.qformer_num_hidden_layers}+{c.num_hidden_layers} layers (optimizer/clip time excluded: <1% of the step)")
-    sample += ("; the one-layer extrapolation is validated by one real full-depth B=1 step (python bench.py --cpu-full-step, "
-               "log committed as profiles/r02_cpu_full_step_B1.log)")
-    return {"value": 1.0 / full, "unit": "steps/s", "cores": threads, "kind": "port", "sample": sample}
+    sample += ("; the fp32 one-layer extrapolation is the one validated by a real full-depth fp32 B=1 step (python bench.py --cpu-full-step, "
+               "log committed as profiles/r02_cpu_full_step_B1.log: 34.3 s per sample); `value_fastest_precision_mix` takes the faster of "
+               "fp32 / autocast(bf16)-policy per component and is NOT validated by a full step")
+    return {"value": 1.0 / full_fp32, "unit": "steps/s", "cores": threads, "kind": "port", "precision": "fp32", "sample": sample,
+            "value_fastest_precision_mix": 1.0 / full_mix}
 
 
 def cpu_full_step(cfg, S_ctx, S_tgt, threads):
@@ -150,6 +153,98 @@ def cpu_full_step(cfg, S_ctx, S_tgt, threads):
             "cores": threads, "precision": "fp32"}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(a, argv):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: start the N ranks as a FRESH child process —
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same flags>`, the driver's own command line —
+    BEFORE this process has touched the GPU, relay its output (rank 0 prints the JSON line) and exit with its code.  A request
+    for more ranks than the node has GPUs exits non-zero instead of quietly running fewer."""
+    import subprocess
+    if not a.single_device and not a.launch_check:
+        have = torch.cuda.device_count()                 # counting devices does not initialise the GPU
+        if have < a.gpus:
+            print(f"[bench] --gpus {a.gpus} but this node exposes {have} GPU(s); refusing to report a smaller run "
+                  "(use --backend gloo --single-device for a one-GPU rehearsal)", file=sys.stderr)
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__), *argv]
+    print(f"[bench] launching {a.gpus} ranks: {' '.join(cmd[1:9])} ...", file=sys.stderr)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launch_check(a, world, rank):
+    """Plumbing-only run of the N-rank path (no device work): rendezvous, one SUM all-reduce, barrier, MAX over ranks, rank 0
+    prints a line with `n_gpus`.  What the CPU test of the self-launch drives (`--launch-check --backend gloo`)."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(a.backend if a.backend != "nccl" else "gloo")
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "launch-check (no device work)", "value": None, "n_gpus": dist.get_world_size(),
+                          "ranks_sum": float(t), "requested_gpus": a.gpus, "backend": dist.get_backend()}))
+    dist.destroy_process_group()
+
+
+def box_calibration(H, dev, warm_seconds=2.0, launches=20):
+    """The same fixed work on every box, measured in this process right before the timed region, so that a reader can
+    separate the BOX (clock under the power cap: the same binary spreads +-2.5 % over boxes) from the CODE when
+    comparing bench lines across boxes and rounds: this library's bf16 GEMM on 8192^3 and on the gate_up shape
+    (5120 x 28672 x 4096), random operands, HIP events around `launches` back-to-back calls after a warm loop, and one
+    streaming device-to-device copy of 1 GiB."""
+    out = {}
+    g = torch.Generator(device=dev).manual_seed(99)
+
+    def rnd(r, c):
+        return (torch.rand(r, c, generator=g, device=dev, dtype=torch.float32) * 2 - 1).mul_(c ** -0.5).to(torch.bfloat16)
+
+    def timed(fn, n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / n
+    A, Bm, C = rnd(8192, 8192), rnd(8192, 8192), torch.empty(8192, 8192, dtype=torch.bfloat16, device=dev)
+    t_end = time.perf_counter() + warm_seconds
+    while time.perf_counter() < t_end:                   # clocks settle under sustained MFMA load
+        for _ in range(10):
+            H.gemm(A, Bm, C, 8192, 8192, 8192)
+        torch.cuda.synchronize()
+    dt = timed(lambda: H.gemm(A, Bm, C, 8192, 8192, 8192), launches)
+    out["gemm_8192cubed_tflops"] = 2 * 8192 ** 3 / dt / 1e12
+    del A, Bm, C
+    X, W, Y = rnd(5120, 4096), rnd(28672, 4096), torch.empty(5120, 28672, dtype=torch.bfloat16, device=dev)
+    for _ in range(5):
+        H.gemm(X, W, Y, 5120, 28672, 4096)
+    dt = timed(lambda: H.gemm(X, W, Y, 5120, 28672, 4096), launches)
+    out["gemm_gate_up_tflops"] = 2 * 5120 * 28672 * 4096 / dt / 1e12
+    del X, W, Y
+    src = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_(generator=g)
+    dst = torch.empty_like(src)
+    for _ in range(3):
+        dst.copy_(src)
+    dt = timed(lambda: dst.copy_(src), 10)
+    out["copy_1GiB_GBps"] = 2 * src.numel() * 4 / dt / 1e9                   # bytes read + bytes written
+    del src, dst
+    pr = torch.cuda.get_device_properties(dev)
+    out["device"] = {"name": pr.name, "arch": getattr(pr, "gcnArchName", None), "uuid": str(getattr(pr, "uuid", "")) or None,
+                     "pci_bus_id": getattr(pr, "pci_bus_id", None), "compute_units": pr.multi_processor_count}
+    out["note"] = (f"{launches} launches each after a {warm_seconds:.0f}-s warm loop, random operands; "
+                   "roofline.frac_normalised = in-situ dominant-kernel TFLOP/s / gemm_gate_up_tflops")
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,6 +270,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group and run the gradient all-reduce even at WORLD_SIZE 1 (one-GPU rehearsal of the N > 1 path over RCCL)")
     ap.add_argument("--small-gemm-ring", type=int, default=None, help="A/B: option 6 of desta_gemm_set_option (0 = the 128x128 GEMM never takes its four-slot ring form, 1 = default, 2 = always)")
     ap.add_argument("--splitk-inkernel", action="store_true", help="A/B: reduce the K-slices of tail tiles inside the GEMM launch (scattered, ticketed) instead of by the fix-up launch")
+    ap.add_argument("--launch-check", action="store_true", help="plumbing only: rendezvous + one all-reduce of the N ranks, no device work (CPU test of the self-launch path)")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the box_calibration block (fixed GEMM / copy workloads before the timed region)")
     ap.add_argument("--full-lm-head", action="store_true", help="A/B: lm_head / CE over the whole token grid, not only the target rows")
     a = ap.parse_args()
 
@@ -186,8 +283,18 @@ def main():
                                                          min(len(os.sched_getaffinity(0)), 64)), "config": a.config}))
         return
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:    # not under torchrun: become the launcher (before any GPU call)
+        sys.exit(self_launch(a, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if a.gpus != world:
+        if rank == 0:
+            print(f"[bench] --gpus {a.gpus} does not match WORLD_SIZE {world}: refusing to print a line for a different run",
+                  file=sys.stderr)
+        sys.exit(2)
+    if a.launch_check:
+        launch_check(a, world, rank)
+        return
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.single_device:
         local = 0
@@ -204,8 +311,6 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
         else:
             dist.init_process_group(a.backend)
-    if a.gpus != world and rank == 0 and world > 1:
-        print(f"[bench] --gpus {a.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
 
@@ -281,14 +386,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    calib = None
+    if rank == 0 and not a.no_calibration:
+        calib = box_calibration(H, dev)
+    fence()
     run(a.warmup, 0)
     fence()
+    trainer.comm_profile = [] if (world > 1 or a.force_dist) else None     # HIP events around the collective / the main stream's wait
     H.gemm_profile_start()
     t0 = time.perf_counter()
     loss = run(a.steps, a.warmup, mark=True)
     fence()
     elapsed = time.perf_counter() - t0
     prof = H.gemm_profile_stop(by_kernel=True)
+    comm, trainer.comm_profile = trainer.comm_profile, None
     per_step = [x.elapsed_time(y) for x, y in zip(step_events[:-1], step_events[1:])]
     # untimed extra pass: HIP events around every HBM-bound / attention launch (algorithmic bytes / FLOP per call from the wrappers)
     kprof, kp_steps = {}, 3
@@ -334,6 +445,9 @@ def main():
             with open(rpath) as f:
                 torch_ref = json.load(f)
             torch_ref["speedup_of_this_run"] = torch_ref["ms_per_step"] / ms_step
+            torch_ref["measured_in_this_run"] = False
+            torch_ref["note"] = ("stored constant: tools/hf_step_bench.py measured once in round 2 on another box "
+                                 "(profiles/r02_hf_pytorch_step.log); only the ratio uses this run's ms_per_step")
         mean_ps = sum(per_step) / max(1, len(per_step))
         sd_ps = (sum((x - mean_ps) ** 2 for x in per_step) / max(1, len(per_step) - 1)) ** 0.5
         # executed FLOP per step: every GEMM launch of the timed region (HIP-event records carry 2MNK) + the attention kernels'
@@ -371,9 +485,12 @@ def main():
                                               "(rows whose logits the loss ignores / whose gradient nothing consumes are not computed; "
                                               "loss and every parameter gradient identical to the full grid, tests/test_gpu_model.py)")},
             "final_loss": final_loss,
+            "box_calibration": calib,
             "pytorch_rocm_reference_point": torch_ref,
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_256_kernel", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
+                         # in-situ rate of the dominant kernel / the same kernel alone on this box right before the run (gate_up shape)
+                         "frac_normalised": (achieved / calib["gemm_gate_up_tflops"]) if calib else None,
                          "launches_per_step": n_launch / a.steps, "avg_launch_us": 1e3 * gemm_ms / max(n_launch, 1),
                          "flop_per_launch": flops / max(n_launch, 1), "gemm_ms_per_step": gemm_ms / a.steps,
                          "other_gemm_kernels": {"launches_per_step": n_other / a.steps, "ms_per_step": ms_other / a.steps,
@@ -390,6 +507,17 @@ def main():
                          # HBM-bound kernels of the step: ALGORITHMIC bytes / HIP-event time of an untimed 3-step pass, vs 8 TB/s
                          "hbm_kernels": hbm_kernels, "attention_kernels": attn_kernels},
         }
+        if comm is not None:
+            # data-parallel exchange of the timed region (rank 0's events): the flat fp32 gradient arena, one collective per step
+            ar = [x.elapsed_time(y) for kind, x, y in comm if kind == "allreduce"]
+            st = [x.elapsed_time(y) for kind, x, y in comm if kind == "wait_update"]
+            out["allreduce_ms"] = sum(ar) / max(1, len(ar))
+            out["allreduce_ms_min_max"] = [min(ar), max(ar)] if ar else None
+            out["bytes_allreduced"] = int(model.arena.grads.numel() * 4)
+            out["allreduce_busbw_GBps"] = (2 * (world - 1) / world * out["bytes_allreduced"] / (out["allreduce_ms"] * 1e-3) / 1e9) if ar and world > 1 and out["allreduce_ms"] > 0 else None
+            out["wait_update_stall_ms"] = sum(st) / max(1, len(st))        # main stream idle in front of the connector forward, waiting for the side-stream tail (all-reduce + Adafactor + re-cast) of the previous step
+            out["comm_hidden"] = bool(st) and out["wait_update_stall_ms"] < 0.05
+            out["comm_backend"] = dist.get_backend() if dist.is_initialized() else None
         if not a.no_cpu_baseline and world == 1:
             try:
                 threads = min(len(os.sched_getaffinity(0)), 64)

@@ -934,6 +934,7 @@ class DeSTA25AudioModel:
         self.compact_lm_head = True            # training: lm_head / CE / its backward on target rows only
         self._tr_stream = self._tr_idx = self._tr_lab = self._tr_count = self._tr_count_host = None
         self._fwd_count = 0
+        self._slot_cache: Dict[tuple, tuple] = {}
 
     # -- weights -------------------------------------------------------------------------------
     @staticmethod
@@ -1022,19 +1023,37 @@ class DeSTA25AudioModel:
         self._weights_dirty = True
 
     # -- forward / backward ----------------------------------------------------------------------
+    def _audio_slots(self, starts, B: int, S: int, s_major: bool):
+        """Flat row indices of the audio slots of inputs_embeds ([N_audio * K] int64, device) and the source-map values that
+        mark them (-(audio_row + 1), int32), cached per (starts, B, S, layout) signature: batches of one run share a handful of
+        signatures, so neither forward nor backward rebuilds and re-uploads index tensors every step."""
+        K = self.config.prompt_size
+        key = (tuple(starts), B, S, bool(s_major))
+        hit = self._slot_cache.get(key)
+        if hit is None:
+            ar = torch.arange(K, dtype=torch.int64)
+            pos = torch.cat([((s + ar) * B + r) if s_major else (r * S + s + ar) for r, s in starts])
+            val = -(torch.arange(len(starts) * K, dtype=torch.int32) + 1)
+            if len(self._slot_cache) >= 64:
+                self._slot_cache.clear()
+            hit = self._slot_cache[key] = (pos.to(self.device), val.to(self.device), pos.to(self.device, torch.int32))
+        return hit
+
     def _src_rows(self, input_ids, batch_transcription_ids, batch_start_positions, audio_lengths):
         """int32 map [B*S]: >=0 token row of the embedding table, <0 -(audio_row+1)."""
         B, S = input_ids.shape
         K = self.config.prompt_size
         src = input_ids.to(torch.int32).clone()
-        for a, (row, start) in enumerate(batch_start_positions):
-            row, start = int(row), int(start)
+        starts = [(int(r), int(s)) for r, s in batch_start_positions]
+        for a, (row, start) in enumerate(starts):
+            assert start + K + batch_transcription_ids[a].numel() <= S, "audio span exceeds the sequence"
+        if starts:
+            pos, val, _ = self._audio_slots(starts, B, S, False)
+            src.view(-1).index_copy_(0, pos, val)                             # one launch for every audio span of the batch
+        for a, (row, start) in enumerate(starts):
             tr = batch_transcription_ids[a].reshape(-1)
-            n = K + tr.numel()
-            assert start + n <= S, "audio span exceeds the sequence"
-            src[row, start:start + K] = -(torch.arange(a * K, (a + 1) * K, device=src.device, dtype=torch.int32) + 1)
-            if tr.numel():
-                src[row, start + K:start + n] = tr.to(src.device, torch.int32)
+            if tr.numel():                                                    # (empty in training, hazard H9)
+                src[row, start + K:start + K + tr.numel()] = tr.to(src.device, torch.int32)
         return src.reshape(-1).contiguous()
 
     def forward(self, input_ids, attention_mask, batch_features, batch_transcription_ids, batch_start_positions,
@@ -1356,10 +1375,9 @@ class DeSTA25AudioModel:
         with torch.cuda.device(self.device):
             if f["s_major"]:
                 dx0 = self.llm.backward(first_needed_pos=min(s for _, s in f["starts"]))
-                idx = torch.cat([torch.arange(s, s + K, dtype=torch.int32) * B + r for r, s in f["starts"]]).to(self.device)
             else:
                 dx0 = self.llm.backward()
-                idx = torch.cat([torch.arange(r * S + s, r * S + s + K, dtype=torch.int32) for r, s in f["starts"]]).to(self.device)
+            idx = self._audio_slots(f["starts"], B, S, f["s_major"])[2]
             d_af = torch.empty(f["N_audio"] * K, self.config.llm_config.hidden_size, dtype=BF16, device=self.device)
             H.gather_rows(dx0, idx, f["N_audio"] * K, self.config.llm_config.hidden_size, d_af)
         self._fwd = None

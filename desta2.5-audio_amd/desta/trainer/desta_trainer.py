@@ -53,6 +53,9 @@ class TrainingArguments:
     shuffle: bool = True                           # (HF: RandomSampler unless group_by_length); False = manifest order
 
 
+ALLREDUCE_CALLS: Dict[str, int] = {}              # "<backend>:<op>" -> collectives issued by this process (tests assert which branch ran)
+
+
 def allreduce_mean_(flat: torch.Tensor) -> None:
     """Mean over data-parallel ranks of ONE flat buffer (what DDP's bucketed reducer does for the
     reference, accelerate `accelerator.py:1892`): RCCL AVG over xGMI on GPUs, SUM + scale on gloo."""
@@ -62,9 +65,12 @@ def allreduce_mean_(flat: torch.Tensor) -> None:
         return
     if dist.get_backend() == "nccl":
         dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+        ALLREDUCE_CALLS["nccl:AVG"] = ALLREDUCE_CALLS.get("nccl:AVG", 0) + 1
     else:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat.mul_(1.0 / dist.get_world_size())
+        key = f"{dist.get_backend()}:SUM*1/world"
+        ALLREDUCE_CALLS[key] = ALLREDUCE_CALLS.get(key, 0) + 1
 
 
 def micro_batches_per_epoch(args: TrainingArguments, n_samples: Optional[int], world: int) -> Optional[int]:
@@ -175,14 +181,31 @@ class DeSTA25Trainer:
     # -- one optimizer step ----------------------------------------------------------------------
     def _reduce_and_update(self, lr: float) -> None:
         arena = self.model.arena
-        allreduce_mean_(arena.grads)                                          # one flat buffer, no buckets
+        prof = getattr(self, "comm_profile", None)
+        if prof is not None:                                                  # bench.py: HIP events around the collective, on the stream it runs on
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            allreduce_mean_(arena.grads)
+            e1.record()
+            prof.append(("allreduce", e0, e1))
+        else:
+            allreduce_mean_(arena.grads)                                      # one flat buffer, no buckets
         self.optimizer.step(lr)
         self.model.connector.refresh_weights()
 
     def wait_update(self) -> None:
         """Main stream waits for the side-stream all-reduce + optimizer of the previous step."""
         if self._side_done is not None:
-            torch.cuda.current_stream(self.model.device).wait_event(self._side_done)
+            main = torch.cuda.current_stream(self.model.device)
+            prof = getattr(self, "comm_profile", None)
+            if prof is not None:                                              # how long the main stream sits in front of this wait
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(main)
+                main.wait_event(self._side_done)
+                e1.record(main)
+                prof.append(("wait_update", e0, e1))
+            else:
+                main.wait_event(self._side_done)
             self._side_done = None
 
     def training_step(self, inputs: Dict[str, Any], next_inputs: Optional[Dict[str, Any]] = None,

@@ -58,7 +58,9 @@ def worker(out_dir):
     assert tr.world == world and tr._side is not None and model.dropout_seed == 1 + rank
     losses = tr.train(_batches(d, rank))
     assert tr.global_step == STEPS and tr.optimizer.step_count == STEPS
-    torch.save({"params": model.arena.params.cpu(), "state": tr.optimizer.state.cpu(), "losses": losses}, os.path.join(out_dir, f"rank{rank}.pt"))
+    from desta.trainer.desta_trainer import ALLREDUCE_CALLS
+    torch.save({"params": model.arena.params.cpu(), "state": tr.optimizer.state.cpu(), "losses": losses,
+                "backend": dist.get_backend(), "allreduce_calls": dict(ALLREDUCE_CALLS)}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -77,6 +79,7 @@ def test_two_rank_trainer_bit_identical_and_equals_single_process_mean(tmp_path)
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
     r0, r1 = (torch.load(tmp_path / f"rank{r}.pt", weights_only=True) for r in range(2))
+    assert r0["allreduce_calls"] == r1["allreduce_calls"] == {"gloo:SUM*1/world": STEPS}
     assert torch.equal(r0["params"], r1["params"]), "ranks diverged"
     assert torch.equal(r0["state"], r1["state"]), "optimizer state diverged across ranks"
     assert r1["losses"][EMPTY_AT[0]] == 0.0 and all(l > 0 for l in r0["losses"])
@@ -125,6 +128,7 @@ def test_rccl_branch_at_world_size_one_is_the_identity(tmp_path):
                        stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:]
     r0 = torch.load(tmp_path / "rank0.pt", weights_only=True)
+    assert r0["backend"] == "nccl" and r0["allreduce_calls"] == {"nccl:AVG": STEPS}, (r0["backend"], r0["allreduce_calls"])   # the RCCL AVG branch ran, once per step
     _setup_paths()
     from desta.trainer.desta_trainer import DeSTA25Trainer, TrainingArguments
     d, model = _model()
