@@ -32,6 +32,7 @@ struct AttnArgs {
     const bf16_t* Q; const bf16_t* K; const bf16_t* V; bf16_t* O;
     const bf16_t* dO; bf16_t* dQ; bf16_t* dK; bf16_t* dV;
     float* lse; const float* delta;
+    float* O32;                                                      // optional fp32 copy of O (same strides as O): delta = rowsum(dO * O) from the UNROUNDED output
     long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;           // batch / row strides (elements)
     long do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
     int B, Hq, Hkv, Sq, Sk;
@@ -336,7 +337,235 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (D == 64 ? ATTN_FWD64_WAVES : 2)
                 for (int e = 0; e < 4; ++e) o[e] = f2bf(oacc[i][4 * rq + e] * inv);
                 *(u16x4*)(optr + i * 32 + 8 * rq + 4 * h2) = o;
             }
+        if (p.O32) {
+            float* o32 = p.O32 + (long)b * p.o_bs + (long)qcol * p.o_rs + (long)h * D;
+#pragma unroll
+            for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq)
+                    *(f32x4*)(o32 + i * 32 + 8 * rq + 4 * h2) = f32x4{oacc[i][4 * rq] * inv, oacc[i][4 * rq + 1] * inv, oacc[i][4 * rq + 2] * inv, oacc[i][4 * rq + 3] * inv};
+        }
         if (p.lse && h2 == 0) p.lse[((long)b * p.Hq + h) * p.Sq + qcol] = l > 0.f ? m + log2f(l) : INFINITY;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ forward, 8 waves per block
+// The forward for long query ranges (LLM prefill / training: D = 128 causal GQA; Whisper: D = 64, 1500 x 1500).  Same
+// orientation as above (key on the accumulator rows, query on the lane, P^T straight from the S^T accumulator into the P.V
+// MFMAs), restructured around what the four-wave kernel spends its time on (rocprofv3: mfma-busy 0.18-0.29, waves parked
+// at barriers / waitcnts most of a tile):
+//   * EIGHT waves share one K / V tile: a block is 256 query rows of one head or, under GQA, HPB heads x 256 / HPB rows of one
+//     kv head (the heads of a group read the same K / V): half / a quarter of the staging instructions, LDS writes and global
+//     loads per unit of MFMA work, and under the causal mask 64- or 128-row blocks waste less of the diagonal tiles;
+//   * LDS double buffer, ONE raw s_barrier per tile (no vmcnt drain): tile t+1 is written to the other buffer in the middle of
+//     tile t (between the softmax and the P.V MFMAs) from registers loaded one tile earlier, and the global loads of tile
+//     t+2 are issued right behind it: every load has a whole tile of compute to land;
+//   * deferred rescale (guide T13): the running reference m only moves when some row's tile maximum exceeds it by more than
+//     2^ATTN_DEFER_LOG2: on all other tiles there is no alpha, no O rescale, no l rescale (P <= 2^ATTN_DEFER_LOG2: relative bf16
+//     rounding is unchanged, sums stay far inside fp32 range);
+//   * the row sum stays a per-lane partial (the two half-waves of a query column are combined once, in the epilogue); the row
+//     maximum crosses the half-waves with one v_permlane32_swap instead of a ds_bpermute round trip;
+//   * O is stored as 16-byte pieces after a permlane32 exchange of the packed halves (guide T21).
+// Work order: XCD x walks the (batch, kv head) groups x, x + 8, ...; causal launches the heaviest q-blocks of all its groups
+// first (the K / V of an XCD's ten groups fit its L2 together), non-causal keeps the q-blocks of a group back to back.
+#ifndef ATTN_DEFER_LOG2
+#define ATTN_DEFER_LOG2 6.0f
+#endif
+// MINW = 4 (D = 64 only): two 8-wave blocks per CU (<= 128 registers; costs five spilled registers, one reload per tile)
+__device__ __forceinline__ float swap_halves_max(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);     // r[0] = [lo, lo], r[1] = [hi, hi]
+    return fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+}
+__device__ __forceinline__ float swap_halves_sum(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+
+template <int D, bool CAUSAL, int HPB, int MINW = 2>
+__global__ __launch_bounds__(512, MINW) void attn_fwd8_k(AttnArgs p) {
+    constexpr int NT = 512, RB = 256 / HPB, WPH = RB / 32;         // query rows of a block (per head), waves per head
+    constexpr int TILE = 64 * D * 2;                               // bytes of one 64-key K (or V) image
+    __shared__ __attribute__((aligned(16))) char lds[4 * TILE];    // [buffer][K, V]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h2 = lane >> 5;
+    const int G = p.Hq / p.Hkv, nq = (p.Sq + RB - 1) / RB, hgroups = G / HPB, ngrp = p.B * p.Hkv;
+    int g, qblk, hg;
+    {
+        const int id = blockIdx.x, per = nq * hgroups;
+        if ((ngrp & 7) == 0) {
+            const int xcd = id & 7, slot = id >> 3, gpx = ngrp >> 3;
+            if (CAUSAL) {
+                const int r = slot % (hgroups * gpx);
+                qblk = nq - 1 - slot / (hgroups * gpx); hg = r / gpx; g = (r % gpx) * 8 + xcd;
+            } else {
+                const int r = slot % per;
+                g = (slot / per) * 8 + xcd; hg = r / nq; qblk = r % nq;
+            }
+        } else if (CAUSAL) {
+            const int r = id % (hgroups * ngrp);
+            qblk = nq - 1 - id / (hgroups * ngrp); hg = r / ngrp; g = r % ngrp;
+        } else {
+            const int r = id % per;
+            g = id / per; hg = r / nq; qblk = r % nq;
+        }
+    }
+    const int b = g / p.Hkv, hk = g % p.Hkv;
+    const int h = hk * G + hg * HPB + wave / WPH;
+    const int qb0 = qblk * RB, q0 = qb0 + (wave % WPH) * 32;
+    const int qcol = q0 + (lane & 31);
+    const bool wave_on = q0 < p.Sq;                                 // scalar: a wave past the ragged end only helps staging
+
+    const int coff = p.Sk - p.Sq;
+    const int kv_lo = p.kv_start ? max(0, min(p.kv_start[b], p.Sk)) : 0;
+    int kv_hi = p.Sk;
+    if (CAUSAL) kv_hi = min(p.Sk, min(qb0 + RB - 1, p.Sq - 1) + coff + 1);
+    const int t_lo = kv_lo / 64, t_hi = (kv_hi + 63) / 64;
+    const int q_abs = qcol + coff;
+    const int wave_kmax = CAUSAL ? min(q0 + 31, p.Sq - 1) + coff : p.Sk - 1;
+
+    const bf16_t* kbase = p.K + (long)b * p.k_bs + (long)hk * D;
+    const bf16_t* vbase = p.V + (long)b * p.v_bs + (long)hk * D;
+
+    // prologue, straight-line on purpose: first K / V tile, then the Q fragments; loads return in order, so once the Q
+    // fragments are in (the empty asm makes the compiler wait for them HERE) nothing of the prologue is still in flight and
+    // the loop's vmcnt bookkeeping covers only the K / V stream (with the Q loads pending at the loop head hipcc makes every
+    // tile's S MFMAs wait for vmcnt(3..0), i.e. for the loads of tile t+2 issued half a tile earlier).  Rows are clamped:
+    // the loads are legal even when the block has no tile at all.
+    stage_t<D, 64, NT> kr = tile_load<D, 64, NT>(kbase, p.k_rs, t_lo * 64, p.Sk - 1);
+    stage_t<D, 64, NT> vr = tile_load<D, 64, NT>(vbase, p.v_rs, t_lo * 64, p.Sk - 1);
+    const bf16_t* qptr = p.Q + (long)b * p.q_bs + (long)min(qcol, p.Sq - 1) * p.q_rs + (long)h * D;
+    bf16x8 qf[D / 16];
+#pragma unroll
+    for (int ds = 0; ds < D / 16; ++ds) qf[ds] = *(const bf16x8*)(qptr + 16 * ds + 8 * h2);
+#pragma unroll
+    for (int ds = 0; ds < D / 16; ++ds) asm volatile("" :: "v"(qf[ds]));
+    tile_store<D, 64, NT>(lds, kr);
+    tile_store<D, 64, NT>(lds + TILE, vr);
+    kr = tile_load<D, 64, NT>(kbase, p.k_rs, (t_lo + 1) * 64, p.Sk - 1);
+    vr = tile_load<D, 64, NT>(vbase, p.v_rs, (t_lo + 1) * 64, p.Sk - 1);
+
+    f32x16 oacc[D / 32];
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m = -INFINITY, l = 0.f;                                   // m: reference in scaled log2 units (may lag the true maximum by <= 2^DEFER); l: this lane's partial sum
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    auto tile = [&](const int kt, const int buf) __attribute__((always_inline)) {
+        const char* kimg = lds + buf * 2 * TILE;
+        const char* vimg = kimg + TILE;
+        const bool act = wave_on && kt * 64 <= wave_kmax;           // scalar
+        f32x16 st[2];
+        if (act) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+            bf16x8 ka[D / 16], kbf[D / 16];
+#pragma unroll
+            for (int ds = 0; ds < D / 16; ++ds) ka[ds] = frag_rows<D>(kimg, 0, ds, lane);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ds = 0; ds < D / 16; ++ds) {
+                st[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ds], qf[ds], st[0], 0, 0, 0);
+                kbf[ds] = frag_rows<D>(kimg, 32, ds, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ds = 0; ds < D / 16; ++ds) st[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kbf[ds], qf[ds], st[1], 0, 0, 0);
+            const bool need_mask = (kt * 64 + 63 >= p.Sk) || (kt * 64 < kv_lo) || (CAUSAL && kt * 64 + 63 > q0 + coff);
+            if (need_mask) {
+                asm volatile("; boundary tile" ::: "memory");
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kt * 64 + kb * 32 + acc_row(r, lane);
+                        const bool ok = key < p.Sk && key >= kv_lo && (!CAUSAL || key <= q_abs);
+                        st[kb][r] = ok ? st[kb][r] : -INFINITY;
+                    }
+            }
+            float tmax = fmaxf(st[0][0], st[1][0]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(st[0][r], st[1][r]));     // v_max3_f32
+            tmax = swap_halves_max(tmax) * p.scale_log2;                                      // scale > 0: max commutes
+            if (!__all(!(tmax > m + ATTN_DEFER_LOG2))) {                                      // some row outgrew its reference: move every row's
+                const float mnew = fmaxf(m, tmax);
+                const float alpha = __builtin_amdgcn_exp2f(m - (mnew == -INFINITY ? 0.f : mnew));     // m = -inf: 0 (O = l = 0 anyway)
+                l *= alpha;
+#pragma unroll
+                for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+                m = mnew;
+            }
+            const float nmu = (m == -INFINITY) ? 0.f : -m;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    st[kb][r] = __builtin_amdgcn_exp2f(fmaf(st[kb][r], p.scale_log2, nmu));
+                    l += st[kb][r];
+                }
+        }
+        // tile kt+1: registers -> the other buffer (its last readers passed the barrier that closed tile kt-1); then the loads of kt+2
+        if (kt + 1 < t_hi) {
+            tile_store<D, 64, NT>(lds + (buf ^ 1) * 2 * TILE, kr);
+            tile_store<D, 64, NT>(lds + (buf ^ 1) * 2 * TILE + TILE, vr);
+            if (kt + 2 < t_hi) {
+                kr = tile_load<D, 64, NT>(kbase, p.k_rs, (kt + 2) * 64, p.Sk - 1);
+                vr = tile_load<D, 64, NT>(vbase, p.v_rs, (kt + 2) * 64, p.Sk - 1);
+            }
+        }
+        if (act) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 pb = acc_frag(st[kb], s);
+#pragma unroll
+                    for (int i = 0; i < D / 32; ++i)
+                        oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(vimg, kb * 32 + 16 * s, i * 32, lane), pb, oacc[i], 0, 0, 0);
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // this tile's reads and the next tile's writes are done; global loads stay in flight
+    };
+    for (int kt = t_lo; kt < t_hi; kt += 2) {
+        tile(kt, 0);
+        if (kt + 1 < t_hi) tile(kt + 1, 1);
+    }
+
+    if (wave_on && qcol < p.Sq) {
+        const float lt = swap_halves_sum(l);
+        const float inv = lt > 0.f ? 1.0f / lt : 0.f;
+        bf16_t* optr = p.O + (long)b * p.o_bs + (long)qcol * p.o_rs + (long)h * D;
+#pragma unroll
+        for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                // registers 8j..8j+3: d = 32i + 16j + 4*h2 + e; 8j+4..8j+7: d = 32i + 16j + 8 + 4*h2 + e.  After the exchange a lane
+                // of the lower half holds d = 32i + 16j + 0..7, its partner in the upper half 32i + 16j + 8..15: one 16-byte store each
+                unsigned a[2], c[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    a[e] = (unsigned)f2bf(oacc[i][8 * j + 2 * e] * inv) | ((unsigned)f2bf(oacc[i][8 * j + 2 * e + 1] * inv) << 16);
+                    c[e] = (unsigned)f2bf(oacc[i][8 * j + 4 + 2 * e] * inv) | ((unsigned)f2bf(oacc[i][8 * j + 4 + 2 * e + 1] * inv) << 16);
+                }
+                const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], c[0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], c[1], false, false);
+                *(uint4*)(optr + i * 32 + 16 * j + 8 * h2) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+            }
+        if (p.O32) {
+            float* o32 = p.O32 + (long)b * p.o_bs + (long)qcol * p.o_rs + (long)h * D;
+#pragma unroll
+            for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq)
+                    *(f32x4*)(o32 + i * 32 + 8 * rq + 4 * h2) = f32x4{oacc[i][4 * rq] * inv, oacc[i][4 * rq + 1] * inv, oacc[i][4 * rq + 2] * inv, oacc[i][4 * rq + 3] * inv};
+        }
+        if (p.lse && h2 == 0) p.lse[((long)b * p.Hq + h) * p.Sq + qcol] = lt > 0.f ? m + log2f(lt) : INFINITY;
     }
 }
 
@@ -351,11 +580,18 @@ __global__ __launch_bounds__(256) void attn_delta_k(AttnArgs p, float* __restric
     const bool active = rowid < total;
     const long rr = active ? rowid : 0;
     const int q = (int)(rr % p.Sq), h = (int)((rr / p.Sq) % p.Hq), b = (int)(rr / ((long)p.Sq * p.Hq));
-    const u16x8 o = *(const u16x8*)(p.O + (long)b * p.o_bs + (long)q * p.o_rs + (long)h * D + 8 * j);
     const u16x8 g = *(const u16x8*)(p.dO + (long)b * p.do_bs + (long)q * p.do_rs + (long)h * D + 8 * j);
     float s = 0.f;
+    if (p.O32) {                                           // the unrounded forward output (see desta_attn_desc.O_f32)
+        const float* o32 = p.O32 + (long)b * p.o_bs + (long)q * p.o_rs + (long)h * D + 8 * j;
+        const f32x4 o0 = *(const f32x4*)o32, o1 = *(const f32x4*)(o32 + 4);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s += bf2f(o[e]) * bf2f(g[e]);
+        for (int e = 0; e < 4; ++e) s += o0[e] * bf2f(g[e]) + o1[e] * bf2f(g[4 + e]);
+    } else {
+        const u16x8 o = *(const u16x8*)(p.O + (long)b * p.o_bs + (long)q * p.o_rs + (long)h * D + 8 * j);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += bf2f(o[e]) * bf2f(g[e]);
+    }
 #pragma unroll
     for (int o2 = 1; o2 < G; o2 <<= 1) s += __shfl_xor(s, o2, 64);
     if (active && j == 0) delta[rowid] = s;
@@ -742,7 +978,7 @@ int fill_args(const desta_attn_desc* d, AttnArgs& a) {
     DESTA_CHECK_ARG(d->batch <= 65535 && d->n_q_heads <= 65535, "attention: grid too large");
     a.Q = (const bf16_t*)d->Q; a.K = (const bf16_t*)d->K; a.V = (const bf16_t*)d->V; a.O = (bf16_t*)d->O;
     a.dO = (const bf16_t*)d->dO; a.dQ = (bf16_t*)d->dQ; a.dK = (bf16_t*)d->dK; a.dV = (bf16_t*)d->dV;
-    a.lse = d->lse; a.delta = nullptr;
+    a.lse = d->lse; a.delta = nullptr; a.O32 = d->O_f32;
     a.q_bs = d->q_batch_stride; a.q_rs = d->q_row_stride; a.k_bs = d->k_batch_stride; a.k_rs = d->k_row_stride;
     a.v_bs = d->v_batch_stride; a.v_rs = d->v_row_stride; a.o_bs = d->o_batch_stride; a.o_rs = d->o_row_stride;
     a.do_bs = d->do_batch_stride; a.do_rs = d->do_row_stride; a.dq_bs = d->dq_batch_stride; a.dq_rs = d->dq_row_stride;
@@ -761,11 +997,40 @@ int fill_args(const desta_attn_desc* d, AttnArgs& a) {
 
 }  // namespace
 
+namespace { int g_attn_opt[4] = {1, 0, 0, 0}; }
+extern "C" int desta_attention_set_option(int which, int value) {
+    DESTA_CHECK_ARG(which >= 0 && which < 4, "attention_set_option: unknown option %d", which);
+    g_attn_opt[which] = value;
+    return DESTA_OK;
+}
+
 extern "C" int desta_attention_fwd(const desta_attn_desc* d, void* stream) {
     AttnArgs a;
     if (int rc = fill_args(d, a)) return rc;
     DESTA_CHECK_ARG(d->O, "attention_fwd: null output");
-    DESTA_CHECK_ARG(d->o_row_stride % 4 == 0, "attention_fwd: o_row_stride must be a multiple of 4");
+    DESTA_CHECK_ARG(d->o_row_stride % 8 == 0 && d->o_batch_stride % 8 == 0 && ((size_t)d->O & 15) == 0,
+                    "attention_fwd: O must be 16-byte aligned with row / batch strides that are multiples of 8 elements");
+    if (g_attn_opt[0] && !a.drop_thresh && a.Sq >= 128) {
+        // 8-wave blocks: HPB heads of one GQA group x 256 / HPB query rows (the heads share the K / V tiles)
+        const int G = a.Hq / a.Hkv;
+        const int hpb = !a.causal ? 1 : (d->head_dim == 128 ? (G % 4 == 0 ? 4 : (G % 2 == 0 ? 2 : 1)) : (G % 2 == 0 ? 2 : 1));
+        const int rb = 256 / hpb;
+        dim3 g8((unsigned)((a.Sq + rb - 1) / rb) * (unsigned)(G / hpb) * (unsigned)(a.B * a.Hkv));
+        hipStream_t st = (hipStream_t)stream;
+        if (d->head_dim == 128) {
+            if (!a.causal) hipLaunchKernelGGL((attn_fwd8_k<128, false, 1>), g8, dim3(512), 0, st, a);
+            else if (hpb == 4) hipLaunchKernelGGL((attn_fwd8_k<128, true, 4>), g8, dim3(512), 0, st, a);
+            else if (hpb == 2) hipLaunchKernelGGL((attn_fwd8_k<128, true, 2>), g8, dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((attn_fwd8_k<128, true, 1>), g8, dim3(512), 0, st, a);
+        } else {
+            if (!a.causal && g_attn_opt[1]) hipLaunchKernelGGL((attn_fwd8_k<64, false, 1, 4>), g8, dim3(512), 0, st, a);
+            else if (!a.causal) hipLaunchKernelGGL((attn_fwd8_k<64, false, 1>), g8, dim3(512), 0, st, a);
+            else if (hpb == 2) hipLaunchKernelGGL((attn_fwd8_k<64, true, 2>), g8, dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((attn_fwd8_k<64, true, 1>), g8, dim3(512), 0, st, a);
+        }
+        DESTA_CHECK_LAUNCH("attention_fwd");
+        return DESTA_OK;
+    }
     const bool two = d->head_dim == 64 && a.Sq <= 64;
     dim3 grid((unsigned)((a.Sq + (two ? 63 : 127)) / (two ? 64 : 128)) * a.Hq * a.B);       // 1-D: attn_work_item() orders it per XCD                  // 64-row blocks of two waves (Q-Former queries)
     if (d->head_dim == 128) hipLaunchKernelGGL((attn_fwd_k<128, false>), grid, dim3(256), 0, (hipStream_t)stream, a);

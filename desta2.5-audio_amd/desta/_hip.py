@@ -39,7 +39,7 @@ class GemmDesc(C.Structure):
 
 lib.desta_abi_version.restype = i32
 lib.desta_last_error.restype = C.c_char_p
-ABI_VERSION = 3
+ABI_VERSION = 4
 if lib.desta_abi_version() != ABI_VERSION:
     raise ImportError(f"libdesta_hip.so has ABI version {lib.desta_abi_version()}, this binding needs {ABI_VERSION}: "
                       "rebuild with `python desta2.5-audio_amd/build.py`")
@@ -386,7 +386,7 @@ class AttnDesc(C.Structure):
                 ("dk_batch_stride", i64), ("dk_row_stride", i64), ("dv_batch_stride", i64), ("dv_row_stride", i64),
                 ("batch", i32), ("n_q_heads", i32), ("n_kv_heads", i32), ("seq_q", i32), ("seq_k", i32),
                 ("head_dim", i32), ("causal", i32), ("kv_start", vp), ("scale", f32),
-                ("dropout_p", f32), ("dropout_seed", C.c_uint64)]
+                ("dropout_p", f32), ("dropout_seed", C.c_uint64), ("O_f32", vp)]
 
 
 _attn_fwd = _sig("desta_attention_fwd", C.POINTER(AttnDesc), vp)
@@ -401,9 +401,10 @@ def _elem_ptr(t, offset_elems):
 
 def attn_desc(q, k, v, o, lse, *, batch, hq, hkv, sq, sk, hd, scale, causal=False, kv_start=None,
               q_off=0, k_off=0, v_off=0, q_rs=None, k_rs=None, v_rs=None, o_rs=None, dropout_p=0.0, dropout_seed=0,
-              q_bs=None, k_bs=None, v_bs=None, o_bs=None):
+              q_bs=None, k_bs=None, v_bs=None, o_bs=None, o_f32=None):
     """q/k/v are 2-D row-major [batch*seq, row_stride] buffers (possibly the same fused buffer);
-    *_off = first column of the q/k/v slice."""
+    *_off = first column of the q/k/v slice.  `o_f32`: optional fp32 buffer of O's shape; forward also writes the unrounded
+    output there and backward takes delta = rowsum(dO * O) from it (see include/desta_hip.h)."""
     d = AttnDesc()
     q_rs = q.shape[-1] if q_rs is None else q_rs
     k_rs = k.shape[-1] if k_rs is None else k_rs
@@ -420,7 +421,10 @@ def attn_desc(q, k, v, o, lse, *, batch, hq, hkv, sq, sk, hd, scale, causal=Fals
     d.kv_start = p(kv_start)
     d.scale = scale
     d.dropout_p, d.dropout_seed = dropout_p, dropout_seed
-    d._keep = (q, k, v, o, lse, kv_start)       # the descriptor holds RAW pointers: keep the tensors alive with it
+    if o_f32 is not None:
+        assert o_f32.dtype == torch.float32 and o_f32.shape == o.shape and o_f32.is_contiguous() and o.is_contiguous()
+    d.O_f32 = p(o_f32)
+    d._keep = (q, k, v, o, lse, kv_start, o_f32)       # the descriptor holds RAW pointers: keep the tensors alive with it
     return d
 
 
@@ -533,6 +537,11 @@ def sample_top_p(logits, ld, rows, cols, temperature, top_p, seed, step, out, ke
     """One temperature / top-p sample per row of bf16 logits (HF `generate(do_sample=True)` step)."""
     check(_sample(p(logits), ld, rows, cols, temperature, top_p, seed & 0xFFFFFFFFFFFFFFFF, step & 0xFFFFFFFF, p(out), p(keep_mask),
                   stream()), "desta_sample_top_p_bf16")
+
+
+def attention_set_option(which: int, value: int) -> None:
+    lib.desta_attention_set_option.argtypes = [i32, i32]
+    check(lib.desta_attention_set_option(int(which), int(value)), "desta_attention_set_option")
 
 
 def attention_set_concurrent_bwd(on: bool) -> None:

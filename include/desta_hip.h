@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DESTA_ABI_VERSION 3
+#define DESTA_ABI_VERSION 4
 
 int desta_abi_version(void);
 /* sizeof of the descriptor structs as this library was compiled (0 = desta_gemm_desc, 1 = desta_attn_desc,
@@ -261,6 +261,11 @@ typedef struct desta_attn_desc {
     float scale;
     float dropout_p;                   /* attention-probability dropout (head_dim 64 only), same mask in fwd and bwd */
     uint64_t dropout_seed;
+    float* O_f32;                      /* optional (ABI 4): fp32 copy of O written by fwd, indexed with the o_* strides.  bwd then   */
+                                       /* takes delta = rowsum(dO * O) from the UNROUNDED output: with delta from the bf16-rounded O */
+                                       /* the error of delta is coherent over the keys of a row (dS_err = P * eps_q) and, where the   */
+                                       /* softmax is flat over 1500 encoder frames, puts 10-13 % error on the cross-attention query   */
+                                       /* weight gradient (eager attention in the reference sums P * dP itself: no such term).        */
 } desta_attn_desc;
 int desta_attention_fwd(const desta_attn_desc* d, void* stream);
 size_t desta_attention_bwd_workspace_floats(int batch, int n_q_heads, int seq_q);
@@ -268,6 +273,10 @@ int desta_attention_bwd(const desta_attn_desc* d, float* workspace, void* stream
 /* D = 128 backward: run the dQ kernel on an internal side stream next to dK/dV (fork after delta, join on `stream`);
  * 1 = on (default), 0 = everything on `stream`.  Results are identical either way. */
 int desta_attention_set_concurrent_bwd(int on);
+/* Process-wide kernel selection switches (A/B measurements; results agree to rounding either way):
+ *   which 0: forward for seq_q >= 128 without dropout on the 8-wave kernel (1, default) or the 4-wave kernel (0);
+ *   which 1: head_dim 64 non-causal 8-wave forward at two blocks per CU (1) or one (0, default). */
+int desta_attention_set_option(int which, int value);
 
 /* layer_prompts[j].expand(B,-1,-1) for all taps at once (modeling_desta25.py:589): prompts fp32
  * [taps][n], n = prompt_size*d -> rows [(taps*batch)][n] in fp32 and bf16; prompt_grad sums the

@@ -28,7 +28,8 @@ def test_interrupted_6_plus_6_equals_12_steps_through_main(tmp_path):
     assert a.global_step == 12 and a.total_steps == 12
     for step in (6, 12):
         d = tmp_path / "a" / f"checkpoint-{step}"
-        assert sorted(os.listdir(d)) == ["config.json", "model.safetensors", "optimizer.pt", "scheduler.pt", "trainer_state.json"]
+        assert sorted(os.listdir(d)) == ["config.json", "desta_hip_state.json", "model.safetensors", "optimizer.pt", "rng_state.pth", "scheduler.pt",
+                                         "trainer_state.json", "training_args.bin"]
     assert os.path.isdir(tmp_path / "a" / "checkpoint-initial")
     # optimizer.pt is the transformers.Adafactor wire format (two groups, factored moments)
     sd = torch.load(tmp_path / "a" / "checkpoint-6" / "optimizer.pt", weights_only=True)

@@ -281,6 +281,13 @@ ATTN_CASES = [
     (2, 4, 2, 160, 160, 128, True, [0, 37]),     # Llama GQA causal + left padding
     (2, 4, 1, 70, 70, 64, True, [5, 0]),         # tiny-LLM head dim 64
     (1, 8, 2, 300, 300, 128, True, None),
+    # the 8-wave forward (seq_q >= 128): GQA groups of 4 / 3 / 2 / 1 heads, ragged ends, left padding, seq_k > seq_q
+    (2, 8, 2, 640, 640, 128, True, [0, 100]),    # the LLM's shape per kv head: 4 heads x 64 rows per block
+    (1, 6, 2, 200, 260, 128, True, [3]),         # group of 3 -> one head per block; causal with 60 cached keys in front
+    (1, 4, 2, 257, 257, 128, True, None),        # group of 2 -> 2 heads x 128 rows; one row past a block boundary
+    (2, 2, 1, 257, 257, 64, True, [0, 5]),       # head dim 64 causal, 2 heads per block
+    (1, 2, 2, 1500, 1500, 64, False, None),      # Whisper: 1500 frames = 23.4 key tiles, 5.9 query blocks
+    (1, 2, 2, 130, 700, 128, False, None),       # non-causal head dim 128, ragged both ways
 ]
 
 
@@ -321,7 +328,7 @@ def test_attention_fwd_bwd(hip, case):
     hip.attention_fwd(d)
     got = o.float().cpu().view(B, Sq, Hq, D)
     assert rel_err(got, ref.detach()) < 8e-3, rel_err(got, ref.detach())
-    if pad is not None:
+    if pad is not None and Sq == Sk:                     # left-pad QUERY rows see no key at all (with cached keys in front, seq_k > seq_q, they do)
         for b, pl in enumerate(pad):
             assert float(got[b, :pl].abs().max()) == 0.0 if pl else True
 
@@ -369,6 +376,76 @@ def test_attention_forced_rescale(hip):
     d2 = hip.attn_desc(q0.cuda(), q0.cuda(), bf(v2).cuda(), o2, lse2, batch=1, hq=1, hkv=1, sq=S2, sk=S2, hd=D, scale=1.0)
     hip.attention_fwd(d2)
     torch.testing.assert_close(o2.float().cpu(), v2.mean(0, keepdim=True).expand(S2, D), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("spike", [3.0, 6.5, 40.0])
+def test_attention_deferred_rescale_threshold(hip, D, spike):
+    """The 8-wave forward moves its softmax reference only when a row's tile maximum exceeds it by more than 2^6 (guide T13).
+    Three regimes of ONE late key whose score for ONE query sits `spike` (natural-log units) above everything before it:
+    3.0 and 6.5 around ln 64 = 4.16 (deferred: probabilities up to e^3 against a stale reference / just rescaled), 40 (far
+    beyond).  A wrong deferred path is silent (no NaN), so the whole tensor is compared with an fp64 reference, and the
+    4-wave kernel (reference moves on every tile) must agree with the 8-wave one to rounding."""
+    S, H = 384, 2
+    g = torch.Generator().manual_seed(int(spike * 10) + D)
+    q = bf(torch.randn(S, H * D, generator=g))
+    k = bf(0.3 * torch.randn(S, H * D, generator=g))
+    v = bf(torch.randn(S, H * D, generator=g))
+    for h in range(H):                                   # key 300 (5th tile) for query 7 + h: score = spike + max of the earlier scores
+        qq = q[7 + h, h * D:(h + 1) * D].float()
+        base = float((q[7 + h, h * D:(h + 1) * D].float() @ k[:300, h * D:(h + 1) * D].float().T).max()) * D ** -0.5
+        k[300, h * D:(h + 1) * D] = (qq * ((spike + base) * D ** 0.5 / float(qq @ qq))).to(torch.bfloat16)
+    ref = _attn_ref(q.double().view(1, S, H, D), k.double().view(1, S, H, D), v.double().view(1, S, H, D), D ** -0.5, False, None)
+    outs = []
+    for eight in (1, 0):
+        hip.attention_set_option(0, eight)
+        try:
+            o = torch.zeros(S, H * D, dtype=torch.bfloat16, device="cuda")
+            lse = torch.zeros(1, H, S, device="cuda")
+            d = hip.attn_desc(q.cuda(), k.cuda(), v.cuda(), o, lse, batch=1, hq=H, hkv=H, sq=S, sk=S, hd=D, scale=D ** -0.5)
+            hip.attention_fwd(d)
+            outs.append((o.float().cpu(), lse.cpu().clone()))
+        finally:
+            hip.attention_set_option(0, 1)
+    for o, _ in outs:
+        assert rel_err(o.view(1, S, H, D), ref.float()) < 8e-3
+        assert float((o.view(1, S, H, D) - ref.float()).abs().max()) < 4e-2          # |V| ~ N(0,1): a mis-scaled row is off by O(1)
+    assert float((outs[0][0] - outs[1][0]).abs().max()) < 4e-2
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-4, atol=1e-4)                 # log-sum-exp independent of the reference used
+
+
+def test_attention_fp32_output_copy_feeds_delta(hip):
+    """desta_attn_desc.O_f32: forward also writes the unrounded output, backward takes delta = rowsum(dO * O) from it.  Checked:
+    bf16(O_f32) == O bit for bit, O_f32 is closer to the fp64 reference than O, and the backward with it is at least as
+    accurate on dQ as without (flat softmax over many keys with a common component in K: the regime of the Q-Former's
+    cross-attention, where the rounded-O delta error is coherent over the keys)."""
+    B, H, Sq, Sk, D = 2, 2, 64, 1500, 64
+    g = torch.Generator().manual_seed(5)
+    q = bf(0.2 * torch.randn(B * Sq, H * D, generator=g))
+    kv = bf(0.5 * torch.randn(B * Sk, 2 * H * D, generator=g) + 1.0)          # keys / values with a large common component
+    do = bf(torch.randn(B * Sq, H * D, generator=g))
+    qf_ = q.double().view(B, Sq, H, D).requires_grad_(True)
+    kf = kv[:, :H * D].double().reshape(B, Sk, H, D).requires_grad_(True)
+    vf = kv[:, H * D:].double().reshape(B, Sk, H, D).requires_grad_(True)
+    ref = _attn_ref(qf_, kf, vf, D ** -0.5, False, None)
+    ref.backward(do.double().view(B, Sq, H, D))
+    errs = {}
+    for use32 in (True, False):
+        o = torch.zeros(B * Sq, H * D, dtype=torch.bfloat16, device="cuda")
+        o32 = torch.zeros(B * Sq, H * D, dtype=torch.float32, device="cuda") if use32 else None
+        lse = torch.zeros(B, H, Sq, device="cuda")
+        d = hip.attn_desc(q.cuda(), kv.cuda(), kv.cuda(), o, lse, batch=B, hq=H, hkv=H, sq=Sq, sk=Sk, hd=D, scale=D ** -0.5,
+                          q_off=0, k_off=0, v_off=H * D, o_f32=o32)
+        hip.attention_fwd(d)
+        if use32:
+            assert torch.equal(o32.to(torch.bfloat16), o)
+            assert rel_err(o32.cpu().view(B, Sq, H, D), ref.detach().float()) < rel_err(o.float().cpu().view(B, Sq, H, D), ref.detach().float())
+        dq = torch.zeros(B * Sq, H * D, dtype=torch.bfloat16, device="cuda")
+        dkv = torch.zeros(B * Sk, 2 * H * D, dtype=torch.bfloat16, device="cuda")
+        hip.attention_bwd(d, do.cuda(), dq, dkv, dkv, dk_off=0, dv_off=H * D)
+        errs[use32] = rel_err(dq.float().cpu().view(B, Sq, H, D), qf_.grad.float())
+    print("dQ rel err with fp32 O:", errs[True], " with bf16 O:", errs[False])
+    assert errs[True] < 1.5e-2 and errs[True] <= errs[False] * 1.05
 
 
 def test_attention_desc_keeps_tensors_alive_and_clamps_kv_start(hip):

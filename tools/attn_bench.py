@@ -51,9 +51,27 @@ for name, (B, Hq, Hkv, S, D, causal) in {"llm S=640 D=128 causal GQA": (8, 32, 8
     d = hip.attn_desc(qkv, qkv, qkv, o, lse, batch=B, hq=Hq, hkv=Hkv, sq=S, sk=S, hd=D, scale=D ** -0.5, causal=causal,
                       kv_start=None, q_off=0, k_off=wq, v_off=wq + wkv)
     f = t_us(lambda: hip.attention_fwd(d))
+    hip.attention_set_option(0, 0)
+    f4 = t_us(lambda: hip.attention_fwd(d))
+    hip.attention_set_option(0, 1)
+    extra = f"  [4-wave fwd {f4:6.1f} us"
+    if D == 64:
+        hip.attention_set_option(1, 1)
+        extra += f"; 8-wave at 2 blocks/CU {t_us(lambda: hip.attention_fwd(d)):6.1f} us"
+        hip.attention_set_option(1, 0)
+    if causal:
+        # the training layout of the LLM: position-major token grid (row = s * B + b): row stride B * width, batch stride width
+        d2 = hip.attn_desc(qkv, qkv, qkv, o, lse, batch=B, hq=Hq, hkv=Hkv, sq=S, sk=S, hd=D, scale=D ** -0.5, causal=causal,
+                           kv_start=None, q_off=0, k_off=wq, v_off=wq + wkv, q_rs=B * (wq + 2 * wkv), k_rs=B * (wq + 2 * wkv),
+                           v_rs=B * (wq + 2 * wkv), o_rs=B * wq, q_bs=wq + 2 * wkv, k_bs=wq + 2 * wkv, v_bs=wq + 2 * wkv, o_bs=wq)
+        extra += f"; position-major layout: 8-wave {t_us(lambda: hip.attention_fwd(d2)):6.1f} us"
+        hip.attention_set_option(0, 0)
+        extra += f", 4-wave {t_us(lambda: hip.attention_fwd(d2)):6.1f} us"
+        hip.attention_set_option(0, 1)
+    extra += "]"
     bw = t_us(lambda: hip.attention_bwd(d, do, dqkv, dqkv, dqkv, dq_off=0, dk_off=wq, dv_off=wq + wkv))
     hip.attention_set_concurrent_bwd(False)
     bw_serial = t_us(lambda: hip.attention_bwd(d, do, dqkv, dqkv, dqkv, dq_off=0, dk_off=wq, dv_off=wq + wkv))
     hip.attention_set_concurrent_bwd(True)
     fl = 4.0 * B * Hq * S * S * D * (0.5 if causal else 1.0)
-    print(f"{name:30s} fwd {f:7.1f} us ({fl / f / 1e6:6.0f} TF/s)   bwd {bw:7.1f} us ({2.5 * fl / bw / 1e6:6.0f} TF/s; dQ after dK/dV on one stream: {bw_serial:7.1f} us)", flush=True)
+    print(f"{name:30s} fwd {f:7.1f} us ({fl / f / 1e6:6.0f} TF/s)   bwd {bw:7.1f} us ({2.5 * fl / bw / 1e6:6.0f} TF/s; dQ after dK/dV on one stream: {bw_serial:7.1f} us){extra}", flush=True)
