@@ -352,42 +352,65 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (D == 64 ? ATTN_FWD64_WAVES : 2)
 // ------------------------------------------------------------------------------------------ forward, 8 waves per block
 // The forward for long query ranges (LLM prefill / training: D = 128 causal GQA; Whisper: D = 64, 1500 x 1500).  Same
 // orientation as above (key on the accumulator rows, query on the lane, P^T straight from the S^T accumulator into the P.V
-// MFMAs), restructured around what the four-wave kernel spends its time on (rocprofv3: mfma-busy 0.18-0.29, waves parked
-// at barriers / waitcnts most of a tile):
+// MFMAs), restructured around what the four-wave kernel spends its time on (rocprofv3: mfma-busy 0.18-0.29; per 64-key tile and
+// wave 32 MFMAs beside ~330 VALU instructions, and the two waves of a SIMD doing the same phase at the same time):
 //   * EIGHT waves share one K / V tile: a block is 256 query rows of one head or, under GQA, HPB heads x 256 / HPB rows of one
-//     kv head (the heads of a group read the same K / V): half / a quarter of the staging instructions, LDS writes and global
-//     loads per unit of MFMA work, and under the causal mask 64- or 128-row blocks waste less of the diagonal tiles;
+//     kv head (the heads of a group read the same K / V): half / a quarter of the staging work per unit of MFMA work, and
+//     under the causal mask 64- or 128-row blocks waste less of the diagonal tiles;
 //   * LDS double buffer, ONE raw s_barrier per tile (no vmcnt drain): tile t+1 is written to the other buffer in the middle of
-//     tile t (between the softmax and the P.V MFMAs) from registers loaded one tile earlier, and the global loads of tile
-//     t+2 are issued right behind it: every load has a whole tile of compute to land;
+//     tile t from registers loaded one tile earlier, and the global loads of tile t+2 are issued right behind it: every load
+//     has a whole tile of compute to land;
+//   * (STAGGER = true, off by default: measured) waves 4-7 — the SIMD partners of waves 0-3 — half a tile behind, on a
+//     three-slot ring: between two barriers waves 0-3 do [S, softmax, P.V] of tile t, waves 4-7 [P.V of t-1, S, softmax of t].
+//     Equal on the LLM shape (55.9 vs 55.3 us), SLOWER on the Whisper shape (154 vs 120 us): the partners de-synchronise by
+//     themselves once one of them is ahead in its MFMA chain, and the forced pairing is worse than the one that forms;
 //   * deferred rescale (guide T13): the running reference m only moves when some row's tile maximum exceeds it by more than
 //     2^ATTN_DEFER_LOG2: on all other tiles there is no alpha, no O rescale, no l rescale (P <= 2^ATTN_DEFER_LOG2: relative bf16
 //     rounding is unchanged, sums stay far inside fp32 range);
-//   * the row sum stays a per-lane partial (the two half-waves of a query column are combined once, in the epilogue); the row
-//     maximum crosses the half-waves with one v_permlane32_swap instead of a ds_bpermute round trip;
+//   * softmax VALU diet: row maximum by v_max3 written as asm (fmaxf on MFMA results makes hipcc canonicalise every operand
+//     with an extra v_max: 51 instead of 16 instructions), one v_permlane32_swap to cross the half-waves, the row sum kept as a
+//     per-lane partial (the halves are combined once, in the epilogue); LDS read addresses and the per-thread staging offsets
+//     are computed once (one add of the slot base per read; global loads use a scalar tile base + 32-bit lane offset);
 //   * O is stored as 16-byte pieces after a permlane32 exchange of the packed halves (guide T21).
 // Work order: XCD x walks the (batch, kv head) groups x, x + 8, ...; causal launches the heaviest q-blocks of all its groups
 // first (the K / V of an XCD's ten groups fit its L2 together), non-causal keeps the q-blocks of a group back to back.
 #ifndef ATTN_DEFER_LOG2
 #define ATTN_DEFER_LOG2 6.0f
 #endif
-// MINW = 4 (D = 64 only): two 8-wave blocks per CU (<= 128 registers; costs five spilled registers, one reload per tile)
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float vmax2(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ float swap_halves_max(float x) {
     const unsigned u = __builtin_bit_cast(unsigned, x);
     const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);     // r[0] = [lo, lo], r[1] = [hi, hi]
-    return fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+    return vmax2(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
 }
 __device__ __forceinline__ float swap_halves_sum(float x) {
     const unsigned u = __builtin_bit_cast(unsigned, x);
     const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
     return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
 }
+__device__ __forceinline__ bf16x8 tr_pair(const char* lo, const char* hi) {
+    const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)lo);
+    const bf16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)hi);
+    return __builtin_shufflevector(a, c, 0, 1, 2, 3, 4, 5, 6, 7);            // one register tuple: no element-wise moves
+}
 
-template <int D, bool CAUSAL, int HPB, int MINW = 2>
+// MINW = 4 (D = 64 only): two 8-wave blocks per CU (<= 128 registers)
+template <int D, bool CAUSAL, int HPB, int MINW = 2, bool STAGGER = false>
 __global__ __launch_bounds__(512, MINW) void attn_fwd8_k(AttnArgs p) {
     constexpr int NT = 512, RB = 256 / HPB, WPH = RB / 32;         // query rows of a block (per head), waves per head
     constexpr int TILE = 64 * D * 2;                               // bytes of one 64-key K (or V) image
-    __shared__ __attribute__((aligned(16))) char lds[4 * TILE];    // [buffer][K, V]
+    constexpr int SLOT = 2 * TILE, NSLOT = STAGGER ? 3 : 2;        // lockstep: double buffer; staggered: tile t-1's V is still read while t+1 is written
+    constexpr int NCH = 64 * (D / 8) / NT;                         // 16-byte chunks per thread, tile and tensor (2 / 1)
+    __shared__ __attribute__((aligned(16))) char lds[NSLOT * SLOT];   // ring of [K image, V image]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h2 = lane >> 5;
     const int G = p.Hq / p.Hkv, nq = (p.Sq + RB - 1) / RB, hgroups = G / HPB, ngrp = p.B * p.Hkv;
     int g, qblk, hg;
@@ -424,26 +447,81 @@ __global__ __launch_bounds__(512, MINW) void attn_fwd8_k(AttnArgs p) {
     const int q_abs = qcol + coff;
     const int wave_kmax = CAUSAL ? min(q0 + 31, p.Sq - 1) + coff : p.Sk - 1;
 
-    const bf16_t* kbase = p.K + (long)b * p.k_bs + (long)hk * D;
-    const bf16_t* vbase = p.V + (long)b * p.v_bs + (long)hk * D;
+    const char* kbase = (const char*)(p.K + (long)b * p.k_bs + (long)hk * D);
+    const char* vbase = (const char*)(p.V + (long)b * p.v_bs + (long)hk * D);
+    // staging: this thread's NCH chunks of a tile: (row r, chunk c) -> byte offset from the tile's first row (32-bit; the tile
+    // base is wave-uniform: scalar base + vector offset loads) and its place in the swizzled LDS image
+    int srow[NCH], sdst[NCH];
+    unsigned ksrc[NCH], vsrc[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int id = i * NT + threadIdx.x, r = id / (D / 8), c = id % (D / 8);
+        srow[i] = r;
+        sdst[i] = img_off<D>(r, c);
+        ksrc[i] = (unsigned)(r * (int)p.k_rs + c * 8) * 2u;
+        vsrc[i] = (unsigned)(r * (int)p.v_rs + c * 8) * 2u;
+    }
+    // ONE first-class vector value per tensor (an array that is conditionally re-loaded inside the loop is kept in memory by
+    // hipcc — promoted to LDS here: every load was waited for and parked in LDS right behind its issue)
+    typedef typename stage_vec<NCH>::type stage8_t;
+    stage8_t kr = {}, vr = {};
+    auto load_tile = [&](const int kt) __attribute__((always_inline)) {
+        const char* kb_ = kbase + (long)kt * 64 * p.k_rs * 2;
+        const char* vb_ = vbase + (long)kt * 64 * p.v_rs * 2;
+        const bool ragged = kt * 64 + 64 > p.Sk;                    // last tile (or a block without tiles): clamp the rows
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            unsigned ko = ksrc[i], vo = vsrc[i];
+            if (ragged) {
+                const int rc = max(min(srow[i], p.Sk - 1 - kt * 64), -kt * 64), c = (i * NT + (int)threadIdx.x) % (D / 8);
+                ko = (unsigned)(rc * (int)p.k_rs + c * 8) * 2u;     // (rc < 0 only when the block has no tile: row 0 of the tensor)
+                vo = (unsigned)(rc * (int)p.v_rs + c * 8) * 2u;
+            }
+            const uint4 a = *(const uint4*)(kb_ + (long)(int)ko), c4 = *(const uint4*)(vb_ + (long)(int)vo);
+            kr[4 * i + 0] = a.x; kr[4 * i + 1] = a.y; kr[4 * i + 2] = a.z; kr[4 * i + 3] = a.w;
+            vr[4 * i + 0] = c4.x; vr[4 * i + 1] = c4.y; vr[4 * i + 2] = c4.z; vr[4 * i + 3] = c4.w;
+        }
+    };
+    auto store_tile = [&](char* slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            *(uint4*)(slot + sdst[i]) = make_uint4(kr[4 * i + 0], kr[4 * i + 1], kr[4 * i + 2], kr[4 * i + 3]);
+            *(uint4*)(slot + TILE + sdst[i]) = make_uint4(vr[4 * i + 0], vr[4 * i + 1], vr[4 * i + 2], vr[4 * i + 3]);
+        }
+    };
 
     // prologue, straight-line on purpose: first K / V tile, then the Q fragments; loads return in order, so once the Q
     // fragments are in (the empty asm makes the compiler wait for them HERE) nothing of the prologue is still in flight and
     // the loop's vmcnt bookkeeping covers only the K / V stream (with the Q loads pending at the loop head hipcc makes every
     // tile's S MFMAs wait for vmcnt(3..0), i.e. for the loads of tile t+2 issued half a tile earlier).  Rows are clamped:
     // the loads are legal even when the block has no tile at all.
-    stage_t<D, 64, NT> kr = tile_load<D, 64, NT>(kbase, p.k_rs, t_lo * 64, p.Sk - 1);
-    stage_t<D, 64, NT> vr = tile_load<D, 64, NT>(vbase, p.v_rs, t_lo * 64, p.Sk - 1);
+    load_tile(t_lo);
     const bf16_t* qptr = p.Q + (long)b * p.q_bs + (long)min(qcol, p.Sq - 1) * p.q_rs + (long)h * D;
     bf16x8 qf[D / 16];
 #pragma unroll
     for (int ds = 0; ds < D / 16; ++ds) qf[ds] = *(const bf16x8*)(qptr + 16 * ds + 8 * h2);
 #pragma unroll
     for (int ds = 0; ds < D / 16; ++ds) asm volatile("" :: "v"(qf[ds]));
-    tile_store<D, 64, NT>(lds, kr);
-    tile_store<D, 64, NT>(lds + TILE, vr);
-    kr = tile_load<D, 64, NT>(kbase, p.k_rs, (t_lo + 1) * 64, p.Sk - 1);
-    vr = tile_load<D, 64, NT>(vbase, p.v_rs, (t_lo + 1) * 64, p.Sk - 1);
+    store_tile(lds);
+    load_tile(t_lo + 1);
+
+    // LDS read addresses inside a slot (lane constants; "+v": keep them in registers instead of re-deriving them per tile)
+    int kofs[D / 16], vofs[D / 32][2];
+#pragma unroll
+    for (int ds = 0; ds < D / 16; ++ds) {
+        kofs[ds] = img_off<D>(lane & 31, 2 * ds + h2);             // K rows 0..31 (rows 32..63: + 32 rows, same swizzle)
+        asm volatile("" : "+v"(kofs[ds]));
+    }
+    {
+        const int i16 = lane & 15, gq = (lane >> 4) & 1, qq = i16 >> 2, pp = i16 & 3;
+#pragma unroll
+        for (int i = 0; i < D / 32; ++i) {
+            const int c = i * 32 + 16 * gq + 4 * pp;
+            vofs[i][0] = TILE + img_off<D>(4 * h2 + qq, c >> 3) + ((c & 4) << 1);          // V rows r0 + 4 h2 + q (r0 = multiples of 16: same swizzle)
+            vofs[i][1] = TILE + img_off<D>(4 * h2 + qq + 8, c >> 3) + ((c & 4) << 1);
+            asm volatile("" : "+v"(vofs[i][0]), "+v"(vofs[i][1]));
+        }
+    }
 
     f32x16 oacc[D / 32];
 #pragma unroll
@@ -451,91 +529,122 @@ __global__ __launch_bounds__(512, MINW) void attn_fwd8_k(AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
     float m = -INFINITY, l = 0.f;                                   // m: reference in scaled log2 units (may lag the true maximum by <= 2^DEFER); l: this lane's partial sum
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    f32x16 st[2];                                                   // S^T of the current tile, then its probabilities (waves 4-7 carry them across the barrier)
+#define ATTN_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")   /* LDS traffic of this wave is done; global loads stay in flight */
+    ATTN_BARRIER();
 
-    auto tile = [&](const int kt, const int buf) __attribute__((always_inline)) {
-        const char* kimg = lds + buf * 2 * TILE;
-        const char* vimg = kimg + TILE;
-        const bool act = wave_on && kt * 64 <= wave_kmax;           // scalar
-        f32x16 st[2];
-        if (act) {
+    // S^T = K Q^T of tile kt (slot base `sb`), boundary masks, deferred-rescale online softmax: st := probabilities
+    auto scores = [&](const int kt, const int sb) __attribute__((always_inline)) {
+        if (!(wave_on && kt * 64 <= wave_kmax)) return;             // scalar
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
-            bf16x8 ka[D / 16], kbf[D / 16];
+            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+        bf16x8 ka[D / 16], kbf[D / 16];
+        int kad[D / 16];                                            // ONE add of the slot base per address register; the rest are immediates
 #pragma unroll
-            for (int ds = 0; ds < D / 16; ++ds) ka[ds] = frag_rows<D>(kimg, 0, ds, lane);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int ds = 0; ds < D / 16; ++ds) { kad[ds] = kofs[ds] + sb; asm volatile("" : "+v"(kad[ds])); }
 #pragma unroll
-            for (int ds = 0; ds < D / 16; ++ds) {
-                st[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ds], qf[ds], st[0], 0, 0, 0);
-                kbf[ds] = frag_rows<D>(kimg, 32, ds, lane);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+        for (int ds = 0; ds < D / 16; ++ds) ka[ds] = *(const bf16x8*)(lds + kad[ds]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ds = 0; ds < D / 16; ++ds) st[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kbf[ds], qf[ds], st[1], 0, 0, 0);
-            const bool need_mask = (kt * 64 + 63 >= p.Sk) || (kt * 64 < kv_lo) || (CAUSAL && kt * 64 + 63 > q0 + coff);
-            if (need_mask) {
-                asm volatile("; boundary tile" ::: "memory");
+        for (int ds = 0; ds < D / 16; ++ds) {
+            st[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ds], qf[ds], st[0], 0, 0, 0);
+            kbf[ds] = *(const bf16x8*)(lds + kad[ds] + 32 * D * 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = kt * 64 + kb * 32 + acc_row(r, lane);
-                        const bool ok = key < p.Sk && key >= kv_lo && (!CAUSAL || key <= q_abs);
-                        st[kb][r] = ok ? st[kb][r] : -INFINITY;
-                    }
-            }
-            float tmax = fmaxf(st[0][0], st[1][0]);
-#pragma unroll
-            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(st[0][r], st[1][r]));     // v_max3_f32
-            tmax = swap_halves_max(tmax) * p.scale_log2;                                      // scale > 0: max commutes
-            if (!__all(!(tmax > m + ATTN_DEFER_LOG2))) {                                      // some row outgrew its reference: move every row's
-                const float mnew = fmaxf(m, tmax);
-                const float alpha = __builtin_amdgcn_exp2f(m - (mnew == -INFINITY ? 0.f : mnew));     // m = -inf: 0 (O = l = 0 anyway)
-                l *= alpha;
-#pragma unroll
-                for (int i = 0; i < D / 32; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-                m = mnew;
-            }
-            const float nmu = (m == -INFINITY) ? 0.f : -m;
+        for (int ds = 0; ds < D / 16; ++ds) st[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kbf[ds], qf[ds], st[1], 0, 0, 0);
+        const bool need_mask = (kt * 64 + 63 >= p.Sk) || (kt * 64 < kv_lo) || (CAUSAL && kt * 64 + 63 > q0 + coff);
+        if (need_mask) {
+            asm volatile("; boundary tile" ::: "memory");
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    st[kb][r] = __builtin_amdgcn_exp2f(fmaf(st[kb][r], p.scale_log2, nmu));
-                    l += st[kb][r];
+                    const int key = kt * 64 + kb * 32 + acc_row(r, lane);
+                    const bool ok = key < p.Sk && key >= kv_lo && (!CAUSAL || key <= q_abs);
+                    st[kb][r] = ok ? st[kb][r] : -INFINITY;
                 }
         }
-        // tile kt+1: registers -> the other buffer (its last readers passed the barrier that closed tile kt-1); then the loads of kt+2
-        if (kt + 1 < t_hi) {
-            tile_store<D, 64, NT>(lds + (buf ^ 1) * 2 * TILE, kr);
-            tile_store<D, 64, NT>(lds + (buf ^ 1) * 2 * TILE + TILE, vr);
-            if (kt + 2 < t_hi) {
-                kr = tile_load<D, 64, NT>(kbase, p.k_rs, (kt + 2) * 64, p.Sk - 1);
-                vr = tile_load<D, 64, NT>(vbase, p.v_rs, (kt + 2) * 64, p.Sk - 1);
+        float tmax = vmax3(st[0][0], st[1][0], st[0][1]);
+        tmax = vmax3(tmax, st[1][1], st[0][2]);
+#pragma unroll
+        for (int r = 2; r < 15; ++r) tmax = vmax3(tmax, st[1][r], st[0][r + 1]);
+        tmax = vmax2(tmax, st[1][15]);
+        tmax = swap_halves_max(tmax) * p.scale_log2;                                          // scale > 0: max commutes
+        if (!__all(!(tmax > m + ATTN_DEFER_LOG2))) {                                          // some row outgrew its reference: move every row's
+            const float mnew = vmax2(m, tmax);
+            const float alpha = __builtin_amdgcn_exp2f(m - (mnew == -INFINITY ? 0.f : mnew)); // m = -inf: 0 (O = l = 0 anyway)
+            l *= alpha;
+#pragma unroll
+            for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+            m = mnew;
+        }
+        const float nmu = (m == -INFINITY) ? 0.f : -m;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                st[kb][r] = __builtin_amdgcn_exp2f(fmaf(st[kb][r], p.scale_log2, nmu));
+                l += st[kb][r];
             }
-        }
-        if (act) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const bf16x8 pb = acc_frag(st[kb], s);
-#pragma unroll
-                    for (int i = 0; i < D / 32; ++i)
-                        oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(vimg, kb * 32 + 16 * s, i * 32, lane), pb, oacc[i], 0, 0, 0);
-                }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // this tile's reads and the next tile's writes are done; global loads stay in flight
     };
-    for (int kt = t_lo; kt < t_hi; kt += 2) {
-        tile(kt, 0);
-        if (kt + 1 < t_hi) tile(kt + 1, 1);
+    // O^T += V^T P^T of tile kt
+    auto pv = [&](const int kt, const int sb) __attribute__((always_inline)) {
+        if (!(wave_on && kt * 64 <= wave_kmax)) return;
+        int vad[D / 32][2];
+#pragma unroll
+        for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { vad[i][j] = vofs[i][j] + sb; asm volatile("" : "+v"(vad[i][j])); }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 pb = acc_frag(st[kb], s);
+#pragma unroll
+                for (int i = 0; i < D / 32; ++i)
+                    oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        tr_pair(lds + vad[i][0] + (kb * 32 + 16 * s) * D * 2, lds + vad[i][1] + (kb * 32 + 16 * s) * D * 2), pb, oacc[i], 0, 0, 0);
+            }
+    };
+    // tile kt+1: registers -> its ring slot (last read two barriers ago); then the global loads of tile kt+2
+    auto stage = [&](const int kt, const int sb_next) __attribute__((always_inline)) {
+        if (kt + 1 < t_hi) {
+            store_tile(lds + sb_next);
+            if (kt + 2 < t_hi) load_tile(kt + 2);
+        }
+    };
+    auto next_slot = [](int sb) { return sb == (NSLOT - 1) * SLOT ? 0 : sb + SLOT; };
+    int sb = 0;                                                     // slot of tile kt (scalar)
+    if (!STAGGER || wave < 4) {
+        for (int kt = t_lo; kt < t_hi; ++kt) {
+            const int sn = next_slot(sb);
+            scores(kt, sb);
+            stage(kt, sn);
+            pv(kt, sb);
+            ATTN_BARRIER();
+            sb = sn;
+        }
+    } else if (t_lo < t_hi) {
+        // half a tile behind: the same number of barriers as waves 0-3 (one per tile), P.V of tile kt after the barrier that ends it
+        scores(t_lo, sb);
+        stage(t_lo, next_slot(sb));
+        ATTN_BARRIER();
+        for (int kt = t_lo; kt + 1 < t_hi; ++kt) {
+            const int sn = next_slot(sb);
+            pv(kt, sb);
+            stage(kt + 1, next_slot(sn));
+            scores(kt + 1, sn);
+            ATTN_BARRIER();
+            sb = sn;
+        }
+        pv(t_hi - 1, sb);
     }
+#undef ATTN_BARRIER
 
     if (wave_on && qcol < p.Sq) {
         const float lt = swap_halves_sum(l);
@@ -1019,11 +1128,13 @@ extern "C" int desta_attention_fwd(const desta_attn_desc* d, void* stream) {
         hipStream_t st = (hipStream_t)stream;
         if (d->head_dim == 128) {
             if (!a.causal) hipLaunchKernelGGL((attn_fwd8_k<128, false, 1>), g8, dim3(512), 0, st, a);
+            else if (hpb == 4 && g_attn_opt[2]) hipLaunchKernelGGL((attn_fwd8_k<128, true, 4, 2, true>), g8, dim3(512), 0, st, a);
             else if (hpb == 4) hipLaunchKernelGGL((attn_fwd8_k<128, true, 4>), g8, dim3(512), 0, st, a);
             else if (hpb == 2) hipLaunchKernelGGL((attn_fwd8_k<128, true, 2>), g8, dim3(512), 0, st, a);
             else hipLaunchKernelGGL((attn_fwd8_k<128, true, 1>), g8, dim3(512), 0, st, a);
         } else {
-            if (!a.causal && g_attn_opt[1]) hipLaunchKernelGGL((attn_fwd8_k<64, false, 1, 4>), g8, dim3(512), 0, st, a);
+            if (!a.causal && g_attn_opt[1]) hipLaunchKernelGGL((attn_fwd8_k<64, false, 1, 4, false>), g8, dim3(512), 0, st, a);
+            else if (!a.causal && g_attn_opt[2]) hipLaunchKernelGGL((attn_fwd8_k<64, false, 1, 2, true>), g8, dim3(512), 0, st, a);
             else if (!a.causal) hipLaunchKernelGGL((attn_fwd8_k<64, false, 1>), g8, dim3(512), 0, st, a);
             else if (hpb == 2) hipLaunchKernelGGL((attn_fwd8_k<64, true, 2>), g8, dim3(512), 0, st, a);
             else hipLaunchKernelGGL((attn_fwd8_k<64, true, 1>), g8, dim3(512), 0, st, a);

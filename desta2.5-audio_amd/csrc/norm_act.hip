@@ -724,7 +724,7 @@ extern "C" int desta_layernorm_fwd(const void* x, int x_f32, const float* gamma,
 
 extern "C" size_t desta_layernorm_bwd_workspace_floats(int rows, int cols) {
     int nb = (rows + RPB - 1) / RPB;
-    if (nb > 128) nb = 128;
+    if (nb > 512) nb = 512;                                    // two blocks per CU (128 left half the chip idle: 19.5 us per call, 0.15 of the HBM rate)
     return (size_t)nb * 2 * cols;
 }
 
@@ -735,7 +735,7 @@ extern "C" int desta_layernorm_bwd(const void* dy, int dy_f32, const void* x, in
     DESTA_CHECK_ARG(rows > 0 && cols % 8 == 0 && cols <= 2048, "layernorm_bwd: cols=%d must be a multiple of 8, <= 2048", cols);
     DESTA_CHECK_ARG(!dgamma || (dbeta && workspace), "layernorm_bwd: dgamma needs dbeta and workspace");
     int nb = (rows + RPB - 1) / RPB;
-    if (nb > 128) nb = 128;
+    if (nb > 512) nb = 512;                                    // two blocks per CU (128 left half the chip idle: 19.5 us per call, 0.15 of the HBM rate)
     float* part = dgamma ? workspace : nullptr;
     if (cols <= 512) hipLaunchKernelGGL((layernorm_bwd_k<1>), dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, dy_f32, x, x_f32, gamma, stats, rows, cols, dx_f32, (bf16_t*)dx_bf16, part);
     else if (cols <= 1024) hipLaunchKernelGGL((layernorm_bwd_k<2>), dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, dy_f32, x, x_f32, gamma, stats, rows, cols, dx_f32, (bf16_t*)dx_bf16, part);

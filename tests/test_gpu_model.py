@@ -271,7 +271,10 @@ def test_hf_checkpoint_wire_format_and_resume(tmp_path):
     lb = t_b.train(batches[:2])
     ck = str(tmp_path / "checkpoint-2")
     t_b.save_checkpoint(ck)
-    assert sorted(os.listdir(ck)) == ["config.json", "model.safetensors", "optimizer.pt", "scheduler.pt", "trainer_state.json"]
+    assert sorted(os.listdir(ck)) == ["config.json", "desta_hip_state.json", "model.safetensors", "optimizer.pt", "rng_state.pth", "scheduler.pt",
+                                      "trainer_state.json", "training_args.bin"]
+    from transformers.trainer_callback import TrainerState
+    assert TrainerState.load_from_json(os.path.join(ck, "trainer_state.json")).global_step == 2       # HF reads what this trainer wrote
     m_c, t_c = fresh(0.1)
     t_c.resume_from_checkpoint(ck)
     assert t_c.global_step == 2 and json.load(open(os.path.join(ck, "trainer_state.json")))["global_step"] == 2

@@ -55,6 +55,9 @@ for name, (B, Hq, Hkv, S, D, causal) in {"llm S=640 D=128 causal GQA": (8, 32, 8
     f4 = t_us(lambda: hip.attention_fwd(d))
     hip.attention_set_option(0, 1)
     extra = f"  [4-wave fwd {f4:6.1f} us"
+    hip.attention_set_option(2, 1)
+    extra += f"; 8-wave with the half-tile stagger {t_us(lambda: hip.attention_fwd(d)):6.1f} us"
+    hip.attention_set_option(2, 0)
     if D == 64:
         hip.attention_set_option(1, 1)
         extra += f"; 8-wave at 2 blocks/CU {t_us(lambda: hip.attention_fwd(d)):6.1f} us"
