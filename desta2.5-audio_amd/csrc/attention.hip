@@ -856,6 +856,220 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? ATTN_DQ_BLOCKS : 2) void attn_bw
     }
 }
 
+// ------------------------------------------------------------------------------------------ backward: dQ, 8 waves per block
+// attn_fwd8_k's geometry for the dQ pass of long query ranges (seq_q >= 128, no dropout): 8 waves share each K / V tile (HPB
+// heads of a GQA group x 256 / HPB query rows), LDS double buffer with ONE raw barrier per tile, loads two tiles ahead in
+// registers, heaviest q-blocks first per XCD.  Per 32-key half of a tile and wave: S^T = K Q^T and dP^T = V dO^T (16 MFMAs,
+// K / V rows by ds_read_b128), dS^T = P (dP - delta) scale in registers, dQ^T += K^T dS^T (8 MFMAs, K^T by ds_read_tr from
+// the same image).  delta = rowsum(dO * O) is computed HERE, in the prologue, from the fragments the wave loads anyway (each
+// query row belongs to exactly one wave), and written to `delta_out` for the dK / dV kernel that follows on the stream: the
+// separate delta launch (0.53 ms per step) is gone.
+template <int D, bool CAUSAL, int HPB>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dq8_k(AttnArgs p, float* __restrict__ delta_out) {
+    constexpr int NT = 512, RB = 256 / HPB, WPH = RB / 32;
+    constexpr int TILE = 64 * D * 2, SLOT = 2 * TILE;
+    constexpr int NCH = 64 * (D / 8) / NT;
+    __shared__ __attribute__((aligned(16))) char lds[2 * SLOT];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h2 = lane >> 5;
+    const int G = p.Hq / p.Hkv, nq = (p.Sq + RB - 1) / RB, hgroups = G / HPB, ngrp = p.B * p.Hkv;
+    int g, qblk, hg;
+    {
+        const int id = blockIdx.x, per = nq * hgroups;
+        if ((ngrp & 7) == 0) {
+            const int xcd = id & 7, slot = id >> 3, gpx = ngrp >> 3;
+            if (CAUSAL) {
+                const int r = slot % (hgroups * gpx);
+                qblk = nq - 1 - slot / (hgroups * gpx); hg = r / gpx; g = (r % gpx) * 8 + xcd;
+            } else {
+                const int r = slot % per;
+                g = (slot / per) * 8 + xcd; hg = r / nq; qblk = r % nq;
+            }
+        } else if (CAUSAL) {
+            const int r = id % (hgroups * ngrp);
+            qblk = nq - 1 - id / (hgroups * ngrp); hg = r / ngrp; g = r % ngrp;
+        } else {
+            const int r = id % per;
+            g = id / per; hg = r / nq; qblk = r % nq;
+        }
+    }
+    const int b = g / p.Hkv, hk = g % p.Hkv;
+    const int h = hk * G + hg * HPB + wave / WPH;
+    const int qb0 = qblk * RB, q0 = qb0 + (wave % WPH) * 32;
+    const int qcol = q0 + (lane & 31), qc = min(qcol, p.Sq - 1);
+    const bool wave_on = q0 < p.Sq;
+
+    const int coff = p.Sk - p.Sq;
+    const int kv_lo = p.kv_start ? max(0, min(p.kv_start[b], p.Sk)) : 0;
+    int kv_hi = p.Sk;
+    if (CAUSAL) kv_hi = min(p.Sk, min(qb0 + RB - 1, p.Sq - 1) + coff + 1);
+    const int t_lo = kv_lo / 64, t_hi = (kv_hi + 63) / 64;
+    const int q_abs = qcol + coff;
+    const int wave_kmax = CAUSAL ? min(q0 + 31, p.Sq - 1) + coff : p.Sk - 1;
+
+    const char* kbase = (const char*)(p.K + (long)b * p.k_bs + (long)hk * D);
+    const char* vbase = (const char*)(p.V + (long)b * p.v_bs + (long)hk * D);
+    int srow[NCH], sdst[NCH];
+    unsigned ksrc[NCH], vsrc[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int id = i * NT + threadIdx.x, r = id / (D / 8), c = id % (D / 8);
+        srow[i] = r;
+        sdst[i] = img_off<D>(r, c);
+        ksrc[i] = (unsigned)(r * (int)p.k_rs + c * 8) * 2u;
+        vsrc[i] = (unsigned)(r * (int)p.v_rs + c * 8) * 2u;
+    }
+    typedef typename stage_vec<NCH>::type stage8_t;
+    stage8_t kr = {}, vr = {};
+    auto load_tile = [&](const int kt) __attribute__((always_inline)) {
+        const char* kb_ = kbase + (long)kt * 64 * p.k_rs * 2;
+        const char* vb_ = vbase + (long)kt * 64 * p.v_rs * 2;
+        const bool ragged = kt * 64 + 64 > p.Sk;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            unsigned ko = ksrc[i], vo = vsrc[i];
+            if (ragged) {
+                const int rc = max(min(srow[i], p.Sk - 1 - kt * 64), -kt * 64), c = (i * NT + (int)threadIdx.x) % (D / 8);
+                ko = (unsigned)(rc * (int)p.k_rs + c * 8) * 2u;
+                vo = (unsigned)(rc * (int)p.v_rs + c * 8) * 2u;
+            }
+            const uint4 a = *(const uint4*)(kb_ + (long)(int)ko), c4 = *(const uint4*)(vb_ + (long)(int)vo);
+            kr[4 * i + 0] = a.x; kr[4 * i + 1] = a.y; kr[4 * i + 2] = a.z; kr[4 * i + 3] = a.w;
+            vr[4 * i + 0] = c4.x; vr[4 * i + 1] = c4.y; vr[4 * i + 2] = c4.z; vr[4 * i + 3] = c4.w;
+        }
+    };
+    auto store_tile = [&](char* slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            *(uint4*)(slot + sdst[i]) = make_uint4(kr[4 * i + 0], kr[4 * i + 1], kr[4 * i + 2], kr[4 * i + 3]);
+            *(uint4*)(slot + TILE + sdst[i]) = make_uint4(vr[4 * i + 0], vr[4 * i + 1], vr[4 * i + 2], vr[4 * i + 3]);
+        }
+    };
+
+    load_tile(t_lo);
+    const bf16_t* qptr = p.Q + (long)b * p.q_bs + (long)qc * p.q_rs + (long)h * D;
+    const bf16_t* gptr = p.dO + (long)b * p.do_bs + (long)qc * p.do_rs + (long)h * D;
+    const bf16_t* optr = p.O + (long)b * p.o_bs + (long)qc * p.o_rs + (long)h * D;
+    bf16x8 qf[D / 16], gf[D / 16];
+    float dl = 0.f;
+#pragma unroll
+    for (int ds = 0; ds < D / 16; ++ds) {
+        qf[ds] = *(const bf16x8*)(qptr + 16 * ds + 8 * h2);
+        gf[ds] = *(const bf16x8*)(gptr + 16 * ds + 8 * h2);
+        const bf16x8 of = *(const bf16x8*)(optr + 16 * ds + 8 * h2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dl += (float)of[j] * (float)gf[ds][j];
+    }
+    const long stat = ((long)b * p.Hq + h) * p.Sq + qc;
+    const float nlse = -p.lse[stat];
+    const float dlt = swap_halves_sum(dl);                          // this lane's half of the head dim + its partner's
+    if (wave_on && qcol < p.Sq && h2 == 0) delta_out[stat] = dlt;
+#pragma unroll
+    for (int ds = 0; ds < D / 16; ++ds) asm volatile("" :: "v"(qf[ds]), "v"(gf[ds]));
+    asm volatile("" :: "v"(nlse));
+    store_tile(lds);
+    load_tile(t_lo + 1);
+
+    int kofs[D / 16], tofs[D / 32][2];
+#pragma unroll
+    for (int ds = 0; ds < D / 16; ++ds) {
+        kofs[ds] = img_off<D>(lane & 31, 2 * ds + h2);
+        asm volatile("" : "+v"(kofs[ds]));
+    }
+    {
+        const int i16 = lane & 15, gq = (lane >> 4) & 1, qq = i16 >> 2, pp = i16 & 3;
+#pragma unroll
+        for (int i = 0; i < D / 32; ++i) {
+            const int c = i * 32 + 16 * gq + 4 * pp;
+            tofs[i][0] = img_off<D>(4 * h2 + qq, c >> 3) + ((c & 4) << 1);           // K^T operand: rows r0 + 4 h2 + q of the K image
+            tofs[i][1] = img_off<D>(4 * h2 + qq + 8, c >> 3) + ((c & 4) << 1);
+            asm volatile("" : "+v"(tofs[i][0]), "+v"(tofs[i][1]));
+        }
+    }
+    f32x16 dq[D / 32];
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
+#define ATTN_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    ATTN_BARRIER();
+
+    int sb = 0;
+    for (int kt = t_lo; kt < t_hi; ++kt) {
+        const int sn = SLOT - sb;
+        const bool act = wave_on && kt * 64 <= wave_kmax;
+        if (act) {
+            int kad[D / 16];
+#pragma unroll
+            for (int ds = 0; ds < D / 16; ++ds) { kad[ds] = kofs[ds] + sb; asm volatile("" : "+v"(kad[ds])); }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                if (CAUSAL && kt * 64 + kb * 32 > wave_kmax) break;                  // upper half of a diagonal tile: masked for every row of the wave
+                f32x16 st, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+                for (int ds = 0; ds < D / 16; ++ds) {
+                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(lds + kad[ds] + kb * 32 * D * 2), qf[ds], st, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(lds + kad[ds] + TILE + kb * 32 * D * 2), gf[ds], dp, 0, 0, 0);
+                }
+                const bool need_mask = (kt * 64 + kb * 32 + 31 >= p.Sk) || (kt * 64 + kb * 32 < kv_lo) ||
+                                       (CAUSAL && kt * 64 + kb * 32 + 31 > q0 + coff);
+                if (need_mask) {
+                    asm volatile("; boundary tile" ::: "memory");
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kt * 64 + kb * 32 + acc_row(r, lane);
+                        const bool ok = key < p.Sk && key >= kv_lo && (!CAUSAL || key <= q_abs);
+                        st[r] = ok ? st[r] : -INFINITY;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(st[r], p.scale_log2, nlse));
+                    st[r] = pv * ((dp[r] - dlt) * p.scale);                          // dS^T
+                }
+                int tad[D / 32][2];
+#pragma unroll
+                for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) { tad[i][j] = tofs[i][j] + sb + kb * 32 * D * 2; asm volatile("" : "+v"(tad[i][j])); }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 dsf = acc_frag(st, s);
+#pragma unroll
+                    for (int i = 0; i < D / 32; ++i)
+                        dq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_pair(lds + tad[i][0] + 16 * s * D * 2, lds + tad[i][1] + 16 * s * D * 2), dsf, dq[i], 0, 0, 0);
+                }
+            }
+        }
+        if (kt + 1 < t_hi) {
+            store_tile(lds + sn);
+            if (kt + 2 < t_hi) load_tile(kt + 2);
+        }
+        ATTN_BARRIER();
+        sb = sn;
+    }
+#undef ATTN_BARRIER
+
+    if (wave_on && qcol < p.Sq) {
+        bf16_t* dqp = p.dQ + (long)b * p.dq_bs + (long)qcol * p.dq_rs + (long)h * D;
+#pragma unroll
+        for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                unsigned a[2], c[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    a[e] = (unsigned)f2bf(dq[i][8 * j + 2 * e]) | ((unsigned)f2bf(dq[i][8 * j + 2 * e + 1]) << 16);
+                    c[e] = (unsigned)f2bf(dq[i][8 * j + 4 + 2 * e]) | ((unsigned)f2bf(dq[i][8 * j + 4 + 2 * e + 1]) << 16);
+                }
+                const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], c[0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], c[1], false, false);
+                *(uint4*)(dqp + i * 32 + 16 * j + 8 * h2) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ backward: dK, dV
 // block = 128 keys of one (batch, kv head); wave w owns keys [k0 + 32w, k0 + 32w + 32).  QR query rows (32 or 64) are
 // staged per iteration: QR = 64 halves the barriers / staging round trips per unit of MFMA work.
@@ -1191,6 +1405,29 @@ extern "C" int desta_attention_bwd(const desta_attn_desc* d, float* workspace, v
     const long rows = (long)a.B * a.Hq * a.Sq;
     const int G = d->head_dim / 8;
     dim3 gd((unsigned)((rows * G + 255) / 256));
+    dim3 gk_((unsigned)((a.Sk + 127) / 128) * a.Hkv * a.B);
+    if (g_attn_opt[0] && !a.drop_thresh && !a.O32 && a.Sq >= 128 && d->dq_row_stride % 8 == 0 && d->dq_batch_stride % 8 == 0 &&
+        ((size_t)d->dQ & 15) == 0) {
+        // 8-wave dQ kernel (computes delta itself and leaves it in the workspace), then dK / dV on the same stream
+        const int G = a.Hq / a.Hkv;
+        const int hpb = !a.causal ? 1 : (d->head_dim == 128 ? (G % 4 == 0 ? 4 : (G % 2 == 0 ? 2 : 1)) : (G % 2 == 0 ? 2 : 1));
+        const int rb = 256 / hpb;
+        dim3 g8((unsigned)((a.Sq + rb - 1) / rb) * (unsigned)(G / hpb) * (unsigned)(a.B * a.Hkv));
+        if (d->head_dim == 128) {
+            if (!a.causal) hipLaunchKernelGGL((attn_bwd_dq8_k<128, false, 1>), g8, dim3(512), 0, st, a, workspace);
+            else if (hpb == 4) hipLaunchKernelGGL((attn_bwd_dq8_k<128, true, 4>), g8, dim3(512), 0, st, a, workspace);
+            else if (hpb == 2) hipLaunchKernelGGL((attn_bwd_dq8_k<128, true, 2>), g8, dim3(512), 0, st, a, workspace);
+            else hipLaunchKernelGGL((attn_bwd_dq8_k<128, true, 1>), g8, dim3(512), 0, st, a, workspace);
+            if (d->dK) hipLaunchKernelGGL((attn_bwd_dkdv_k<128, false>), gk_, dim3(256), 0, st, a);
+        } else {
+            if (!a.causal) hipLaunchKernelGGL((attn_bwd_dq8_k<64, false, 1>), g8, dim3(512), 0, st, a, workspace);
+            else if (hpb == 2) hipLaunchKernelGGL((attn_bwd_dq8_k<64, true, 2>), g8, dim3(512), 0, st, a, workspace);
+            else hipLaunchKernelGGL((attn_bwd_dq8_k<64, true, 1>), g8, dim3(512), 0, st, a, workspace);
+            if (d->dK) hipLaunchKernelGGL((attn_bwd_dkdv_k<64, false>), gk_, dim3(256), 0, st, a);
+        }
+        DESTA_CHECK_LAUNCH("attention_bwd");
+        return DESTA_OK;
+    }
     const bool two_q = d->head_dim == 64 && a.Sq <= 64;
     dim3 gq((unsigned)((a.Sq + (two_q ? 63 : 127)) / (two_q ? 64 : 128)) * a.Hq * a.B);
     dim3 gk((unsigned)((a.Sk + 127) / 128) * a.Hkv * a.B);
