@@ -33,6 +33,7 @@ struct AttnArgs {
     const bf16_t* dO; bf16_t* dQ; bf16_t* dK; bf16_t* dV;
     float* lse; const float* delta;
     float* O32;                                                      // optional fp32 copy of O (same strides as O): delta = rowsum(dO * O) from the UNROUNDED output
+    const float* rope_cs;                                            // bwd: [seq][D/2][2] (cos, sin): dQ / dK are rotated back (adjacent-pair layout) before the store
     long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;           // batch / row strides (elements)
     long do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
     int B, Hq, Hkv, Sq, Sk;
@@ -1053,6 +1054,19 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq8_k(AttnArgs p, float* __re
 
     if (wave_on && qcol < p.Sq) {
         bf16_t* dqp = p.dQ + (long)b * p.dq_bs + (long)qcol * p.dq_rs + (long)h * D;
+        if (p.rope_cs) {
+            // Q is the rotary-embedded projection (adjacent-pair layout): gradient of the projection output = R(pos)^T dQ
+            const float* cs = p.rope_cs + (long)qcol * D;           // (D / 2) pairs x 2 floats per position
+#pragma unroll
+            for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {                    // registers 4 jj .. 4 jj + 3: d = 32 i + 8 jj + 4 h2 + e
+                    const float4 c4 = *(const float4*)(cs + (32 * i + 8 * jj + 4 * h2));
+                    const float g0 = dq[i][4 * jj], g1 = dq[i][4 * jj + 1], g2 = dq[i][4 * jj + 2], g3 = dq[i][4 * jj + 3];
+                    dq[i][4 * jj] = g0 * c4.x + g1 * c4.y;     dq[i][4 * jj + 1] = g1 * c4.x - g0 * c4.y;
+                    dq[i][4 * jj + 2] = g2 * c4.z + g3 * c4.w; dq[i][4 * jj + 3] = g3 * c4.z - g2 * c4.w;
+                }
+        }
 #pragma unroll
         for (int i = 0; i < D / 32; ++i)
 #pragma unroll
@@ -1253,7 +1267,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkdv_k(AttnArgs
         // CONSECUTIVE columns of one key: 4 x 16-byte stores per 64 columns, 128-byte row segments.
         __syncthreads();                                                     // every wave is done with the Q / dO images
         float* tb = (float*)lds + wave * (32 * 64);
-        auto emit = [&](const f32x16 (&acc)[D / 32], bf16_t* base, long rs) __attribute__((always_inline)) {
+        auto emit = [&](const f32x16 (&acc)[D / 32], bf16_t* base, long rs, const bool rope) __attribute__((always_inline)) {
 #pragma unroll
             for (int hf = 0; hf < D / 64; ++hf) {
 #pragma unroll
@@ -1264,7 +1278,14 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkdv_k(AttnArgs
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int row = (lane >> 3) + 8 * j, key = k0 + row;
-                    const float4 x0 = *(const float4*)(tb + row * 64 + (lane & 7) * 8), x1 = *(const float4*)(tb + row * 64 + (lane & 7) * 8 + 4);
+                    float4 x0 = *(const float4*)(tb + row * 64 + (lane & 7) * 8), x1 = *(const float4*)(tb + row * 64 + (lane & 7) * 8 + 4);
+                    if (rope) {                                              // K is the rotary-embedded projection: R(position = key)^T dK
+                        const float* cs = p.rope_cs + (long)min(key, p.Sk - 1) * D + hf * 64 + (lane & 7) * 8;
+                        const float4 c0 = *(const float4*)cs, c1 = *(const float4*)(cs + 4);
+                        const float4 y0 = make_float4(x0.x * c0.x + x0.y * c0.y, x0.y * c0.x - x0.x * c0.y, x0.z * c0.z + x0.w * c0.w, x0.w * c0.z - x0.z * c0.w);
+                        const float4 y1 = make_float4(x1.x * c1.x + x1.y * c1.y, x1.y * c1.x - x1.x * c1.y, x1.z * c1.z + x1.w * c1.w, x1.w * c1.z - x1.z * c1.w);
+                        x0 = y0; x1 = y1;
+                    }
                     u16x8 o;
                     o[0] = f2bf(x0.x); o[1] = f2bf(x0.y); o[2] = f2bf(x0.z); o[3] = f2bf(x0.w);
                     o[4] = f2bf(x1.x); o[5] = f2bf(x1.y); o[6] = f2bf(x1.z); o[7] = f2bf(x1.w);
@@ -1273,8 +1294,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkdv_k(AttnArgs
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // reads done before the next half overwrites the tile
             }
         };
-        emit(dk, dkp, p.dk_rs);
-        emit(dv, dvp, p.dv_rs);
+        emit(dk, dkp, p.dk_rs, p.rope_cs != nullptr);
+        emit(dv, dvp, p.dv_rs, false);
         return;
     }
 #pragma unroll
@@ -1301,7 +1322,7 @@ int fill_args(const desta_attn_desc* d, AttnArgs& a) {
     DESTA_CHECK_ARG(d->batch <= 65535 && d->n_q_heads <= 65535, "attention: grid too large");
     a.Q = (const bf16_t*)d->Q; a.K = (const bf16_t*)d->K; a.V = (const bf16_t*)d->V; a.O = (bf16_t*)d->O;
     a.dO = (const bf16_t*)d->dO; a.dQ = (bf16_t*)d->dQ; a.dK = (bf16_t*)d->dK; a.dV = (bf16_t*)d->dV;
-    a.lse = d->lse; a.delta = nullptr; a.O32 = d->O_f32;
+    a.lse = d->lse; a.delta = nullptr; a.O32 = d->O_f32; a.rope_cs = d->rope_cos_sin;
     a.q_bs = d->q_batch_stride; a.q_rs = d->q_row_stride; a.k_bs = d->k_batch_stride; a.k_rs = d->k_row_stride;
     a.v_bs = d->v_batch_stride; a.v_rs = d->v_row_stride; a.o_bs = d->o_batch_stride; a.o_rs = d->o_row_stride;
     a.do_bs = d->do_batch_stride; a.do_rs = d->do_row_stride; a.dq_bs = d->dq_batch_stride; a.dq_rs = d->dq_row_stride;
@@ -1406,6 +1427,12 @@ extern "C" int desta_attention_bwd(const desta_attn_desc* d, float* workspace, v
     const int G = d->head_dim / 8;
     dim3 gd((unsigned)((rows * G + 255) / 256));
     dim3 gk_((unsigned)((a.Sk + 127) / 128) * a.Hkv * a.B);
+    if (a.rope_cs)
+        DESTA_CHECK_ARG(g_attn_opt[0] && !a.drop_thresh && !a.O32 && a.Sq >= 128 && a.Sq == a.Sk && d->dq_row_stride % 8 == 0 &&
+                        d->dq_batch_stride % 8 == 0 && ((size_t)d->dQ & 15) == 0 &&
+                        (!d->dK || ((((d->dk_row_stride | d->dv_row_stride | d->dk_batch_stride | d->dv_batch_stride) & 7) == 0) &&
+                                    (((size_t)d->dK | (size_t)d->dV) & 15) == 0)),
+                        "attention_bwd: rope_cos_sin needs seq_q == seq_k >= 128, no dropout and 16-byte aligned dQ / dK / dV");
     if (g_attn_opt[0] && !a.drop_thresh && !a.O32 && a.Sq >= 128 && d->dq_row_stride % 8 == 0 && d->dq_batch_stride % 8 == 0 &&
         ((size_t)d->dQ & 15) == 0) {
         // 8-wave dQ kernel (computes delta itself and leaves it in the workspace), then dK / dV on the same stream

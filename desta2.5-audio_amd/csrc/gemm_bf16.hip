@@ -45,7 +45,20 @@ struct GemmArgs {
     float* ws;                                          // fp32 partial slabs [(tile-full)*split + slice][256][256]
     int* tickets;                                       // per split tile: arrivals of its K-slices (in-kernel reduction) or null
     const float* rms_w; float rms_eps;                  // skinny kernel: RMSNorm(A rows; weight rms_w) applied on the fly
+    const float* rope_cs; const int* rope_pos; int rope_cols, rope_hd;   // rotary embedding of output columns [0, rope_cols) in adjacent pairs
+    int desync;                                         // 256-kernel: first-round blocks start up to desync x 0.5 us apart (see gemm_bf16_nt_256_kernel)
 };
+
+// rotary embedding of 4 consecutive outputs (two adjacent pairs) of row m, columns n0 .. n0 + 3 (see desta_gemm_desc.rope_*)
+__device__ __forceinline__ void rope4(const GemmArgs& p, int m, int n0, float (&v)[4]) {
+    if (p.rope_cs && n0 < p.rope_cols) {
+        const int pos = p.rope_pos[m];
+        const float4 cs = *(const float4*)(p.rope_cs + ((long)pos * (p.rope_hd >> 1) + ((n0 & (p.rope_hd - 1)) >> 1)) * 2);
+        const float a0 = v[0], b0 = v[1], a1 = v[2], b1 = v[3];
+        v[0] = a0 * cs.x - b0 * cs.y; v[1] = b0 * cs.x + a0 * cs.y;
+        v[2] = a1 * cs.z - b1 * cs.w; v[3] = b1 * cs.z + a1 * cs.w;
+    }
+}
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -61,6 +74,7 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& p, int z, int m, int n
         const float4 b = *(const float4*)(p.bias + n0);
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
     }
+    rope4(p, m, n0, v);
     if (p.preact) {
         u16x4 o;
 #pragma unroll
@@ -177,6 +191,7 @@ __device__ __forceinline__ void epilogue_pair_bf16(const GemmArgs& p, int z, int
             const float4 b = *(const float4*)(p.bias + n0);
             v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
         }
+        rope4(p, min(m, p.M - 1), n0, v);
         if (p.act == 1) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = gelu_erf_fast(v[e]);
@@ -564,6 +579,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
+
+    // De-synchronised start (multi-round grids only, host decides).  All tiles of a launch take the same time, so with one
+    // block per CU the 256 CUs reach their epilogues TOGETHER, round after round: 256 x 128 KB of stores (+ as much residual
+    // read) hit HBM as one burst — the 8-11 us (plain store) / 19-21 us (residual) per-tile overhead of the K-sweep cost model
+    // is that burst at ~3-4 TB/s — while nothing is written during the main loops.  Spreading the START of the first round's
+    // blocks over about one epilogue length keeps the CUs out of phase for the whole launch (a CU takes its next tile when it
+    // is done), so every epilogue runs beside 255 main loops.  Costs the average delay once per launch.
+    if (p.desync > 0 && (int)blockIdx.x < 256 && blockIdx.y == 0) {
+        const int n = (int)((((unsigned)blockIdx.x * 97u) & 255u) * (unsigned)p.desync) >> 8;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);              // 16 x 64 cycles ~ 0.5 us
+    }
 
     // work item -> (tile, K-slice): the first `full_tiles` items are whole tiles; the remainder of the
     // tile grid (the tail round that would leave CUs idle) is cut into `split` K-slices per tile
@@ -1283,6 +1309,8 @@ static int g_small_ring = 1;      // option 6: 0 never, 1 the four-slot ring for
 static int g_phases2 = 1;         // automatic choice uses the 2-phase (32 MFMAs per phase) staggered schedule (+5-16 % on every shape)
 extern "C" int desta_gemm_set_persistent(int on) { g_persistent = on; return DESTA_OK; }
 static int g_skinny = 0;          // 0 auto, else COLS*10 + U of the skinny (M <= 16) kernel (tuning)
+static int g_desync = 0;          // option 7: spread of the first round's block starts in 0.5-us units, grids of >= g_desync_min_items
+static int g_desync_min = 640;    // option 8: items from which the spread is applied (2.5 rounds)
 static int g_skinny_blocks = 512;  // persistent grid of the skinny kernel (2 blocks per CU)
 extern "C" int desta_gemm_set_option(int option, int value) {
     if (option == 0) g_persistent = value;
@@ -1297,6 +1325,8 @@ extern "C" int desta_gemm_set_option(int option, int value) {
     else if (option == 4) g_phases2 = value;
     else if (option == 5) g_inkernel_splitk = value;
     else if (option == 6) g_small_ring = value;
+    else if (option == 7) g_desync = value;
+    else if (option == 8) g_desync_min = value;
     else if (option == 3) {
         if (value < 1 || value > 65535) { desta_set_error("gemm_set_option: skinny grid %d out of range", value); return DESTA_EINVAL; }
         g_skinny_blocks = value;
@@ -1356,6 +1386,12 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
             if (sp >= 2 && (size_t)rem * sp * 256 * 256 * sizeof(float) + 4096 <= d->workspace_bytes) { split = sp; full = (int)(T - rem); }
         }
     }
+    a.rope_cs = d->rope_cos_sin; a.rope_pos = d->rope_pos; a.rope_cols = d->rope_cols; a.rope_hd = d->rope_head_dim;
+    if (d->rope_cos_sin)
+        DESTA_CHECK_ARG(d->rope_pos && (d->rope_head_dim == 64 || d->rope_head_dim == 128) && d->rope_cols > 0 && d->rope_cols <= d->N &&
+                        d->rope_cols % d->rope_head_dim == 0 && d->act == 0 && !d->bias && !d->residual && !d->preact && !d->out_f32 &&
+                        d->dropout_p == 0.f && d->batch == 1 && d->M > 16 && !d->trans_a && !d->trans_b,
+                        "gemm: the rotary epilogue needs rope_pos, head_dim 64 / 128, rope_cols a multiple of it, a plain bf16 output (no bias / residual / act) and M > 16");
     a.rms_w = d->a_rms_weight; a.rms_eps = d->a_rms_eps;
     if (d->a_rms_weight)
         DESTA_CHECK_ARG(d->M <= 16 && (size_t)d->M * 2 * (size_t)d->K <= (size_t)SKINNY_XS_BYTES && d->K % 512 == 0 &&
@@ -1400,6 +1436,7 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
         a.tilesM = tM; a.tilesN = tN;
         a.full_tiles = full; a.split = split; a.ws = (float*)d->workspace;
         const int items = full + (int)(T - full) * split;
+        a.desync = (g_desync > 0 && items >= g_desync_min && d->batch == 1) ? g_desync : 0;
         // tickets: the last 4 KiB of the workspace (<= 128 split tiles); zero at first use (the caller hands over a zeroed
         // workspace once) and self-resetting afterwards.  Only the plain (non-persistent) kernels carry the in-kernel reduce.
         const bool persistent_ = g_force_variant == 4 || g_force_variant == 8 || (g_force_variant == 0 && g_persistent && items > NCU);

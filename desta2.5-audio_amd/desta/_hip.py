@@ -34,7 +34,8 @@ class GemmDesc(C.Structure):
                 ("preact", vp), ("ldp", i64), ("stride_p", i64), ("alpha", f32),
                 ("aux", vp), ("ld_aux", i64), ("dropout_p", f32), ("dropout_seed", C.c_uint64),
                 ("workspace", vp), ("workspace_bytes", C.c_size_t),
-                ("trans_a", i32), ("trans_b", i32), ("a_rms_weight", vp), ("a_rms_eps", f32)]
+                ("trans_a", i32), ("trans_b", i32), ("a_rms_weight", vp), ("a_rms_eps", f32),
+                ("rope_cos_sin", vp), ("rope_pos", vp), ("rope_cols", i32), ("rope_head_dim", i32)]
 
 
 lib.desta_abi_version.restype = i32
@@ -72,9 +73,11 @@ _gemm = _sig("desta_gemm_bf16_nt", C.POINTER(GemmDesc), vp)
 def gemm(A, B, out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, residual=None, ldr=None,
          act=0, preact=None, ldp=None, alpha=1.0, batch=1, stride_a=0, stride_b=0, stride_c=0,
          stride_r=0, stride_p=0, aux=None, ld_aux=0, dropout_p=0.0, dropout_seed=0, a_rms_weight=None, a_rms_eps=0.0,
-         trans_a=False, trans_b=False):
+         trans_a=False, trans_b=False, rope=None):
     """out[M,N] = act(alpha * A[M,K] @ B[N,K]^T + bias) + residual  (bf16 operands, MFMA).
-    a_rms_weight: decode path, RMSNorm(A; weight, eps) fused into the projection (see `rms_fusable`)."""
+    a_rms_weight: decode path, RMSNorm(A; weight, eps) fused into the projection (see `rms_fusable`).
+    rope = (cos_sin [positions, hd/2, 2] fp32, pos [M] int32, cols, head_dim): rotary embedding of output columns [0, cols) in
+    adjacent pairs inside the epilogue (include/desta_hip.h, desta_gemm_desc.rope_*)."""
     d = GemmDesc()
     d.A, d.B, d.C = p(A), p(B), p(out)
     d.M, d.N, d.K, d.batch = M, N, K, batch
@@ -97,6 +100,10 @@ def gemm(A, B, out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, residua
     d.aux, d.ld_aux = p(aux), ld_aux
     d.dropout_p, d.dropout_seed = dropout_p, dropout_seed
     d.a_rms_weight, d.a_rms_eps = p(a_rms_weight), a_rms_eps
+    if rope is not None:
+        cs_, pos_, cols_, hd_ = rope
+        assert cs_.dtype == torch.float32 and pos_.dtype == torch.int32 and pos_.numel() >= M and cs_.is_contiguous()
+        d.rope_cos_sin, d.rope_pos, d.rope_cols, d.rope_head_dim = p(cs_), p(pos_), int(cols_), int(hd_)
     st = stream()
     ws = _gemm_ws.get((A.device, st))                       # one split-K scratch per STREAM: GEMMs of one stream run serially,
     if ws is None:                                          # GEMMs of two streams (encoder prefetch beside the LLM) must not share it
@@ -386,7 +393,7 @@ class AttnDesc(C.Structure):
                 ("dk_batch_stride", i64), ("dk_row_stride", i64), ("dv_batch_stride", i64), ("dv_row_stride", i64),
                 ("batch", i32), ("n_q_heads", i32), ("n_kv_heads", i32), ("seq_q", i32), ("seq_k", i32),
                 ("head_dim", i32), ("causal", i32), ("kv_start", vp), ("scale", f32),
-                ("dropout_p", f32), ("dropout_seed", C.c_uint64), ("O_f32", vp)]
+                ("dropout_p", f32), ("dropout_seed", C.c_uint64), ("rope_cos_sin", vp), ("O_f32", vp)]
 
 
 _attn_fwd = _sig("desta_attention_fwd", C.POINTER(AttnDesc), vp)
@@ -445,9 +452,12 @@ def attention_fwd(d: AttnDesc):
 
 @_profiled(lambda d, *a, **k: "attn_bwd:" + _attn_tag(d), lambda d, *a, **k: _attn_flops(d, 2.5))     # dS, dP recompute, dQ, dK, dV
 def attention_bwd(d: AttnDesc, do, dq, dk=None, dv=None, *, do_rs=None, dq_off=0, dk_off=0, dv_off=0, dq_rs=None,
-                  dk_rs=None, dv_rs=None, do_bs=None, dq_bs=None, dk_bs=None, dv_bs=None):
+                  dk_rs=None, dv_rs=None, do_bs=None, dq_bs=None, dk_bs=None, dv_bs=None, rope_cos_sin=None):
     """Backward of the attention described by `d` (O and lse filled by forward); *_bs override the batch strides
-    (position-major token grids: row stride = batch * width, batch stride = width)."""
+    (position-major token grids: row stride = batch * width, batch stride = width).  rope_cos_sin [seq, hd/2, 2] fp32: Q / K
+    are rotary-embedded projections in the adjacent-pair layout; dQ / dK are rotated back before the store."""
+    d.rope_cos_sin = p(rope_cos_sin)
+    d._keep_rope = rope_cos_sin
     do_rs = do.shape[-1] if do_rs is None else do_rs
     dq_rs = dq.shape[-1] if dq_rs is None else dq_rs
     d.dO, d.do_row_stride, d.do_batch_stride = p(do), do_rs, (d.seq_q * do_rs if do_bs is None else do_bs)

@@ -647,6 +647,15 @@ class CausalLMHIP:
             wd = g(p + "mlp.down_proj.weight").to(BF16).contiguous()
             ly = dict(n1=g(p + "input_layernorm.weight").float().contiguous(), n2=g(p + "post_attention_layernorm.weight").float().contiguous(),
                       wqkv=wqkv, wqkvT=T(wqkv), wo=wo, woT=T(wo), wgu=wgu, wguT=T(wgu), wd=wd, wdT=T(wd))
+            if not c.qk_norm:
+                # rotary embedding fused into the q|k|v projection (frozen weights, so a re-layout at load is free): the rows of
+                # every q / k head in the order 0, hd/2, 1, hd/2+1, ... put HF's rotate_half pair (i, i + hd/2) on ADJACENT output
+                # columns, which one lane of the GEMM epilogue owns; q.k is invariant under a permutation of the head dim applied
+                # to both.  A second copy of the weight (+1.6 GB for Llama-3.1-8B): eval / generate keep the plain layout.
+                nqk = (self.hq + self.hkv) * self.hd
+                il = wqkv.clone()
+                il[:nqk] = wqkv[:nqk].view(self.hq + self.hkv, 2, self.hd // 2, wqkv.shape[1]).transpose(1, 2).reshape(nqk, wqkv.shape[1])
+                ly["wqkv_il"], ly["wqkvT_il"] = il, T(il)
             if c.qk_norm:
                 ly["qn"] = g(p + "self_attn.q_norm.weight").float().contiguous()
                 ly["kn"] = g(p + "self_attn.k_norm.weight").float().contiguous()
@@ -655,6 +664,7 @@ class CausalLMHIP:
         self.head = self.embed if c.tie_word_embeddings else g("lm_head.weight").to(BF16).contiguous()
         self.headT = T(self.head)                                             # [h, Vp], zero padded
         self.inv_freq = rope_inv_freq(c).to(dev)
+        self.fuse_rope = not c.qk_norm              # A/B switch (bench.py --no-rope-fusion); q/k-norm models (Qwen3) keep the rope kernel
         self.B = self.S = 0
 
     def _alloc(self, B: int, S: int):
@@ -665,6 +675,9 @@ class CausalLMHIP:
             return torch.empty(*s, dtype=BF16, device=dev)
         fr = torch.outer(torch.arange(S, device=dev, dtype=F32), self.inv_freq)
         self.cos_sin = torch.stack([fr.cos(), fr.sin()], dim=1).contiguous()                 # [S, 2, hd/2]
+        self.cos_sin_il = torch.stack([fr.cos(), fr.sin()], dim=2).contiguous()              # [S, hd/2, 2]: (cos, sin) per adjacent pair
+        ar = torch.arange(M, device=dev, dtype=torch.int32)
+        self.pos_rows = {False: (ar % S).contiguous(), True: (ar // B).contiguous()}         # position of a token row: batch-major / position-major
         self.xs = [b16(M, h) for _ in range(self.L + 1)]
         self.sv = []
         for _ in range(self.L):
@@ -704,11 +717,22 @@ class CausalLMHIP:
         self.s_major = bool(s_major)
         smb = B if s_major else 0
         rsm = B if s_major else 1
+        # rotary embedding inside the q|k|v GEMM epilogue: training / eval forward over a whole sequence with arange positions
+        # (H7); the backward then needs the 8-wave dQ path (seq >= 128).  generate() (cache append, shifted positions) and
+        # q/k-norm models keep the separate kernel.
+        fused = self._rope_fused = bool(self.fuse_rope and "wqkv_il" in self.layers[0] and kv_cache is None and pos_shift is None
+                                        and cos_sin is None and S >= 128 and M > 16)
         for i, (ly, s) in enumerate(zip(self.layers, self.sv)):
             x = self.xs[i]
             H.rmsnorm_fwd(x, ly["n1"], c.rms_norm_eps, self.hb, s["r1"])
-            H.gemm(self.hb, ly["wqkv"], s["qkv"], M, self.qkvw, h, preact=s.get("pre"))
-            if kv_cache is None:
+            if fused:
+                H.gemm(self.hb, ly["wqkv_il"], s["qkv"], M, self.qkvw, h,
+                       rope=(self.cos_sin_il, self.pos_rows[self.s_major], (self.hq + self.hkv) * self.hd, self.hd))
+            else:
+                H.gemm(self.hb, ly["wqkv"], s["qkv"], M, self.qkvw, h, preact=s.get("pre"))
+            if fused:
+                pass                                                          # q, k left the projection rotated
+            elif kv_cache is None:
                 H.rope(s["qkv"], self.qkvw, M, S, self.hq, self.hkv, self.hd, cs, ly.get("qn"), ly.get("kn"), c.rms_norm_eps, pos_shift=pos_shift,
                        s_major_batch=smb)
             else:
@@ -891,15 +915,19 @@ class CausalLMHIP:
             H.rmsnorm_bwd(dhb[r0:], s["xm"][r0:], ly["n2"], s["r2"][r0:], other[r0:], dres=dx[r0:])   # other := d x_mid
             H.gemm(other[r0:], ly["woT"], self.datt[r0:], Mr, aw, h)
             # attention backward runs on the whole grid (rows < r0 of datt stay zero; their dQ / the dK,dV of those keys are unused)
+            fused = getattr(self, "_rope_fused", False)
+            rcs = self.cos_sin_il if fused else None                 # fused: dQ / dK leave the attention backward already rotated back
             if self.s_major:
                 H.attention_bwd(s["ad"], self.datt, self.dqkv, self.dqkv, self.dqkv, dq_off=0, dk_off=aw, dv_off=(self.hq + self.hkv) * self.hd,
                                 do_rs=B * aw, dq_rs=B * self.qkvw, dk_rs=B * self.qkvw, dv_rs=B * self.qkvw,
-                                do_bs=aw, dq_bs=self.qkvw, dk_bs=self.qkvw, dv_bs=self.qkvw)
+                                do_bs=aw, dq_bs=self.qkvw, dk_bs=self.qkvw, dv_bs=self.qkvw, rope_cos_sin=rcs)
             else:
-                H.attention_bwd(s["ad"], self.datt, self.dqkv, self.dqkv, self.dqkv, dq_off=0, dk_off=aw, dv_off=(self.hq + self.hkv) * self.hd)
-            H.rope(self.dqkv, self.qkvw, M, S, self.hq, self.hkv, self.hd, self.cos_sin, ly.get("qn"), ly.get("kn"), c.rms_norm_eps,
-                   pre_norm=s.get("pre"), ld_pre=self.qkvw, backward=True, s_major_batch=smb)
-            H.gemm(self.dqkv[r0:], ly["wqkvT"], dhb[r0:], Mr, h, self.qkvw)
+                H.attention_bwd(s["ad"], self.datt, self.dqkv, self.dqkv, self.dqkv, dq_off=0, dk_off=aw, dv_off=(self.hq + self.hkv) * self.hd,
+                                rope_cos_sin=rcs)
+            if not fused:
+                H.rope(self.dqkv, self.qkvw, M, S, self.hq, self.hkv, self.hd, self.cos_sin, ly.get("qn"), ly.get("kn"), c.rms_norm_eps,
+                       pre_norm=s.get("pre"), ld_pre=self.qkvw, backward=True, s_major_batch=smb)
+            H.gemm(self.dqkv[r0:], ly["wqkvT_il" if fused else "wqkvT"], dhb[r0:], Mr, h, self.qkvw)
             H.rmsnorm_bwd(dhb[r0:], self.xs[i][r0:], ly["n1"], s["r1"][r0:], dx[r0:], dres=other[r0:])   # dx := d x_in
         return dx
 

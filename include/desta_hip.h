@@ -85,6 +85,17 @@ typedef struct desta_gemm_desc {
     const float* a_rms_weight;         /* decode path (M <= 16, M*2K <= 65536 B, act 0 or 4): A holds the  */
     float a_rms_eps;                   /*   un-normalised rows; RMSNorm(A; weight, eps) is applied on the fly   */
                                        /*   (LlamaRMSNorm fused into the projection that consumes it). NULL = off */
+    /* (ABI 4) rotary embedding in the epilogue of the fused q|k|v projection (apply_rotary_pos_emb,                  */
+    /* TF:models/llama/modeling_llama.py:120-160): output columns [0, rope_cols) are rotated in ADJACENT PAIRS          */
+    /* (2i, 2i+1) of each rope_head_dim-wide head by the angle of (position rope_pos[m], frequency i):                  */
+    /*   y[2i] = x[2i] c - x[2i+1] s,  y[2i+1] = x[2i+1] c + x[2i] s,  (c, s) = rope_cos_sin[(pos * hd/2 + i) * 2 ..].    */
+    /* HF pairs column i with i + hd/2 (rotate_half); the caller stores the frozen q / k weight rows of every head in   */
+    /* the order 0, hd/2, 1, hd/2 + 1, ... so that the pair is adjacent — q.k is invariant under a permutation of the    */
+    /* head dimension applied to both.  The fp32 accumulator is rotated and rounded ONCE (the reference rounds the      */
+    /* projection to bf16, rotates, rounds again).  NULL = off.  Needs act 0, no bias / residual / dropout, bf16 output. */
+    const float* rope_cos_sin;         /* [positions][rope_head_dim / 2][2] fp32 */
+    const int32_t* rope_pos;           /* [M] position of every output row */
+    int rope_cols, rope_head_dim;
 } desta_gemm_desc;
 int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream);
 /* tuning / tests only: 0 = automatic tile choice, 1 = force 128x128, 2 / 3 / 4 = force the 256x256 kernel with the
@@ -261,6 +272,11 @@ typedef struct desta_attn_desc {
     float scale;
     float dropout_p;                   /* attention-probability dropout (head_dim 64 only), same mask in fwd and bwd */
     uint64_t dropout_seed;
+    const float* rope_cos_sin;         /* optional (ABI 4), bwd only: [seq][head_dim / 2][2] fp32 (cos, sin).  Q and K are the rotary-  */
+                                       /* embedded projections in the adjacent-pair layout of desta_gemm_desc.rope_*: dQ (row q: position */
+                                       /* q) and dK (row k: position k) are rotated back by the transposed rotation before they are       */
+                                       /* stored, i.e. they come out as gradients of the projection OUTPUTS.  Needs the 8-wave dQ path   */
+                                       /* (seq_q >= 128, no dropout, 16-byte aligned dQ / dK / dV).  NULL = off.                         */
     float* O_f32;                      /* optional (ABI 4): fp32 copy of O written by fwd, indexed with the o_* strides.  bwd then   */
                                        /* takes delta = rowsum(dO * O) from the UNROUNDED output: with delta from the bf16-rounded O */
                                        /* the error of delta is coherent over the keys of a row (dS_err = P * eps_q) and, where the   */

@@ -89,12 +89,50 @@ def test_deep_and_tied_vs_reference_golden(golden_dir, name):
     errs = {n: float((model.arena.grad(n).double().cpu() - g["grad::" + n].double()).norm() / max(float(g["grad::" + n].double().norm()), floor)) for n in names}
     worst = max(errs, key=errs.get)
     rec["worst_grad"] = (worst.split("connector.")[-1], round(errs[worst], 4))
+    # per-TENSOR yardstick: the error the reference's own autocast(bf16) policy carries on that tensor against the same fp32
+    # golden (tests/golden/autocast_policy_grad_errors.json, made by tests/golden/make_policy_grad_errors.py on the CPU).  Round 2
+    # showed 10-13 % on the deep cross-attention query weights against 2.5 % for the policy: delta = rowsum(dO * O) taken from
+    # the bf16-ROUNDED attention output; with the fp32 output (desta_attn_desc.O_f32) the tensor sits at the policy's floor.
+    import json
+    pol = json.load(open(os.path.join(golden_dir, "autocast_policy_grad_errors.json")))[name]
+    ratio = {n: errs[n] / max(pol[n], 5e-3) for n in names}
+    wr = max(ratio, key=ratio.get)
+    rec["worst_vs_policy"] = (wr.split("connector.")[-1], round(errs[wr], 4), round(pol[wr], 4))
     print(name, {k: (round(v, 5) if isinstance(v, float) else v) for k, v in rec.items()})
+    assert ratio[wr] < 2.5, rec                                              # no tensor more than 2.5x the policy's own error (floor 5e-3)
     assert rec["dloss"] < 8e-3, rec
     assert rec["logits"] < 4e-2 and rec["af"] < 2e-2, rec
     assert all(t < 1e-2 for t in rec.get("taps", [])), rec                 # flat in depth: fp32 Whisper residual stream
     assert rec["grad"] < 5e-2 and rec["cos"] > 0.999, rec
-    assert errs[worst] < 0.15, rec
+    assert errs[worst] < 0.06, rec                                           # (round 2: 0.15, with the 10-13 % outlier inside)
+
+
+@pytest.mark.parametrize("s_tgt", [150, 80])
+def test_rope_fused_into_the_qkv_epilogue(s_tgt):
+    """Sequences of >= 128 tokens take the rotary embedding inside the q|k|v GEMM epilogue (permuted frozen weights, adjacent
+    pairs) and its transpose inside the attention backward's dQ / dK stores; shorter ones the separate kernel.  Both must agree
+    with each other (same loss to bf16 rounding, same gradients) and with the oracle, on both token layouts."""
+    d = O.tiny_dims(False)
+    model, w = _model(d)
+    batch = O.synthetic_batch(d, B=3, S_ctx=9, S_tgt=s_tgt, seed=5, pad=[0, 7, 2])
+    S = batch["input_ids"].shape[1]
+    names = model.trainable_parameter_names
+    loss_o, _ = O.model_forward(w, d, batch)
+    res = {}
+    for fuse in (True, False):
+        model.llm.fuse_rope = fuse
+        for fast in (True, False):                                  # position-major training fast path / batch-major grid
+            out = model(**batch) if fast else model(**batch, keep_logits=True)
+            assert model.llm._rope_fused == (fuse and S >= 128)
+            model.backward()
+            res[(fuse, fast)] = (float(out.loss), model.arena.grads.clone())
+            assert abs(float(out.loss) - float(loss_o)) < 2e-2
+    for fast in (True, False):
+        la, ga = res[(True, fast)]
+        lb, gb = res[(False, fast)]
+        assert abs(la - lb) < 5e-3, (la, lb)
+        assert float((ga - gb).double().norm() / gb.double().norm()) < 2e-2
+    model.llm.fuse_rope = True
 
 
 def test_stagewise_vs_oracle():
@@ -352,8 +390,10 @@ def test_connector_reference_unit_test_shapes_fwd_bwd():
 
 def test_loss_curve_tracks_oracle_over_many_steps():
     """120 optimizer steps on a cycled pool of 8 batches (tiny config, dropout off): the bf16 HIP path's loss curve
-    stays on the fp32 oracle's (north star: loss curve parity over many steps; the 1000-step run of
-    tools/loss_curve.py is committed under profiles/r01_c_loss_curve_*: mean |d| 1.7e-3, last-100 mean 7.7e-4)."""
+    stays on the fp32 oracle's (north star: loss curve parity over many steps).  Bounds = the measured regime of the
+    1000-step three-way runs of tools/loss_curve.py (profiles/r02_loss_curve_summary.log): per-step mean |d| of the HIP path
+    against the fp32 oracle 1.2e-3 (Llama) / 1.7e-3 (Qwen3), the reference's OWN autocast(bf16) policy against the same fp32
+    run 2.2e-3 / 1.5e-3 — the bf16 floor; single steps reach 1.5e-2; the smoothed curves agree within 4e-4."""
     from desta.trainer.desta_trainer import DeSTA25Trainer, TrainingArguments
     torch.set_num_threads(min(8, torch.get_num_threads()))
     d = O.tiny_dims(False)
@@ -372,8 +412,8 @@ def test_loss_curve_tracks_oracle_over_many_steps():
     diff = [abs(a - b) for a, b in zip(hip, ref)]
     print("loss", ref[0], "->", ref[-1], "| mean diff", sum(diff) / len(diff), "max", max(diff))
     assert ref[-1] < ref[0] - 0.3                                # the pool is being fitted
-    assert sum(diff) / len(diff) < 5e-3 and max(diff) < 3e-2
-    assert abs(sum(hip[-10:]) - sum(ref[-10:])) / 10 < 5e-3
+    assert sum(diff) / len(diff) < 2.5e-3 and max(diff) < 3e-2
+    assert abs(sum(hip[-10:]) - sum(ref[-10:])) / 10 < 2e-3
 
 
 def test_training_entry_point_debug_config(tmp_path):

@@ -448,6 +448,63 @@ def test_attention_fp32_output_copy_feeds_delta(hip):
     assert errs[True] < 1.5e-2 and errs[True] <= errs[False] * 1.05
 
 
+@pytest.mark.parametrize("hd,smajor", [(128, True), (64, False)])
+def test_rope_in_gemm_epilogue_and_attention_backward(hip, hd, smajor):
+    """desta_gemm_desc.rope_*: the q|k|v projection with permuted q / k weight rows leaves q, k rotated (adjacent pairs) —
+    equal, after undoing the permutation, to HF's apply_rotary_pos_emb on the plain projection.  desta_attn_desc.rope_cos_sin:
+    the backward returns gradients of the projection OUTPUTS (checked against torch autograd through rotate + attention)."""
+    B, S, Hq, Hkv, K = 2, 160, 4, 2, 256
+    g = torch.Generator().manual_seed(hd)
+    nqk, w = (Hq + Hkv) * hd, (Hq + 2 * Hkv) * hd
+    x = bf(torch.randn(B * S, K, generator=g))
+    W = bf(torch.randn(w, K, generator=g) / 16)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    fr = torch.outer(torch.arange(S).float(), inv)                       # [S, hd/2]
+    cs_il = torch.stack([fr.cos(), fr.sin()], dim=2).contiguous()
+    pos = (torch.arange(B * S) // B if smajor else torch.arange(B * S) % S).to(torch.int32)
+    Wil = W.clone()
+    Wil[:nqk] = W[:nqk].view(Hq + Hkv, 2, hd // 2, K).transpose(1, 2).reshape(nqk, K)
+    out = torch.empty(B * S, w, dtype=torch.bfloat16, device="cuda")
+    hip.gemm(x.cuda(), Wil.cuda(), out, B * S, w, K, rope=(cs_il.cuda(), pos.cuda(), nqk, hd))
+    # reference: plain projection (fp32), HF rotation, then the same permutation of the head dim
+    y = (x.float() @ W.float().T).requires_grad_(True)
+    yh = y[:, :nqk].view(B * S, Hq + Hkv, hd)
+    c = torch.cat([fr, fr], -1).cos()[pos.long()][:, None, :]
+    sn = torch.cat([fr, fr], -1).sin()[pos.long()][:, None, :]
+    rot = torch.cat([-yh[..., hd // 2:], yh[..., :hd // 2]], -1)
+    ye = yh * c + rot * sn                                                # [rows, heads, hd] HF layout
+    ye_il = ye.view(B * S, Hq + Hkv, 2, hd // 2).transpose(2, 3).reshape(B * S, nqk)
+    assert rel_err(out[:, :nqk].float().cpu(), ye_il.detach()) < 6e-3
+    assert rel_err(out[:, nqk:].float().cpu(), y[:, nqk:].detach()) < 6e-3
+    # attention on the rotated projections, backward to the projection outputs
+    rs, bs = (B * w, w) if smajor else (w, S * w)
+    o = torch.zeros(B * S, Hq * hd, dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros(B, Hq, S, device="cuda")
+    d = hip.attn_desc(out, out, out, o, lse, batch=B, hq=Hq, hkv=Hkv, sq=S, sk=S, hd=hd, scale=hd ** -0.5, causal=True,
+                      q_off=0, k_off=Hq * hd, v_off=nqk, q_rs=rs, k_rs=rs, v_rs=rs, o_rs=rs // w * Hq * hd,
+                      q_bs=bs, k_bs=bs, v_bs=bs, o_bs=bs // w * Hq * hd)
+    hip.attention_fwd(d)
+    do = bf(torch.randn(B * S, Hq * hd, generator=g))
+    dqkv = torch.zeros(B * S, w, dtype=torch.bfloat16, device="cuda")
+    ors, obs = rs // w * Hq * hd, bs // w * Hq * hd
+    hip.attention_bwd(d, do.cuda(), dqkv, dqkv, dqkv, dq_off=0, dk_off=Hq * hd, dv_off=nqk, do_rs=ors, dq_rs=rs, dk_rs=rs, dv_rs=rs,
+                      do_bs=obs, dq_bs=bs, dk_bs=bs, dv_bs=bs, rope_cos_sin=cs_il.cuda())
+    # torch: rows -> [B, S] order, rotate, attention, autograd back to y
+    idx = (torch.arange(S)[None, :] * B + torch.arange(B)[:, None]).reshape(-1) if smajor else torch.arange(B * S)
+    qe = ye[idx][:, :Hq].view(B, S, Hq, hd)
+    ke = ye[idx][:, Hq:].view(B, S, Hkv, hd)
+    v = y[idx][:, nqk:].view(B, S, Hkv, hd)
+    ref = _attn_ref(qe, ke, v, hd ** -0.5, True, None)
+    assert rel_err(o.float().cpu()[idx].view(B, S, Hq, hd), ref.detach()) < 8e-3
+    ref.backward(do.float()[idx].view(B, S, Hq, hd))
+    gy = y.grad                                                           # gradient of the PLAIN projection, plain layout
+    gy_il = torch.cat([gy[:, :nqk].view(B * S, Hq + Hkv, 2, hd // 2).transpose(2, 3).reshape(B * S, nqk), gy[:, nqk:]], 1)
+    got = dqkv.float().cpu()
+    assert rel_err(got[:, :Hq * hd], gy_il[:, :Hq * hd]) < 1.5e-2
+    assert rel_err(got[:, Hq * hd:nqk], gy_il[:, Hq * hd:nqk]) < 1.5e-2
+    assert rel_err(got[:, nqk:], gy_il[:, nqk:]) < 1.5e-2
+
+
 def test_attention_desc_keeps_tensors_alive_and_clamps_kv_start(hip):
     """The descriptor holds raw device pointers: it must keep temporaries alive (a freed kv_start buffer
     reused by a later allocation once turned into garbage pad lengths).  Out-of-range pad lengths are
