@@ -69,7 +69,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(6, max(1, len(todo)))) as ex:
         list(ex.map(cc, todo))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs,
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl",
            "-Wl,-rpath,/opt/rocm/lib", "-Wl,-soname,libdesta_hip.so"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

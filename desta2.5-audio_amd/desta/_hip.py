@@ -549,6 +549,40 @@ def sample_top_p(logits, ld, rows, cols, temperature, top_p, seed, step, out, ke
                   stream()), "desta_sample_top_p_bf16")
 
 
+# ----------------------------------------------------------------------------- data-parallel exchange without torch.distributed
+class CommUniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
+def comm_get_unique_id() -> bytes:
+    """128 opaque bytes (ncclUniqueId) made on rank 0; every rank passes them to `comm_create`."""
+    lib.desta_comm_get_unique_id.argtypes = [C.POINTER(CommUniqueId)]
+    uid = CommUniqueId()
+    check(lib.desta_comm_get_unique_id(C.byref(uid)), "desta_comm_get_unique_id")
+    return bytes(C.string_at(C.addressof(uid), 128))
+
+
+def comm_create(world_size: int, rank: int, unique_id: bytes) -> int:
+    lib.desta_comm_create.argtypes = [C.POINTER(vp), i32, i32, C.POINTER(CommUniqueId)]
+    uid = CommUniqueId()
+    C.memmove(C.addressof(uid), unique_id, 128)
+    comm = vp()
+    check(lib.desta_comm_create(C.byref(comm), world_size, rank, C.byref(uid)), "desta_comm_create")
+    return comm.value
+
+
+def allreduce_grads(comm: int, grads: torch.Tensor) -> None:
+    """In-place mean over the ranks of `comm` of a flat fp32 tensor, on the current stream (one RCCL all-reduce)."""
+    assert grads.dtype == torch.float32 and grads.is_contiguous()
+    lib.desta_allreduce_grads.argtypes = [vp, vp, i64, vp]
+    check(lib.desta_allreduce_grads(comm, p(grads), grads.numel(), stream()), "desta_allreduce_grads")
+
+
+def comm_destroy(comm: int) -> None:
+    lib.desta_comm_destroy.argtypes = [vp]
+    check(lib.desta_comm_destroy(comm), "desta_comm_destroy")
+
+
 def attention_set_option(which: int, value: int) -> None:
     lib.desta_attention_set_option.argtypes = [i32, i32]
     check(lib.desta_attention_set_option(int(which), int(value)), "desta_attention_set_option")

@@ -346,6 +346,23 @@ int desta_rope_kv_append(void* qkv, int64_t ld, int rows, int seq, int n_q_heads
                          const int32_t* pos_shift, void* kv_cache, int64_t kv_batch_stride, int64_t kv_row_stride,
                          int slot0, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Data-parallel gradient exchange: the MEAN over ranks of the flat fp32 gradient arena as one
+ * RCCL all-reduce (ncclAvg) on `stream`, in place — what DDP's bucketed reducer does for the reference (accelerate
+ * `accelerator.py:1892`; loss semantics: each rank's loss is its own token mean, gradients are averaged over ranks, hazard H8).
+ * For hosts without torch.distributed (the Python host layer issues the same collective through torch's RCCL binding):
+ *   rank 0: desta_comm_get_unique_id(&id); hand the 128 bytes to every rank (any channel);
+ *   every rank (its device current): desta_comm_create(&comm, world, rank, &id);
+ *   every step: desta_allreduce_grads(comm, arena_grads, n, stream) between backward and desta_clip_adafactor_step;
+ *   desta_comm_destroy(comm).
+ * RCCL is loaded on first use (dlopen): the other entry points need no RCCL on the box.  One process per GPU. */
+typedef struct { char internal[128]; } desta_comm_unique_id;        /* = ncclUniqueId */
+typedef void* desta_comm;                                            /* = ncclComm_t */
+int desta_comm_get_unique_id(desta_comm_unique_id* id);
+int desta_comm_create(desta_comm* comm, int world_size, int rank, const desta_comm_unique_id* id);
+int desta_allreduce_grads(desta_comm comm, float* grads, int64_t n, void* stream);
+int desta_comm_destroy(desta_comm comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -175,5 +175,34 @@ def test_gradient_accumulation_equals_the_sum_of_micro_batch_gradients():
     assert torch.equal(got_p, ref.arena.params) and torch.equal(got_s, opt.state)
 
 
+@pytest.mark.gpu
+def test_c_abi_allreduce_grads_at_world_size_one():
+    """desta_comm_* / desta_allreduce_grads (the exchange for hosts without torch.distributed): RCCL communicator of ONE rank
+    (the box has one GPU: RCCL wants a device per rank), ncclAvg of a 131.5 M-float arena on a side stream: the identity, bit
+    for bit; a second communicator can be made after the first is destroyed; bad arguments are reported, not thrown."""
+    _setup_paths()
+    from desta import _hip as H
+    uid = H.comm_get_unique_id()
+    assert len(uid) == 128
+    comm = H.comm_create(1, 0, uid)
+    g = torch.randn(131_540_000 // 64 * 64, device="cuda")
+    ref = g.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        H.allreduce_grads(comm, g)
+        H.allreduce_grads(comm, g)
+    side.synchronize()
+    assert torch.equal(g, ref)
+    H.comm_destroy(comm)
+    comm2 = H.comm_create(1, 0, H.comm_get_unique_id())
+    H.allreduce_grads(comm2, g[:1024])
+    torch.cuda.synchronize()
+    assert torch.equal(g, ref)
+    H.comm_destroy(comm2)
+    with pytest.raises(RuntimeError):
+        H.comm_create(2, 5, uid)                                   # rank outside the world
+
+
 if __name__ == "__main__" and len(sys.argv) >= 3 and sys.argv[1] == "--worker":
     worker(sys.argv[2])
