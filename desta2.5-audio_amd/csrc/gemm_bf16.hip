@@ -66,6 +66,11 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 }
 
 // epilogue for 4 consecutive N outputs of row m: alpha, bias, pre-activation copy, GELU, residual, store
+// ROPE: compiled in only where a rotary-epilogue GEMM can arrive without taking the wide-store path (128x128 kernels, split-K
+// fix-up / in-kernel reduce); inside the 256x256 kernels' generic loops the extra body made hipcc give up the full unroll and
+// keep the 128 accumulators in SCRATCH (528 B per thread: WRITE_SIZE 106 -> 472 MB per launch) — rotary GEMMs satisfy the
+// wide-store conditions there (checked on the host).
+template <bool ROPE = false>
 __device__ __forceinline__ void epilogue4(const GemmArgs& p, int z, int m, int n0, const f32x4& a) {
     float v[4];
 #pragma unroll
@@ -74,7 +79,7 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& p, int z, int m, int n
         const float4 b = *(const float4*)(p.bias + n0);
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
     }
-    rope4(p, m, n0, v);
+    if constexpr (ROPE) rope4(p, m, n0, v);
     if (p.preact) {
         u16x4 o;
 #pragma unroll
@@ -346,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs p) {
         for (int j = 0; j < 4; ++j) {
             const int n0 = bcol + wc * 64 + j * 16 + fq * 4;
             if (n0 >= p.N) continue;
-            epilogue4(p, z, m, n0, acc[i][j]);
+            epilogue4<true>(p, z, m, n0, acc[i][j]);
         }
     }
 }
@@ -549,7 +554,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_ring_kernel(GemmArgs p) {
         for (int j = 0; j < 4; ++j) {
             const int n0 = bcol + wc * 64 + j * 16 + fq * 4;
             if (n0 >= p.N) continue;
-            epilogue4(p, z, m, n0, acc[i][j]);
+            epilogue4<true>(p, z, m, n0, acc[i][j]);
         }
     }
 }
@@ -818,7 +823,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
                     v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
                 }
                 const int m = brow + ml, n0 = bcol + nl;
-                if (m < p.M && n0 < p.N) epilogue4(p, z, m, n0, v);
+                if (m < p.M && n0 < p.N) epilogue4<true>(p, z, m, n0, v);
             }
         }
         __syncthreads();                                                       // every thread is done with the slabs
@@ -856,7 +861,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
         for (int j = 0; j < 4; ++j) {
             const int n0 = bcol + wn * 64 + j * 16 + fq * 4;
             if (n0 >= p.N) continue;
-            epilogue4(p, z, m, n0, acc[i][j]);
+            epilogue4(p, z, m, n0, acc[i][j]);               // (no rotary epilogue here: see epilogue4)
         }
     }
 }
@@ -1122,7 +1127,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_fixup_kernel(GemmArgs p) {
         acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
     }
     const int m = tm * 256 + ml, n0 = tn * 256 + nl;
-    if (m < p.M && n0 < p.N) epilogue4(p, z, m, n0, acc);
+    if (m < p.M && n0 < p.N) epilogue4<true>(p, z, m, n0, acc);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1390,7 +1395,7 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
     if (d->rope_cos_sin)
         DESTA_CHECK_ARG(d->rope_pos && (d->rope_head_dim == 64 || d->rope_head_dim == 128) && d->rope_cols > 0 && d->rope_cols <= d->N &&
                         d->rope_cols % d->rope_head_dim == 0 && d->act == 0 && !d->bias && !d->residual && !d->preact && !d->out_f32 &&
-                        d->dropout_p == 0.f && d->batch == 1 && d->M > 16 && !d->trans_a && !d->trans_b,
+                        d->dropout_p == 0.f && d->batch == 1 && d->M > 16 && !d->trans_a && !d->trans_b && d->N % 32 == 0 && d->ldc % 8 == 0,
                         "gemm: the rotary epilogue needs rope_pos, head_dim 64 / 128, rope_cols a multiple of it, a plain bf16 output (no bias / residual / act) and M > 16");
     a.rms_w = d->a_rms_weight; a.rms_eps = d->a_rms_eps;
     if (d->a_rms_weight)

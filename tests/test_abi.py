@@ -65,3 +65,23 @@ def test_graft_entry_build_runs_on_cpu():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     mod.build()
+
+
+def test_hot_kernels_use_no_scratch():
+    """Code-object metadata of the built library: the kernels that carry the step keep everything in registers (scratch =
+    `private_segment_fixed_size` = 0).  Round 3 lost the 256x256 GEMM's 128 accumulators to a 528-byte stack frame when an
+    epilogue helper grew past hipcc's full-unroll budget — invisible in the tests, +366 MB of HBM writes per launch."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.kernel_resources()
+    assert len(res) > 100
+    hot = ("gemm_bf16_nt_256_kernel", "gemm_bf16_nt_256p_kernel", "gemm_bf16_nt_kernel", "gemm_bf16_nt_ring_kernel", "gemm_bf16_nt_skinny_kernel",
+           "attn_fwd8_k", "attn_bwd_dq8_k", "attn_bwd_dkdv_k", "swiglu", "rmsnorm", "layernorm", "af_apply", "af_stats")
+    seen = 0
+    for name, r in res.items():
+        if any(h in name for h in hot):
+            seen += 1
+            assert r["scratch"] == 0 and r["spill"] == 0, (name, r)
+    assert seen >= 30
