@@ -273,6 +273,8 @@ def main():
     ap.add_argument("--launch-check", action="store_true", help="plumbing only: rendezvous + one all-reduce of the N ranks, no device work (CPU test of the self-launch path)")
     ap.add_argument("--no-calibration", action="store_true", help="skip the box_calibration block (fixed GEMM / copy workloads before the timed region)")
     ap.add_argument("--no-rope-fusion", action="store_true", help="A/B: rotary embedding as its own kernel (forward and backward) instead of inside the q|k|v GEMM epilogue / attention-backward stores")
+    ap.add_argument("--attn-r2-backward", action="store_true", help="A/B: attention backward on round 2's kernels (separate delta, 4-wave dQ beside dK/dV); implies --no-rope-fusion")
+    ap.add_argument("--attn-r2-forward", action="store_true", help="A/B: attention forward AND backward on round 2's 4-wave kernels; implies --no-rope-fusion")
     ap.add_argument("--full-lm-head", action="store_true", help="A/B: lm_head / CE over the whole token grid, not only the target rows")
     a = ap.parse_args()
 
@@ -341,8 +343,13 @@ def main():
         model.connector.overlap_dw = False
     if a.full_lm_head:
         model.compact_lm_head = False
-    if a.no_rope_fusion:
+    if a.no_rope_fusion or a.attn_r2_backward or a.attn_r2_forward:
         model.llm.fuse_rope = False
+    if a.attn_r2_backward:
+        H.attention_set_option(3, 1)
+    if a.attn_r2_forward:
+        H.attention_set_option(0, 0)
+
     B, S = a.batch, a.ctx + cfg.prompt_size + a.tgt
     n_mels = cfg.encoder_config.num_mel_bins
     # two alternating synthetic batches per rank, resident in HBM (seed 1234 + rank)

@@ -1341,9 +1341,9 @@ int fill_args(const desta_attn_desc* d, AttnArgs& a) {
 
 }  // namespace
 
-namespace { int g_attn_opt[4] = {1, 0, 0, 0}; }
+namespace { int g_attn_opt[8] = {1, 0, 0, 0, 0, 0, 0, 0}; }
 extern "C" int desta_attention_set_option(int which, int value) {
-    DESTA_CHECK_ARG(which >= 0 && which < 4, "attention_set_option: unknown option %d", which);
+    DESTA_CHECK_ARG(which >= 0 && which < 8, "attention_set_option: unknown option %d", which);
     g_attn_opt[which] = value;
     return DESTA_OK;
 }
@@ -1428,18 +1428,20 @@ extern "C" int desta_attention_bwd(const desta_attn_desc* d, float* workspace, v
     dim3 gd((unsigned)((rows * G + 255) / 256));
     dim3 gk_((unsigned)((a.Sk + 127) / 128) * a.Hkv * a.B);
     if (a.rope_cs)
-        DESTA_CHECK_ARG(g_attn_opt[0] && !a.drop_thresh && !a.O32 && a.Sq >= 128 && a.Sq == a.Sk && d->dq_row_stride % 8 == 0 &&
+        DESTA_CHECK_ARG(g_attn_opt[0] && !g_attn_opt[3] && !a.drop_thresh && !a.O32 && a.Sq >= 128 && a.Sq == a.Sk && d->dq_row_stride % 8 == 0 &&
                         d->dq_batch_stride % 8 == 0 && ((size_t)d->dQ & 15) == 0 &&
                         (!d->dK || ((((d->dk_row_stride | d->dv_row_stride | d->dk_batch_stride | d->dv_batch_stride) & 7) == 0) &&
                                     (((size_t)d->dK | (size_t)d->dV) & 15) == 0)),
                         "attention_bwd: rope_cos_sin needs seq_q == seq_k >= 128, no dropout and 16-byte aligned dQ / dK / dV");
-    if (g_attn_opt[0] && !a.drop_thresh && !a.O32 && a.Sq >= 128 && d->dq_row_stride % 8 == 0 && d->dq_batch_stride % 8 == 0 &&
+    if (g_attn_opt[0] && !g_attn_opt[3] && !a.drop_thresh && !a.O32 && a.Sq >= 128 && d->dq_row_stride % 8 == 0 && d->dq_batch_stride % 8 == 0 &&
         ((size_t)d->dQ & 15) == 0) {
         // 8-wave dQ kernel (computes delta itself and leaves it in the workspace), then dK / dV on the same stream
         const int G = a.Hq / a.Hkv;
         const int hpb = !a.causal ? 1 : (d->head_dim == 128 ? (G % 4 == 0 ? 4 : (G % 2 == 0 ? 2 : 1)) : (G % 2 == 0 ? 2 : 1));
         const int rb = 256 / hpb;
         dim3 g8((unsigned)((a.Sq + rb - 1) / rb) * (unsigned)(G / hpb) * (unsigned)(a.B * a.Hkv));
+        // (the 8-wave dQ kernel on a side stream beside dK / dV, with delta by its own launch again, measured equal in the step:
+        // 168.41 / 169.16 vs 168.54 / 169.16 ms in alternating runs on one box; removed)
         if (d->head_dim == 128) {
             if (!a.causal) hipLaunchKernelGGL((attn_bwd_dq8_k<128, false, 1>), g8, dim3(512), 0, st, a, workspace);
             else if (hpb == 4) hipLaunchKernelGGL((attn_bwd_dq8_k<128, true, 4>), g8, dim3(512), 0, st, a, workspace);

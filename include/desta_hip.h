@@ -292,7 +292,9 @@ int desta_attention_set_concurrent_bwd(int on);
 /* Process-wide kernel selection switches (A/B measurements; results agree to rounding either way):
  *   which 0: forward for seq_q >= 128 without dropout on the 8-wave kernel (1, default) or the 4-wave kernel (0);
  *   which 1: head_dim 64 non-causal 8-wave forward at two blocks per CU (1) or one (0, default);
- *   which 2: 1 = the 8-wave forward WITH waves 4-7 half a tile behind waves 0-3 (LLM / Whisper shapes only; default 0). */
+ *   which 2: 1 = the 8-wave forward WITH waves 4-7 half a tile behind waves 0-3 (LLM / Whisper shapes only; default 0);
+ *   which 3: 1 = backward on round 2's path (separate delta launch, 4-wave dQ kernel on a side stream beside dK / dV) instead
+ *            of the 8-wave dQ kernel that computes delta itself (default 0; not available with rope_cos_sin). */
 int desta_attention_set_option(int which, int value);
 
 /* layer_prompts[j].expand(B,-1,-1) for all taps at once (modeling_desta25.py:589): prompts fp32
