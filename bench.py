@@ -439,9 +439,8 @@ def main():
         # HBM bytes per launch of the dominant kernel: from the separate rocprofv3 --pmc passes of this same
         # command (profiles/, FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes); null if absent
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_gemm_hbm_traffic.json")
-        if not os.path.isfile(tpath):
-            tpath = os.path.join(ROOT, "profiles", "r01_c_gemm_hbm_traffic.json")
+        tpath = next((pth for pth in (os.path.join(ROOT, "profiles", f) for f in ("r03_gemm_hbm_traffic.json", "r02_gemm_hbm_traffic.json",
+                                                                                    "r01_c_gemm_hbm_traffic.json")) if os.path.isfile(pth)), "")
         if a.config == "desta25_llama31-8B_Qformer6L" and os.path.isfile(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
