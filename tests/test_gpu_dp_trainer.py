@@ -34,6 +34,11 @@ def _batches(d, rank):
     return out
 
 
+def _eval_batches(d):
+    import desta_oracle as O
+    return [O.synthetic_batch(d, B=2, S_ctx=4, S_tgt=9 + i, seed=900 + i) for i in range(5)]
+
+
 def _model():
     import desta_oracle as O
     from helpers import cfg_from_dims
@@ -58,6 +63,15 @@ def worker(out_dir):
     assert tr.world == world and tr._side is not None and model.dropout_seed == 1 + rank
     losses = tr.train(_batches(d, rank))
     assert tr.global_step == STEPS and tr.optimizer.step_count == STEPS
+    if os.environ.get("DESTA_TEST_EVAL"):
+        # data-parallel evaluate(): every "sample" of the eval set is one collated batch (collator = identity on a 1-row list);
+        # rank r takes batches r, r + world, ...; loss sums are all-reduced, result files written by rank 0 only
+        import types
+        tr.eval_dataset, tr.data_collator = _eval_batches(d), (lambda rows: rows[0])
+        tr.args.per_device_eval_batch_size = 1
+        tr.cfg = types.SimpleNamespace(exp_dir=out_dir, get=lambda k, dflt=None: out_dir if k == "exp_dir" else dflt)
+        metrics = tr.evaluate()
+        torch.save(metrics, os.path.join(out_dir, f"eval{rank}.pt"))
     from desta.trainer.desta_trainer import ALLREDUCE_CALLS
     torch.save({"params": model.arena.params.cpu(), "state": tr.optimizer.state.cpu(), "losses": losses,
                 "backend": dist.get_backend(), "allreduce_calls": dict(ALLREDUCE_CALLS)}, os.path.join(out_dir, f"rank{rank}.pt"))
@@ -110,6 +124,37 @@ def test_two_rank_trainer_bit_identical_and_equals_single_process_mean(tmp_path)
     torch.cuda.synchronize()
     assert torch.equal(model.arena.params.cpu(), r0["params"]), float((model.arena.params.cpu() - r0["params"]).abs().max())
     assert torch.equal(opt.state.cpu(), r0["state"])
+
+
+@pytest.mark.gpu
+def test_two_rank_evaluate_shards_reduces_and_writes_once(tmp_path):
+    """`DeSTA25Trainer.evaluate()` under data parallel: the eval batches are sharded by rank, the loss sums are
+    all-reduced, rank 0 alone writes the result files: both ranks report the same eval_loss / eval_ppl, equal to one process
+    evaluating every batch, and <exp_dir>/results/val holds exactly ONE report."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0", DESTA_TEST_EVAL="1")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", str(tmp_path)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    m0, m1 = (torch.load(tmp_path / f"eval{r}.pt", weights_only=True) for r in range(2))
+    assert m0 == m1 and m0["eval_loss"] > 0
+    reports = [f for f in os.listdir(tmp_path / "results" / "val") if f.endswith("-report.json")]
+    assert len(reports) == 1, reports
+    # single process over all five batches, same trained parameters
+    _setup_paths()
+    from desta.trainer.desta_trainer import DeSTA25Trainer, TrainingArguments
+    d, model = _model()
+    r0 = torch.load(tmp_path / "rank0.pt", weights_only=True)
+    model.arena.params.copy_(r0["params"].cuda())
+    model.mark_weights_updated()
+    tr = DeSTA25Trainer(model, args=TrainingArguments(overlap_comm=False))
+    ref = tr.evaluate(eval_batches=_eval_batches(d))
+    assert abs(ref["eval_loss"] - m0["eval_loss"]) < 1e-6 and abs(ref["eval_ppl"] - m0["eval_ppl"]) < 1e-4
 
 
 @pytest.mark.gpu
