@@ -275,6 +275,7 @@ def main():
     ap.add_argument("--no-rope-fusion", action="store_true", help="A/B: rotary embedding as its own kernel (forward and backward) instead of inside the q|k|v GEMM epilogue / attention-backward stores")
     ap.add_argument("--attn-r2-backward", action="store_true", help="A/B: attention backward on round 2's kernels (separate delta, 4-wave dQ beside dK/dV); implies --no-rope-fusion")
     ap.add_argument("--attn-r2-forward", action="store_true", help="A/B: attention forward AND backward on round 2's 4-wave kernels; implies --no-rope-fusion")
+    ap.add_argument("--lora", action="store_true", help="NOT the headline config: the reference's optional use_lora=True (rank-16 adapters on q/k/v of every decoder layer, full-row backward)")
     ap.add_argument("--full-lm-head", action="store_true", help="A/B: lm_head / CE over the whole token grid, not only the target rows")
     a = ap.parse_args()
 
@@ -332,7 +333,7 @@ def main():
         H.gemm_set_option(6, a.small_gemm_ring)
     if a.splitk_inkernel:
         H.gemm_set_option(5, 1)
-    cfg = DeSTA25Config(**FULL_CONFIGS[a.config])
+    cfg = DeSTA25Config(**FULL_CONFIGS[a.config], use_lora=a.lora)
     t0 = time.time()
     model = DeSTA25AudioModel(cfg, weights=RandomWeights(cfg, dev, seed=0), device=dev)
     args = TrainingArguments(learning_rate=1e-4, weight_decay=0.01, warmup_steps=5000, max_steps=10 ** 6, logging_steps=10 ** 9,
@@ -481,7 +482,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{a.config}: {os.path.basename(cfg.encoder_model_id)} + {os.path.basename(cfg.llm_model_id)}, "
                                    f"Q-Former {cfg.qformer_num_hidden_layers}L, per-GPU batch {B} x 30 s clips, "
-                                   f"S={S} ({a.ctx} ctx + {cfg.prompt_size} audio + {a.tgt} target tokens), random-init weights at true shapes",
+                                   f"S={S} ({a.ctx} ctx + {cfg.prompt_size} audio + {a.tgt} target tokens), random-init weights at true shapes"
+                                   + (" + use_lora (rank-16 q/k/v adapters trainable: NOT the headline config)" if a.lora else ""),
                        "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}",
                        "step_definition": "one pass of the hot path over one per-GPU batch; value = per-GPU batch-steps per second "
                                           "summed over the node (N x K / max-over-ranks time), weak scaling",

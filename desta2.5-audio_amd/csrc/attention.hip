@@ -1413,6 +1413,18 @@ BwdFork* bwd_fork() {
 }
 }  // namespace
 extern "C" int desta_attention_set_concurrent_bwd(int on) { g_bwd_concurrent = on; return DESTA_OK; }
+// desta_create / desta_destroy (api.hip): make / release the current device's internal fork stream and events
+int desta_internal_reserve(void) { return bwd_fork() ? DESTA_OK : DESTA_ELAUNCH; }
+int desta_internal_release(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return DESTA_EINVAL;
+    BwdFork& f = g_bwd_fork[dev];
+    if (f.side) { (void)hipStreamSynchronize(f.side); (void)hipStreamDestroy(f.side); }
+    if (f.fork) (void)hipEventDestroy(f.fork);
+    if (f.join) (void)hipEventDestroy(f.join);
+    f = BwdFork();
+    return DESTA_OK;
+}
 
 extern "C" int desta_attention_bwd(const desta_attn_desc* d, float* workspace, void* stream) {
     AttnArgs a;

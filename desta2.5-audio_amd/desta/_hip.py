@@ -583,6 +583,40 @@ def comm_destroy(comm: int) -> None:
     check(lib.desta_comm_destroy(comm), "desta_comm_destroy")
 
 
+class Context:
+    """`desta_create` / `desta_destroy` (include/desta_hip.h): optional per-device context.  Creating it checks the device is a
+    gfx950 part, makes it current and creates the library's internal fork stream / events up front; closing it releases them."""
+
+    def __init__(self, device: int = 0):
+        lib.desta_create.argtypes = [i32, C.POINTER(vp)]
+        h = vp()
+        check(lib.desta_create(int(device), C.byref(h)), "desta_create")
+        self.handle = h.value
+
+    def info(self) -> dict:
+        lib.desta_handle_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.c_char_p, C.c_size_t]
+        dev, cus, arch = i32(), i32(), C.create_string_buffer(64)
+        check(lib.desta_handle_info(self.handle, C.byref(dev), C.byref(cus), arch, 64), "desta_handle_info")
+        return {"device": dev.value, "compute_units": cus.value, "arch": arch.value.decode()}
+
+    def last_error(self) -> str:
+        lib.desta_handle_last_error.argtypes = [vp]
+        lib.desta_handle_last_error.restype = C.c_char_p
+        return lib.desta_handle_last_error(self.handle).decode()
+
+    def close(self) -> None:
+        if self.handle:
+            lib.desta_destroy.argtypes = [vp]
+            check(lib.desta_destroy(self.handle), "desta_destroy")
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 def attention_set_option(which: int, value: int) -> None:
     lib.desta_attention_set_option.argtypes = [i32, i32]
     check(lib.desta_attention_set_option(int(which), int(value)), "desta_attention_set_option")

@@ -104,11 +104,13 @@ class DeSTA25Config:
             raise NotImplementedError(
                 f"connector_mode '{connector_mode}' not implemented. Supported modes: 'qformer_1' "
                 "(ORCA hybrid is out of scope of the MI355X hot path, SURVEY.md §8f)")
-        if use_lora:
-            raise NotImplementedError("use_lora=True is not on the MI355X hot path (no shipped config enables it)")
+        # use_lora: peft.LoraConfig(r=16, lora_alpha=16, lora_dropout=0.1, target_modules=[q_proj, k_proj, v_proj]) on the
+        # decoder (modeling_desta25.py:720-729); the three constants are fixed there, kept as fields for tests
+        self.lora_r, self.lora_alpha = int(kwargs.pop("lora_r", 16)), float(kwargs.pop("lora_alpha", 16))
+        self.lora_dropout = float(kwargs.pop("lora_dropout", 0.1))
         self.llm_model_id, self.encoder_model_id = llm_model_id, encoder_model_id
         self.connector_mode, self.qformer_num_hidden_layers, self.prompt_size = connector_mode, qformer_num_hidden_layers, prompt_size
-        self.use_lora, self.audio_locator, self.placeholder_token = use_lora, audio_locator, placeholder_token
+        self.use_lora, self.audio_locator, self.placeholder_token = bool(use_lora), audio_locator, placeholder_token
         self.orca_enabled = False
         self.qformer_intermediate_size = qformer_intermediate_size   # BertConfig() default (never overridden, :156-162)
         # BertConfig() defaults hidden_dropout_prob = attention_probs_dropout_prob = 0.1 are never overridden
@@ -154,7 +156,7 @@ class DeSTA25Config:
                 "prompt_size": self.prompt_size, "use_lora": self.use_lora, "audio_locator": self.audio_locator,
                 "placeholder_token": self.placeholder_token, "orca_enabled": False,
                 "qformer_intermediate_size": self.qformer_intermediate_size, "target_layer_ids": self.target_layer_ids,
-                "qformer_dropout": self.qformer_dropout,
+                "qformer_dropout": self.qformer_dropout, "lora_r": self.lora_r, "lora_alpha": self.lora_alpha, "lora_dropout": self.lora_dropout,
                 "llm_config": asdict(self.llm_config), "encoder_config": asdict(self.encoder_config), "info": self.info}
 
     def save_pretrained(self, path: str) -> None:
@@ -205,11 +207,37 @@ def connector_param_shapes(cfg: DeSTA25Config) -> "OrderedDict[str, Tuple[int, .
     return s
 
 
+LORA_TARGETS = ("q", "k", "v")
+
+
+def lora_param_shapes(cfg: DeSTA25Config) -> "OrderedDict[str, Tuple[int, ...]]":
+    """LoRA adapters of the decoder's q/k/v projections under peft's names (`get_peft_model(...).base_model.model`,
+    modeling_desta25.py:729), in ARENA order: per layer the three A matrices [r, hidden] adjacent (one [3r, hidden] operand),
+    then the three B matrices [out, r] adjacent (one [(Hq + 2 Hkv) hd, r] operand)."""
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    if not cfg.use_lora:
+        return s
+    c, r = cfg.llm_config, cfg.lora_r
+    outs = {"q": c.num_attention_heads * c.head_dim, "k": c.num_key_value_heads * c.head_dim, "v": c.num_key_value_heads * c.head_dim}
+    assert (r * c.hidden_size) % 64 == 0 and all((o * r) % 64 == 0 for o in outs.values()) and 3 * r <= 64, "LoRA rank / widths vs arena alignment"
+    for i in range(c.num_hidden_layers):
+        p = f"{LLM}model.layers.{i}.self_attn."
+        for m in LORA_TARGETS:
+            s[f"{p}{m}_proj.lora_A.default.weight"] = (r, c.hidden_size)
+        for m in LORA_TARGETS:
+            s[f"{p}{m}_proj.lora_B.default.weight"] = (outs[m], r)
+    return s
+
+
 def reference_parameter_names(cfg: DeSTA25Config) -> List[str]:
     """Trainable tensors in the REFERENCE's `named_parameters()` order (registration order of
-    QformerConnector.__init__, modeling_desta25.py:148-168, and of BertLayer): the order HF Trainer uses to
-    number parameters inside `optimizer.pt`."""
-    names = [f"{CON}layer_prompts.{j}" for j in range(len(cfg.target_layer_ids))] + [f"{CON}layer_weights"]
+    QformerConnector.__init__, modeling_desta25.py:148-168, and of BertLayer; with `use_lora` the adapters of `llm_model`,
+    which is registered before `perception`, come first): the order HF Trainer uses to number parameters inside `optimizer.pt`."""
+    names = []
+    if getattr(cfg, "use_lora", False):
+        names += [f"{LLM}model.layers.{i}.self_attn.{m}_proj.lora_{ab}.default.weight"
+                  for i in range(cfg.llm_config.num_hidden_layers) for m in LORA_TARGETS for ab in "AB"]
+    names += [f"{CON}layer_prompts.{j}" for j in range(len(cfg.target_layer_ids))] + [f"{CON}layer_weights"]
     for i in range(cfg.qformer_num_hidden_layers):
         p = f"{CON}qformer.layer.{i}."
         for blk in ("attention", "crossattention"):
@@ -666,6 +694,99 @@ class CausalLMHIP:
         self.inv_freq = rope_inv_freq(c).to(dev)
         self.fuse_rope = not c.qk_norm              # A/B switch (bench.py --no-rope-fusion); q/k-norm models (Qwen3) keep the rope kernel
         self.B = self.S = 0
+        self.lora = None
+
+    # -- LoRA adapters on q/k/v (reference: peft, modeling_desta25.py:720-729; published layer: y = W x + (alpha / r) B A drop(x)) --------
+    LORA_KP = 64                                    # the three rank-r adapters side by side, padded to one 64-wide GEMM K block
+
+    def attach_lora(self, arena: ParamArena, r: int, alpha: float, p_drop: float) -> None:
+        """The adapters live in the trainable arena (fp32, like peft keeps them); `refresh_lora` makes the bf16 operand copies:
+        per layer `a16` [64, h] (rows 16p..16p+r = A_p, the rest zero), `b16` [(Hq+2Hkv) hd, 64] block-diagonal (rows of
+        projection p carry scaling * B_p in columns 16p..16p+r), so that  t = x a16^T  [M, 64]  and  qkv += t b16^T  are two
+        GEMMs for all three projections.  The rows in front of the first audio span cannot be skipped in the backward (their
+        keys / values carry adapter gradient), and the rotary embedding stays a separate kernel (it follows the adapter sum)."""
+        assert 3 * r <= self.LORA_KP
+        self.lora = dict(arena=arena, r=r, scaling=alpha / r, p=p_drop, dirty=True, merged_dirty=True, seed_base=0, p_now=0.0)
+        h, dev = self.h, self.dev
+        for ly in self.layers:
+            ly["a16"] = torch.zeros(self.LORA_KP, h, dtype=BF16, device=dev)
+            ly["b16"] = torch.zeros(self.qkvw, self.LORA_KP, dtype=BF16, device=dev)
+            ly["a16p"] = [torch.zeros(self.LORA_KP, h, dtype=BF16, device=dev) for _ in LORA_TARGETS]   # a16 with the rows of ONE projection (dropout backward)
+        self.B = self.S = 0                                                    # re-allocate the activations with the adapter buffers
+
+    def _lora_names(self, i: int, ab: str) -> List[str]:
+        return [f"{LLM}model.layers.{i}.self_attn.{m}_proj.lora_{ab}.default.weight" for m in LORA_TARGETS]
+
+    def refresh_lora(self) -> None:
+        lo = self.lora
+        if lo is None or not lo["dirty"]:
+            return
+        r, ar = lo["r"], lo["arena"]
+        outs = (self.hq * self.hd, self.hkv * self.hd, self.hkv * self.hd)
+        for i, ly in enumerate(self.layers):
+            row = 0
+            for j, (na, nb) in enumerate(zip(self._lora_names(i, "A"), self._lora_names(i, "B"))):
+                ly["a16"][16 * j:16 * j + r].copy_(ar.param(na))
+                ly["a16p"][j][16 * j:16 * j + r].copy_(ar.param(na))
+                ly["b16"][row:row + outs[j], 16 * j:16 * j + r].copy_(ar.param(nb) * lo["scaling"])
+                row += outs[j]
+        lo["dirty"], lo["merged_dirty"] = False, True
+
+    def _lora_merged(self, i: int) -> torch.Tensor:
+        """q|k|v weight with the adapters merged, W + scaling * B A (bf16), for generate(): the decode kernels stream ONE weight."""
+        lo = self.lora
+        if lo["merged_dirty"]:
+            for ly in self.layers:
+                if "wqkv_m" not in ly:
+                    ly["wqkv_m"] = torch.empty_like(ly["wqkv"])
+                H.gemm(ly["b16"], ly["a16"], ly["wqkv_m"], self.qkvw, self.h, self.LORA_KP, trans_b=True, ldb=self.h, residual=ly["wqkv"])
+            lo["merged_dirty"] = False
+        return self.layers[i]["wqkv_m"]
+
+    def _lora_seed(self, i: int, j: int) -> int:
+        return ((self.lora["seed_base"] ^ (1 << 39)) + 4 * i + j) & 0xFFFFFFFFFFFFFFFF      # bit 39: apart from the Q-Former's sites of any forward
+
+    def _lora_fwd(self, i: int, ly, s, M: int) -> None:
+        """s["qkv"] (plain layout, before the rotary embedding) += adapters of layer i applied to self.hb."""
+        lo, h, KP = self.lora, self.h, self.LORA_KP
+        t = s["lt"]
+        if lo["p_now"] > 0.0:                                                    # peft: every adapted module has its OWN dropout
+            for j in range(len(LORA_TARGETS)):
+                H.dropout_bf16(self.hb, self.lxd, M, h, h, lo["p_now"], self._lora_seed(i, j))
+                H.gemm(self.lxd, ly["a16"][16 * j:16 * j + 16], t[:, 16 * j:], M, 16, h, ldc=KP)
+        else:
+            H.gemm(self.hb, ly["a16"], t, M, KP, h)
+        H.gemm(t, ly["b16"], s["qkv"], M, self.qkvw, KP, residual=s["qkv"])
+
+    def _lora_bwd(self, i: int, ly, s, dhb, M: int) -> None:
+        """Adapter gradients of layer i into the arena, and dhb [M, h] += their input gradient.  self.dqkv = d(q|k|v) of the
+        plain layout, all M rows; the reduction over tokens runs on Mp = M rounded up to 64 rows whose pad rows are zero."""
+        lo, h, KP, Mp = self.lora, self.h, self.LORA_KP, self.Mp
+        ar, r = lo["arena"], lo["r"]
+        t, dt = s["lt"], self.ldt
+        H.rmsnorm_fwd(self.xs[i], ly["n1"], self.c.rms_norm_eps, self.lhb, self.lr1)           # the projection's input again (not kept by the forward)
+        outs = (self.hq * self.hd, self.hkv * self.hd, self.hkv * self.hd)
+        col = 0
+        for j, nb in enumerate(self._lora_names(i, "B")):                                      # dB_p = scaling * dY_p^T t_p
+            H.gemm(self.dqkv[:, col:], t[:, 16 * j:], ar.grad(nb), outs[j], r, Mp, trans_a=True, trans_b=True, lda=self.qkvw, ldb=KP, alpha=lo["scaling"])
+            col += outs[j]
+        H.gemm(self.dqkv, ly["b16"], dt, M, KP, self.qkvw, trans_b=True, ldb=KP)                # dt = dY (scaling B)
+        na = self._lora_names(i, "A")
+        if lo["p_now"] > 0.0:
+            for j in range(len(LORA_TARGETS)):
+                H.dropout_bf16(self.lhb, self.lxd, M, h, h, lo["p_now"], self._lora_seed(i, j))
+                H.gemm(dt[:, 16 * j:], self.lxd, ar.grad(na[j]), r, h, Mp, trans_a=True, trans_b=True, lda=KP, ldb=h)
+                H.gemm(dt, ly["a16p"][j], self.lxd, M, h, KP, trans_b=True, ldb=h)            # d drop_p(x) = dt_p A_p
+                H.dropout_bf16(self.lxd, self.lxd, M, h, h, lo["p_now"], self._lora_seed(i, j))
+                dhb[:M].add_(self.lxd[:M])
+        else:
+            ga = ar.grads[ar.offsets[na[0]]:ar.offsets[na[0]] + 3 * r * h].view(3 * r, h) if r == 16 else None
+            if ga is not None:
+                H.gemm(dt, self.lhb, ga, 3 * r, h, Mp, trans_a=True, trans_b=True, lda=KP, ldb=h)
+            else:
+                for j in range(len(LORA_TARGETS)):
+                    H.gemm(dt[:, 16 * j:], self.lhb, ar.grad(na[j]), r, h, Mp, trans_a=True, trans_b=True, lda=KP, ldb=h)
+            H.gemm(dt, ly["a16"], dhb, M, h, KP, trans_b=True, ldb=h, residual=dhb)
 
     def _alloc(self, B: int, S: int):
         h, dev, M = self.h, self.dev, B * S
@@ -695,8 +816,16 @@ class CausalLMHIP:
         # backward scratch
         self.dxa, self.dxb = b16(M, h), b16(M, h)
         self.dgu = b16(M, 2 * self.I)
-        self.dqkv = b16(M, self.qkvw)
+        self.Mp = _r64(M)
+        self.dqkv = torch.zeros(self.Mp, self.qkvw, dtype=BF16, device=dev)                  # rows >= M: zero (token-reduction operand of the adapter gradients)
         self.datt = torch.zeros(M, self.hq * self.hd, dtype=BF16, device=dev)                # rows in front of the first audio span stay 0
+        if self.lora is not None:
+            # token-reduction operands of the adapter gradients: Mp rows, pad rows zero for good (kernels write rows < M only)
+            z = lambda *sh: torch.zeros(*sh, dtype=BF16, device=dev)
+            self.lhb, self.lxd, self.ldt = z(self.Mp, h), z(self.Mp, h), z(self.Mp, self.LORA_KP)
+            self.lr1 = torch.empty(M, dtype=F32, device=dev)
+            for s in self.sv:
+                s["lt"] = z(self.Mp, self.LORA_KP)
 
     def forward(self, x0_filler, B: int, S: int, kv_start: Optional[torch.Tensor], labels: Optional[torch.Tensor], need_grad: bool,
                 pos_shift: Optional[torch.Tensor] = None, cos_sin: Optional[torch.Tensor] = None, last_logits: Optional[torch.Tensor] = None,
@@ -721,15 +850,24 @@ class CausalLMHIP:
         # (H7); the backward then needs the 8-wave dQ path (seq >= 128).  generate() (cache append, shifted positions) and
         # q/k-norm models keep the separate kernel.
         fused = self._rope_fused = bool(self.fuse_rope and "wqkv_il" in self.layers[0] and kv_cache is None and pos_shift is None
-                                        and cos_sin is None and S >= 128 and M > 16)
+                                        and cos_sin is None and S >= 128 and M > 16 and self.lora is None)
+        lora = self.lora is not None and kv_cache is None                 # generate(): merged weights instead (`_lora_merged`)
+        if self.lora is not None:
+            self.refresh_lora()
+            self.lora["p_now"] = self.lora["p"] if need_grad else 0.0
         for i, (ly, s) in enumerate(zip(self.layers, self.sv)):
             x = self.xs[i]
             H.rmsnorm_fwd(x, ly["n1"], c.rms_norm_eps, self.hb, s["r1"])
             if fused:
                 H.gemm(self.hb, ly["wqkv_il"], s["qkv"], M, self.qkvw, h,
                        rope=(self.cos_sin_il, self.pos_rows[self.s_major], (self.hq + self.hkv) * self.hd, self.hd))
+            elif lora:
+                H.gemm(self.hb, ly["wqkv"], s["qkv"], M, self.qkvw, h)
+                self._lora_fwd(i, ly, s, M)
+                if "pre" in s:
+                    s["pre"].copy_(s["qkv"])                                  # q/k-norm backward wants the projection before the norm
             else:
-                H.gemm(self.hb, ly["wqkv"], s["qkv"], M, self.qkvw, h, preact=s.get("pre"))
+                H.gemm(self.hb, ly["wqkv"] if self.lora is None else self._lora_merged(i), s["qkv"], M, self.qkvw, h, preact=s.get("pre"))
             if fused:
                 pass                                                          # q, k left the projection rotated
             elif kv_cache is None:
@@ -810,8 +948,8 @@ class CausalLMHIP:
             else:
                 H.rmsnorm_fwd(xin, nw, c.rms_norm_eps, self.g_hb, self.g_r)
                 H.gemm(self.g_hb, w, out, B, N, h, **kw)
-        for ly, cache in zip(self.layers, self.kv_cache):
-            proj(x, ly["n1"], ly["wqkv"], self.g_qkv, self.qkvw)
+        for li, (ly, cache) in enumerate(zip(self.layers, self.kv_cache)):
+            proj(x, ly["n1"], ly["wqkv"] if self.lora is None else self._lora_merged(li), self.g_qkv, self.qkvw)
             H.rope_kv_append(self.g_qkv, self.qkvw, B, 1, self.hq, self.hkv, self.hd, self.gen_cos_sin, ly.get("qn"), ly.get("kn"),
                              c.rms_norm_eps, pos_shift, cache, Smax * self.kvw, self.kvw, cur)     # rotate q,k + append K|V at slot cur
             ad = H.attn_desc(self.g_qkv, cache, cache, self.g_att, self.g_lse, batch=B, hq=self.hq, hkv=self.hkv, sq=1, sk=cur + 1,
@@ -890,6 +1028,8 @@ class CausalLMHIP:
         positions >= first_needed_pos (the first audio span of the batch) are propagated: the rows in front of it are frozen
         text embeddings whose gradient nothing consumes (under the causal mask they do not feed any needed row either)."""
         c, h, M, S, B = self.c, self.h, self.M, self.S, self.B
+        if self.lora is not None:
+            first_needed_pos = 0             # adapter gradients of the keys / values in front of the first audio span
         r0 = first_needed_pos * B if self.s_major else 0
         Mr = M - r0
         smb = B if self.s_major else 0
@@ -928,6 +1068,8 @@ class CausalLMHIP:
                 H.rope(self.dqkv, self.qkvw, M, S, self.hq, self.hkv, self.hd, self.cos_sin, ly.get("qn"), ly.get("kn"), c.rms_norm_eps,
                        pre_norm=s.get("pre"), ld_pre=self.qkvw, backward=True, s_major_batch=smb)
             H.gemm(self.dqkv[r0:], ly["wqkvT_il" if fused else "wqkvT"], dhb[r0:], Mr, h, self.qkvw)
+            if self.lora is not None:
+                self._lora_bwd(i, ly, s, dhb, M)
             H.rmsnorm_bwd(dhb[r0:], self.xs[i][r0:], ly["n1"], s["r1"][r0:], dx[r0:], dres=other[r0:])   # dx := d x_in
         return dx
 
@@ -946,12 +1088,15 @@ class DeSTA25AudioModel:
         if weights is None:
             weights = self._load_base_weights(config)
         shapes = connector_param_shapes(config)
+        shapes.update(lora_param_shapes(config))                       # use_lora: the decoder's q/k/v adapters are trainable too
         self.arena = ParamArena(list(shapes.items()), self.device)
         self.trainable_parameter_names = list(shapes.keys())
         with torch.cuda.device(self.device):
             self.encoder = WhisperEncoderHIP(config, weights, self.device)
             self.llm = CausalLMHIP(config, weights, self.device)
             self.connector = QformerConnectorHIP(config, self.arena, self.device)
+            if config.use_lora:
+                self.llm.attach_lora(self.arena, config.lora_r, config.lora_alpha, config.lora_dropout)
         self._init_connector(weights)
         e = config.encoder_config
         self.enc_all = None
@@ -992,7 +1137,9 @@ class DeSTA25AudioModel:
             if name in weights:
                 self.arena.param(name).copy_(weights[name].to(self.device, F32).reshape(shape))
                 continue
-            if "layer_prompts" in name:
+            if ".lora_B." in name:
+                v = torch.zeros(*shape)                                # peft: B = 0, A = kaiming_uniform(a = sqrt 5) = U(+-1/sqrt(fan_in)), the `.weight` rule below
+            elif "layer_prompts" in name:
                 v = torch.randn(*shape, generator=g)
             elif name.endswith("layer_weights"):
                 v = torch.zeros(*shape)
@@ -1053,6 +1200,14 @@ class DeSTA25AudioModel:
     def mark_weights_updated(self):
         self._weights_dirty = True
 
+    def refresh_weights(self):
+        """bf16 operand copies of every trainable tensor from the fp32 arena, on the current stream (the trainer calls this right
+        behind the optimizer step; a forward does it itself when `mark_weights_updated` / `load_state_dict` flagged a change)."""
+        self.connector.refresh_weights()
+        if self.llm.lora is not None:
+            self.llm.lora["dirty"] = True
+            self.llm.refresh_lora()
+
     # -- forward / backward ----------------------------------------------------------------------
     def _audio_slots(self, starts, B: int, S: int, s_major: bool):
         """Flat row indices of the audio slots of inputs_embeds ([N_audio * K] int64, device) and the source-map values that
@@ -1097,16 +1252,20 @@ class DeSTA25AudioModel:
         N_audio = len(batch_start_positions)
         with torch.cuda.device(dev):
             if self._weights_dirty:
-                self.connector.refresh_weights()
+                self.refresh_weights()
                 self._weights_dirty = False
             af = None
+            seed_base = ((self.dropout_seed & 0xFFFFFF) << 40) | ((self._fwd_count & 0xFFFFFFFF) << 8)
+            if self.llm.lora is not None:
+                self.llm.lora["seed_base"] = seed_base
+            if N_audio > 0 or self.llm.lora is not None:
+                self._fwd_count += 1
             if N_audio > 0:
                 assert len(batch_start_positions) == len(batch_transcription_ids) == batch_features.shape[0], \
                     "batch_start_positions, batch_transcription_ids, audio_features, speech_feature_lengths must have the same length."
                 self._encode(batch_features, N_audio)
                 self.connector.p_drop = cfg.qformer_dropout if self.training else 0.0
-                self.connector.seed_base = ((self.dropout_seed & 0xFFFFFF) << 40) | ((self._fwd_count & 0xFFFFFFFF) << 8)
-                self._fwd_count += 1
+                self.connector.seed_base = seed_base
                 af = self.connector.forward(self.enc_all, N_audio)
                 src = self._src_rows(input_ids, [t.to(dev) for t in batch_transcription_ids], batch_start_positions, None)
             else:
@@ -1130,7 +1289,7 @@ class DeSTA25AudioModel:
             loss = None
             if labels is not None:
                 labels = labels.to(dev).contiguous()
-                need_grad = self.training and N_audio > 0
+                need_grad = self.training and (N_audio > 0 or self.llm.lora is not None)
                 if need_grad:
                     # dlogits overwrite the logits buffer: hand the caller a copy only if asked to keep them
                     if kwargs.get("keep_logits", False):
@@ -1141,7 +1300,7 @@ class DeSTA25AudioModel:
                 loss = self.llm.loss_and_grad(labels, write_grad=need_grad).clone().view(())
             # audio rows of inputs_embeds, for the backward gather
             self._fwd = dict(B=B, S=S, N_audio=N_audio, starts=[(int(r), int(s)) for r, s in batch_start_positions],
-                             has_grad=labels is not None and self.training and N_audio > 0, s_major=s_major)
+                             has_grad=labels is not None and self.training and (N_audio > 0 or self.llm.lora is not None), s_major=s_major)
         return _Out(loss, out_logits)
 
     __call__ = forward
@@ -1165,7 +1324,7 @@ class DeSTA25AudioModel:
         try:
             with torch.cuda.device(dev):
                 if self._weights_dirty:
-                    self.connector.refresh_weights()
+                    self.refresh_weights()
                     self._weights_dirty = False
                 af = None
                 if N_audio > 0:
@@ -1395,6 +1554,10 @@ class DeSTA25AudioModel:
         GEMMs, LayerNorms, cross-attention) leave most of the chip idle, and nothing of the NEXT batch's frozen Whisper forward
         depends on them: the trainer runs this half on its side stream beside that forward (`overlap_comm`)."""
         with torch.cuda.device(self.device):
+            if d_af is None:                       # use_lora, batch without audio: only the adapters have a gradient
+                end = min((self.arena.offsets[n] for n in self.arena.names if ".lora_" in n), default=self.arena.numel)
+                self.arena.grads[:end].zero_()
+                return
             self.connector.backward(d_af)
 
     def backward_llm(self) -> torch.Tensor:
@@ -1404,10 +1567,13 @@ class DeSTA25AudioModel:
             raise RuntimeError("backward() needs a training-mode forward with labels and at least one audio")
         K, S, B = self.config.prompt_size, f["S"], f["B"]
         with torch.cuda.device(self.device):
-            if f["s_major"]:
+            if f["s_major"] and f["starts"]:
                 dx0 = self.llm.backward(first_needed_pos=min(s for _, s in f["starts"]))
             else:
                 dx0 = self.llm.backward()
+            if f["N_audio"] == 0:
+                self._fwd = None
+                return None
             idx = self._audio_slots(f["starts"], B, S, f["s_major"])[2]
             d_af = torch.empty(f["N_audio"] * K, self.config.llm_config.hidden_size, dtype=BF16, device=self.device)
             H.gather_rows(dx0, idx, f["N_audio"] * K, self.config.llm_config.hidden_size, d_af)

@@ -191,7 +191,7 @@ class DeSTA25Trainer:
         else:
             allreduce_mean_(arena.grads)                                      # one flat buffer, no buckets
         self.optimizer.step(lr)
-        self.model.connector.refresh_weights()
+        self.model.refresh_weights()
 
     def wait_update(self) -> None:
         """Main stream waits for the side-stream all-reduce + optimizer of the previous step."""
@@ -638,7 +638,7 @@ class DeSTA25Trainer:
             with open(side) as f:
                 self.model._fwd_count = int(json.load(f).get("forward_count", self.model._fwd_count))
         self._micro = 0                                                       # checkpoints are written at window boundaries only
-        self.model.connector.refresh_weights()
+        self.model.refresh_weights()
         self.model._weights_dirty = False
 
     # -- checkpoint (trainable-only model.safetensors + optimizer state) --------------------------

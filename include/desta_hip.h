@@ -41,6 +41,17 @@ int desta_abi_version(void);
 size_t desta_sizeof_desc(int which);
 const char* desta_last_error(void);
 
+/* Optional per-device context.  No data-path call takes it: the path is stateless (see "state" above).  What
+ * it owns is item (c) of that list, which the library otherwise makes at first use and keeps until the process ends:
+ * `desta_create` checks that `device` is a gfx950 part (the only code objects in the library), makes it current and creates
+ * the internal stream / events up front (so a later hipGraph capture never meets a stream creation); `desta_destroy`
+ * drains and releases them.  `desta_handle_last_error` = `desta_last_error()` of the calling thread, copied into the handle. */
+typedef struct desta_context* desta_handle;
+int desta_create(int device, desta_handle* out);
+int desta_destroy(desta_handle h);
+int desta_handle_info(desta_handle h, int* device, int* compute_units, char* arch, size_t arch_bytes);
+const char* desta_handle_last_error(desta_handle h);
+
 /* ------------------------------------------------------------------------------------------
  * Dense contraction  C[M,N] = epi(alpha * A[M,K] · B[N,K]^T)   (bf16 in, fp32 accumulate, MFMA)
  *   epi(v) = act(v + bias[n]) + residual[m,n];  optional copy of (v + bias) before act -> preact.

@@ -25,6 +25,12 @@ flat ``{name: tensor}`` weight dict that uses the reference's own state-dict key
                        ``TF:modeling_rope_utils.py``), Qwen3 per-head q/k RMSNorm
                        ``TF:models/qwen3/modeling_qwen3.py:237-257``; loss
                        ``TF:loss/loss_utils.py:49-71``.
+* LoRA (use_lora) .... ``modeling_desta25.py:720-729``: ``peft.LoraConfig(r=16, lora_alpha=16, lora_dropout=0.1,
+                       target_modules=[q_proj, k_proj, v_proj])``.  ``peft`` is a third-party dependency that is neither
+                       vendored under /root/reference nor installed here (reference pin: ``peft`` without a version,
+                       ``setup.py``): PARITY UNPINNED for this branch.  Restated from the published LoRA layer:
+                       ``y = base(x) + lora_B(lora_A(dropout(x))) * (alpha / r)``, A ~ kaiming_uniform(a=sqrt 5), B = 0,
+                       adapter weights fp32 (peft casts bf16 adapters up), keys ``<module>.lora_{A,B}.default.weight``.
 * clip + Adafactor ... ``TF:trainer.py:1778-1797``; ``TF:optimization.py:1203-1294`` with the
                        Trainer kwargs ``scale_parameter=False, relative_step=False``.
 
@@ -124,6 +130,9 @@ class Dims:
     rope_llama3: Optional[Tuple[float, float, float, int]] = (8.0, 1.0, 4.0, 8192)  # factor, low, high, orig ctx
     qk_norm: bool = False                  # Qwen3
     tie_embeddings: bool = False
+    # LoRA on the decoder's q/k/v projections (modeling_desta25.py:720-729); 0 = off
+    lora_r: int = 0
+    lora_alpha: float = 16.0
 
     @property
     def qf_heads(self) -> int:             # num_attention_heads = encoder heads (modeling_desta25.py:158)
@@ -176,7 +185,15 @@ def trainable_names(d: Dims) -> List[str]:
         for lin in ("intermediate.dense", "output.dense", "output.LayerNorm"):
             names += [f"{p}{lin}.weight", f"{p}{lin}.bias"]
     names += [f"{CON}proj.0.weight", f"{CON}proj.0.bias", f"{CON}proj.1.weight", f"{CON}proj.1.bias"]
-    return names
+    return lora_names(d) + names            # llm_model is registered before perception (modeling_desta25.py:713, 732)
+
+
+def lora_names(d: Dims) -> List[str]:
+    """peft's parameter names under ``get_peft_model(...).base_model.model`` (``modeling_desta25.py:729``)."""
+    if not d.lora_r:
+        return []
+    return [f"{LLM}model.layers.{i}.self_attn.{m}_proj.lora_{ab}.default.weight"
+            for i in range(d.llm_layers) for m in "qkv" for ab in "AB"]
 
 
 def init_weights(d: Dims, seed: int = 0, scale: float = 1.0) -> Dict[str, Tensor]:
@@ -249,6 +266,14 @@ def init_weights(d: Dims, seed: int = 0, scale: float = 1.0) -> Dict[str, Tensor
     ln(LLM + "model.norm", d.llm_h, bias=False)
     if not d.tie_embeddings:
         lin(LLM + "lm_head", d.vocab, d.llm_h, bias=False)
+    # LoRA adapters.  peft initialises B = 0 (the adapter starts as the identity); a seeded non-zero B here so that parity
+    # tests exercise the path (tests that need the peft init zero it themselves).
+    if d.lora_r:
+        for i in range(d.llm_layers):
+            for m, out_f in (("q", d.llm_hq * d.llm_hd), ("k", d.llm_hkv * d.llm_hd), ("v", d.llm_hkv * d.llm_hd)):
+                p = f"{LLM}model.layers.{i}.self_attn.{m}_proj."
+                w[p + "lora_A.default.weight"] = (torch.rand(d.lora_r, d.llm_h, generator=g) * 2 - 1) / math.sqrt(d.llm_h)
+                w[p + "lora_B.default.weight"] = 0.3 * (torch.rand(out_f, d.lora_r, generator=g) * 2 - 1) / math.sqrt(d.lora_r)
     return w
 
 
@@ -454,8 +479,21 @@ def _rot_half(x):
     return torch.cat([-x[..., h:], x[..., :h]], dim=-1)
 
 
+def _lora_lin(w, d: Dims, name: str, h: Tensor, masks: Optional[dict]) -> Tensor:
+    """A q/k/v projection with its optional LoRA adapter: ``base(x) + lora_B(lora_A(dropout(x))) * alpha / r``.
+    ``masks[name]`` = keep mask [B,S,h] * 1/(1-p) of the adapter's OWN dropout module (training; None = eval / p = 0)."""
+    y = _lin(h, w[name + ".weight"])
+    a = w.get(name + ".lora_A.default.weight")
+    if a is None:
+        return y
+    x = h                                                            # peft casts x to the adapter dtype (fp32); under autocast the linear casts back to bf16
+    if masks is not None and masks.get(name) is not None:
+        x = x * masks[name].to(x.dtype)
+    return y + (_lin(_lin(x, a), w[name + ".lora_B.default.weight"]) * (d.lora_alpha / d.lora_r)).to(y.dtype)
+
+
 def llm_forward(w, d: Dims, inputs_embeds: Tensor, attention_mask: Tensor, keep: Optional[dict] = None,
-                position_ids: Optional[Tensor] = None) -> Tensor:
+                position_ids: Optional[Tensor] = None, lora_masks: Optional[dict] = None) -> Tensor:
     """Returns logits [B,S,V].  position_ids = arange(S) for every row (H7) unless given ([B,S], the
     generate() path); additive causal mask AND left-pad key mask, as ``create_causal_mask`` builds it."""
     B, S, _ = inputs_embeds.shape
@@ -479,9 +517,9 @@ def llm_forward(w, d: Dims, inputs_embeds: Tensor, attention_mask: Tensor, keep:
     for i in range(d.llm_layers):
         p = f"{LLM}model.layers.{i}."
         h = _rmsnorm(x, w[p + "input_layernorm.weight"], d.rms_eps)
-        q = _lin(h, w[p + "self_attn.q_proj.weight"]).view(B, S, d.llm_hq, d.llm_hd)
-        k = _lin(h, w[p + "self_attn.k_proj.weight"]).view(B, S, d.llm_hkv, d.llm_hd)
-        v = _lin(h, w[p + "self_attn.v_proj.weight"]).view(B, S, d.llm_hkv, d.llm_hd)
+        q = _lora_lin(w, d, p + "self_attn.q_proj", h, lora_masks).view(B, S, d.llm_hq, d.llm_hd)
+        k = _lora_lin(w, d, p + "self_attn.k_proj", h, lora_masks).view(B, S, d.llm_hkv, d.llm_hd)
+        v = _lora_lin(w, d, p + "self_attn.v_proj", h, lora_masks).view(B, S, d.llm_hkv, d.llm_hd)
         if d.qk_norm:
             q = _rmsnorm(q, w[p + "self_attn.q_norm.weight"], d.rms_eps)
             k = _rmsnorm(k, w[p + "self_attn.k_norm.weight"], d.rms_eps)
@@ -545,7 +583,7 @@ def causal_lm_loss(logits: Tensor, labels: Tensor) -> Tensor:
     return F.cross_entropy(logits.view(-1, logits.shape[-1]), labels.view(-1), ignore_index=-100, reduction="mean")
 
 
-def model_forward(w, d: Dims, batch: dict, keep: Optional[dict] = None):
+def model_forward(w, d: Dims, batch: dict, keep: Optional[dict] = None, lora_masks: Optional[dict] = None):
     """``DeSTA25AudioModel.forward`` (qformer_1 path): returns (loss|None, logits)."""
     ids, am = batch["input_ids"], batch["attention_mask"]
     feats = batch.get("batch_features")
@@ -556,7 +594,7 @@ def model_forward(w, d: Dims, batch: dict, keep: Optional[dict] = None):
     x = embed_splice(w, d, ids, af, batch.get("batch_transcription_ids", []), starts)
     if keep is not None:
         keep["inputs_embeds"] = x
-    logits = llm_forward(w, d, x, am, keep)
+    logits = llm_forward(w, d, x, am, keep, lora_masks=lora_masks)
     loss = causal_lm_loss(logits, batch["labels"]) if batch.get("labels") is not None else None
     return loss, logits
 

@@ -7,7 +7,7 @@ from safetensors.torch import load_file
 import desta_oracle as O
 
 
-def cfg_from_dims(d: O.Dims, dropout: float = 0.0):
+def cfg_from_dims(d: O.Dims, dropout: float = 0.0, **extra):
     from desta.models.modeling_desta25 import DeSTA25Config
     scaling = None
     if d.rope_llama3 is not None:
@@ -22,7 +22,7 @@ def cfg_from_dims(d: O.Dims, dropout: float = 0.0):
                encoder_ffn_dim=d.enc_ffn, max_source_positions=d.enc_T)
     return DeSTA25Config(llm_model_id="local-llm", encoder_model_id="local-whisper", llm_config=llm, encoder_config=enc,
                          qformer_num_hidden_layers=d.qf_layers, prompt_size=d.prompt_size,
-                         qformer_intermediate_size=d.qf_inter, target_layer_ids=list(d.taps), qformer_dropout=dropout)
+                         qformer_intermediate_size=d.qf_inter, target_layer_ids=list(d.taps), qformer_dropout=dropout, **extra)
 
 
 def golden_batch(golden_dir, name):

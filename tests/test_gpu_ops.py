@@ -629,3 +629,38 @@ def test_target_rows_and_scatter(hip):
     # no targets at all -> count 0
     hip.target_rows(torch.full((B, S), -100).cuda(), B, S, idx, lab, cnt)
     assert int(cnt) == 0 and lab[:2].cpu().tolist() == [-100, -100]
+
+
+@pytest.mark.gpu
+def test_context_create_info_destroy_and_attention_still_runs(hip):
+    """`desta_create` / `desta_handle_info` / `desta_handle_last_error` / `desta_destroy`: the context reports the
+    gfx950 device, an invalid device is refused with a message, and after `destroy` released the internal fork stream the
+    attention backward recreates it at first use (same result as before)."""
+    B, H, S, D = 2, 2, 128, 128
+    g = torch.Generator().manual_seed(3)
+    qkv = bf(torch.randn(B * S, 3 * H * D, generator=g)).cuda()
+    do = bf(torch.randn(B * S, H * D, generator=g)).cuda()
+
+    def run():
+        o = torch.zeros(B * S, H * D, dtype=torch.bfloat16, device="cuda")
+        lse = torch.zeros(B, H, S, device="cuda")
+        d = hip.attn_desc(qkv, qkv, qkv, o, lse, batch=B, hq=H, hkv=H, sq=S, sk=S, hd=D, scale=D ** -0.5, causal=True,
+                          q_off=0, k_off=H * D, v_off=2 * H * D)
+        hip.attention_fwd(d)
+        dqkv = torch.zeros(B * S, 3 * H * D, dtype=torch.bfloat16, device="cuda")
+        hip.attention_bwd(d, do, dqkv, dqkv, dqkv, dk_off=H * D, dv_off=2 * H * D)
+        torch.cuda.synchronize()
+        return o, dqkv
+
+    before = run()
+    ctx = hip.Context(0)
+    info = ctx.info()
+    assert info["device"] == 0 and info["arch"].startswith("gfx950") and info["compute_units"] == 256
+    with pytest.raises(RuntimeError):
+        hip.Context(99)
+    assert "device 99" in ctx.last_error()
+    ctx.close()
+    after = run()
+    for a, b in zip(before, after):
+        assert torch.equal(a, b)
+    torch.cuda.synchronize()

@@ -111,3 +111,36 @@ def test_true_width_shallow_depth_vs_oracle(which):
         worst_u = max(worst_u, e)
         assert e < 2e-3, (n, e)                            # error of the UPDATE itself (fp32 row / column statistics over up to 3.9 M elements)
     print(which, "adafactor worst update error", worst_u)
+
+
+def test_true_width_lora_adapters_vs_oracle():
+    """`use_lora=True` at the Llama-3.1-8B width (h 4096, q/k/v 4096 / 1024 / 1024, r = 16; 2 decoder layers): loss and every
+    gradient — adapters and connector — against fp32 autograd on the host (parity unpinned against peft itself, which is absent:
+    see tests/test_gpu_lora.py).  S = 207 is not a multiple of 64: the adapter gradients' token reductions run on zero-padded rows."""
+    from desta.models.modeling_desta25 import DeSTA25AudioModel
+    torch.set_num_threads(max(1, min(64, len(__import__("os").sched_getaffinity(0)))))
+    d = _dims("llama31-8B")
+    d.lora_r = 16
+    w = O.init_weights(d, seed=11)
+    batch = O.synthetic_batch(d, B=1, S_ctx=40, S_tgt=96, seed=3, pad=[7])
+    model = DeSTA25AudioModel(cfg_from_dims(d, use_lora=True, lora_dropout=0.0), weights=w)
+    names = O.trainable_names(d)
+    assert set(names) == set(model.trainable_parameter_names)
+    for n in names:
+        w[n].requires_grad_(True)
+    loss_o, _ = O.model_forward(w, d, batch)
+    loss_o.backward()
+    grads_o = {n: w[n].grad.detach().clone() for n in names}
+    out = model(**batch)
+    model.backward()
+    a = torch.cat([model.arena.grad(n).reshape(-1).double().cpu() for n in names])
+    b = torch.cat([grads_o[n].reshape(-1).double() for n in names])
+    lora = [n for n in names if ".lora_" in n]
+    al = torch.cat([model.arena.grad(n).reshape(-1).double().cpu() for n in lora])
+    bl = torch.cat([grads_o[n].reshape(-1).double() for n in lora])
+    errs = {n: float((model.arena.grad(n).double().cpu() - grads_o[n].double()).norm() / float(grads_o[n].double().norm())) for n in lora}
+    worst = max(errs, key=errs.get)
+    rec = dict(dloss=abs(float(out.loss) - float(loss_o)), grad=float((a - b).norm() / b.norm()), cos=float((a @ b) / (a.norm() * b.norm())),
+               lora_grad=float((al - bl).norm() / bl.norm()), worst_lora=(worst, round(errs[worst], 4)))
+    print("lora true width", rec)
+    assert rec["dloss"] < 8e-3 and rec["grad"] < 5e-2 and rec["cos"] > 0.999 and rec["lora_grad"] < 5e-2 and errs[worst] < 0.1, rec

@@ -211,3 +211,35 @@ def test_decay_mask_matches_trainer_rule():
     dec = get_parameter_names(m, [nn.LayerNorm], ["bias", "layernorm", "rmsnorm", "(?:^|\\.)norm(?:$|\\.)", "_norm(?:$|\\.)"])
     for n in names:
         assert mask[n] == (n in dec), n
+
+
+def test_lora_restatement_is_self_consistent():
+    """LoRA branch of the oracle (`use_lora`, reference modeling_desta25.py:720-729).  `peft` is absent here and not vendored in the
+    reference: PARITY UNPINNED against it.  What can be checked on the restatement of the published layer itself: (a) B = 0 (peft's
+    init) is the base model; (b) the adapter equals the merged weight W + (alpha / r) B A exactly in fp32; (c) the trainable names are
+    peft's, adapters first (llm_model is registered before perception); (d) a dropout mask enters only through the adapter branch."""
+    d = O.tiny_dims()
+    d.lora_r = 16
+    w = O.init_weights(d, seed=3)
+    batch = O.synthetic_batch(d, B=2, S_ctx=5, S_tgt=7, seed=9)
+    names = O.trainable_names(d)
+    assert names[0] == "llm_model.model.layers.0.self_attn.q_proj.lora_A.default.weight" and names[1].endswith("q_proj.lora_B.default.weight")
+    assert sum(".lora_" in n for n in names) == 6 * d.llm_layers
+    d0 = O.tiny_dims()
+    w0 = {k: v for k, v in w.items() if ".lora_" not in k}
+    with torch.no_grad():
+        loss, logits = O.model_forward(w, d, batch)
+        loss0, logits0 = O.model_forward(w0, d0, batch)
+        wz = {k: (torch.zeros_like(v) if ".lora_B." in k else v) for k, v in w.items()}
+        assert torch.equal(O.model_forward(wz, d, batch)[1], logits0)                          # (a)
+        wm = dict(w0)
+        for i in range(d.llm_layers):
+            for m in "qkv":
+                p = f"llm_model.model.layers.{i}.self_attn.{m}_proj."
+                wm[p + "weight"] = w[p + "weight"] + w[p + "lora_B.default.weight"] @ w[p + "lora_A.default.weight"] * (d.lora_alpha / d.lora_r)
+        lm = O.model_forward(wm, d0, batch)[1]
+        assert float((lm - logits).abs().max()) < 1e-4 and float((logits - logits0).abs().max()) > 1e-2   # (b)
+        S = batch["input_ids"].shape[1]
+        masks = {f"llm_model.model.layers.0.self_attn.q_proj": torch.zeros(2, S, d.llm_h)}        # drop everything: q of layer 0 loses its adapter
+        wq = {k: (torch.zeros_like(v) if k == "llm_model.model.layers.0.self_attn.q_proj.lora_B.default.weight" else v) for k, v in w.items()}
+        assert torch.allclose(O.model_forward(w, d, batch, lora_masks=masks)[1], O.model_forward(wq, d, batch)[1], atol=1e-6)   # (d)
