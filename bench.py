@@ -276,6 +276,7 @@ def main():
     ap.add_argument("--attn-r2-backward", action="store_true", help="A/B: attention backward on round 2's kernels (separate delta, 4-wave dQ beside dK/dV); implies --no-rope-fusion")
     ap.add_argument("--attn-r2-forward", action="store_true", help="A/B: attention forward AND backward on round 2's 4-wave kernels; implies --no-rope-fusion")
     ap.add_argument("--lora", action="store_true", help="NOT the headline config: the reference's optional use_lora=True (rank-16 adapters on q/k/v of every decoder layer, full-row backward)")
+    ap.add_argument("--no-dead-row-skip", action="store_true", help="A/B: the last decoder layer's o_proj / MLP (forward and backward) on every row instead of the target tail, layer 0's input gradient on every row instead of the audio rows")
     ap.add_argument("--full-lm-head", action="store_true", help="A/B: lm_head / CE over the whole token grid, not only the target rows")
     a = ap.parse_args()
 
@@ -344,6 +345,8 @@ def main():
         model.connector.overlap_dw = False
     if a.full_lm_head:
         model.compact_lm_head = False
+    if a.no_dead_row_skip:
+        model.llm.skip_dead_rows = False
     if a.no_rope_fusion or a.attn_r2_backward or a.attn_r2_forward:
         model.llm.fuse_rope = False
     if a.attn_r2_backward:

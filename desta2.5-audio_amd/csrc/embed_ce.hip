@@ -47,14 +47,18 @@ __global__ __launch_bounds__(1024) void target_rows_k(const long* __restrict__ l
     __shared__ int part[1024];
     const int M = B * S, tid = threadIdx.x;
     const int per = (M + 1023) / 1024, m0 = tid * per, m1 = min(M, m0 + per);
-    int n = 0;
-    for (int m = m0; m < m1; ++m) n += ((m % S) + 1 < S && labels[m + 1] != -100) ? 1 : 0;
+    __shared__ int first[1024];
+    int n = 0, f = S;                                           // f: first POSITION (m % S) among this thread's target rows
+    for (int m = m0; m < m1; ++m)
+        if ((m % S) + 1 < S && labels[m + 1] != -100) { ++n; f = min(f, m % S); }
     part[tid] = n;
+    first[tid] = f;
     __syncthreads();
     if (tid == 0) {
-        int run = 0;
-        for (int i = 0; i < 1024; ++i) { const int v = part[i]; part[i] = run; run += v; }
-        *count = run;
+        int run = 0, fmin = S;
+        for (int i = 0; i < 1024; ++i) { const int v = part[i]; part[i] = run; run += v; fmin = min(fmin, first[i]); }
+        count[0] = run;
+        count[1] = fmin;                                        // rows of positions < fmin carry no target in any sequence
         lab[0] = -100;
         lab[1 + run] = -100;
     }

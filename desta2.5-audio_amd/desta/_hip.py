@@ -40,7 +40,7 @@ class GemmDesc(C.Structure):
 
 lib.desta_abi_version.restype = i32
 lib.desta_last_error.restype = C.c_char_p
-ABI_VERSION = 4
+ABI_VERSION = 5
 if lib.desta_abi_version() != ABI_VERSION:
     raise ImportError(f"libdesta_hip.so has ABI version {lib.desta_abi_version()}, this binding needs {ABI_VERSION}: "
                       "rebuild with `python desta2.5-audio_amd/build.py`")
@@ -647,5 +647,6 @@ def scatter_rows(src, idx, rows, hidden, out):
 
 
 def target_rows(labels, batch, seq, idx, compact_labels, count, s_major=False):
-    """Rows with a real shifted target -> idx / compact label layout / device count (see include/desta_hip.h)."""
+    """Rows with a real shifted target -> idx / compact label layout / device count int32[2] = (n, first position with a target)
+    (see include/desta_hip.h)."""
     check(_target_rows(p(labels), batch, seq, p(idx), p(compact_labels), p(count), int(s_major), stream()), "desta_target_rows")

@@ -695,6 +695,7 @@ class CausalLMHIP:
         self.fuse_rope = not c.qk_norm              # A/B switch (bench.py --no-rope-fusion); q/k-norm models (Qwen3) keep the rope kernel
         self.B = self.S = 0
         self.lora = None
+        self.skip_dead_rows = True                  # A/B switch (bench.py --no-dead-row-skip): last layer on the target tail, layer-0 dX on the audio rows
 
     # -- LoRA adapters on q/k/v (reference: peft, modeling_desta25.py:720-729; published layer: y = W x + (alpha / r) B A drop(x)) --------
     LORA_KP = 64                                    # the three rank-r adapters side by side, padded to one 64-wide GEMM K block
@@ -855,8 +856,15 @@ class CausalLMHIP:
         if self.lora is not None:
             self.refresh_lora()
             self.lora["p_now"] = self.lora["p"] if need_grad else 0.0
+        # rows of the LAST layer's output that anything reads: with the compact lm_head only the target rows, which in the
+        # position-major grid are the contiguous tail [first target position * B, M) (left padding aligns every sequence's end).
+        # o_proj, the MLP and the final norm of the last layer run on that tail only (its attention still sees every key).
+        self.tail0 = 0
         for i, (ly, s) in enumerate(zip(self.layers, self.sv)):
             x = self.xs[i]
+            if i == self.L - 1 and target_rows is not None and self.s_major and self.skip_dead_rows and self.L > 1:
+                target_rows[3].synchronize()                                   # side stream of `_target_rows`: long done
+                self.tail0 = min(int(target_rows[2][1]), S) * B
             H.rmsnorm_fwd(x, ly["n1"], c.rms_norm_eps, self.hb, s["r1"])
             if fused:
                 H.gemm(self.hb, ly["wqkv_il"], s["qkv"], M, self.qkvw, h,
@@ -884,14 +892,19 @@ class CausalLMHIP:
                              v_bs=self.qkvw if s_major else None, o_bs=aw if s_major else None)
             H.attention_fwd(ad)
             s["ad"] = ad
-            H.gemm(s["att"], ly["wo"], s["xm"], M, h, self.hq * self.hd, residual=x)
-            H.rmsnorm_fwd(s["xm"], ly["n2"], c.rms_norm_eps, self.hb, s["r2"])
-            # (the GEMM also has fused SwiGLU epilogues, act=2/3; measured SLOWER here: with one 256x256 block
-            #  per CU the extra epilogue traffic is not overlapped, the streaming kernels run at HBM rate)
-            H.gemm(self.hb, ly["wgu"], s["gu"], M, 2 * self.I, h)
-            H.swiglu_fwd(s["gu"], self.act, M, self.I)
-            H.gemm(self.act, ly["wd"], self.xs[i + 1], M, h, self.I, residual=s["xm"])
-        H.rmsnorm_fwd(self.xs[self.L], self.norm, c.rms_norm_eps, self.hb, self.rf)
+            t0 = self.tail0 if i == self.L - 1 else 0
+            Mt = M - t0
+            if Mt > 0:
+                H.gemm(s["att"][t0:], ly["wo"], s["xm"][t0:], Mt, h, self.hq * self.hd, residual=x[t0:])
+                H.rmsnorm_fwd(s["xm"][t0:], ly["n2"], c.rms_norm_eps, self.hb[t0:], s["r2"][t0:])
+                # (the GEMM also has fused SwiGLU epilogues, act=2/3; measured SLOWER here: with one 256x256 block
+                #  per CU the extra epilogue traffic is not overlapped, the streaming kernels run at HBM rate)
+                H.gemm(self.hb[t0:], ly["wgu"], s["gu"][t0:], Mt, 2 * self.I, h)
+                H.swiglu_fwd(s["gu"][t0:], self.act[t0:], Mt, self.I)
+                H.gemm(self.act[t0:], ly["wd"], self.xs[i + 1][t0:], Mt, h, self.I, residual=s["xm"][t0:])
+        t0 = self.tail0
+        if M - t0 > 0:
+            H.rmsnorm_fwd(self.xs[self.L][t0:], self.norm, c.rms_norm_eps, self.hb[t0:], self.rf[t0:])
         if last_logits is not None:                      # rows b*S + S-1 only: A is a strided view of hb
             H.gemm(self.hb[S - 1:], self.head, last_logits, B, self.V, h, lda=S * h, ldc=self.Vp)
             return last_logits
@@ -1023,15 +1036,20 @@ class CausalLMHIP:
         H.causal_lm_loss(self.logits, self.Vp, labels, self.B, self.S, self.V, self.loss, write_grad=write_grad)
         return self.loss
 
-    def backward(self, first_needed_pos: int = 0) -> torch.Tensor:
+    def backward(self, first_needed_pos: int = 0, out_rows: Optional[Tuple[int, int]] = None) -> torch.Tensor:
         """dlogits (in self.logits) -> dL/d inputs_embeds [B*S, h] bf16.  In the position-major training layout only the rows of
         positions >= first_needed_pos (the first audio span of the batch) are propagated: the rows in front of it are frozen
-        text embeddings whose gradient nothing consumes (under the causal mask they do not feed any needed row either)."""
+        text embeddings whose gradient nothing consumes (under the causal mask they do not feed any needed row either).
+        Two more dead-row cuts in that layout: (a) the last layer's gradient is zero in front of the first target position
+        (`tail0`, set by forward), so its MLP / o_proj backward runs on the tail only; (b) `out_rows` = (first, last + 1) positions
+        of the audio spans: the caller reads d inputs_embeds at those rows only, so layer 0's q|k|v input gradient and norm
+        backward run on them alone (every other row of the returned buffer is then unspecified)."""
         c, h, M, S, B = self.c, self.h, self.M, self.S, self.B
         if self.lora is not None:
-            first_needed_pos = 0             # adapter gradients of the keys / values in front of the first audio span
+            first_needed_pos, out_rows = 0, None             # adapter gradients of the keys / values in front of the first audio span
         r0 = first_needed_pos * B if self.s_major else 0
         Mr = M - r0
+        tl = max(self.tail0, r0) if self.s_major else r0        # last layer: rows [r0, tl) have zero gradient (forward skipped them)
         smb = B if self.s_major else 0
         dhb = self.hb
         if getattr(self, "compact", None) is not None and self.compact[2] == 0:
@@ -1045,15 +1063,24 @@ class CausalLMHIP:
         else:
             H.gemm(self.logits, self.headT, dhb, M, h, self.Vp, ldb=self.Vp)
         dx, other = self.dxa, self.dxb
-        H.rmsnorm_bwd(dhb[r0:], self.xs[self.L][r0:], self.norm, self.rf[r0:], dx[r0:])
+        if tl > r0:
+            # forward skipped these rows of the last layer (stale activations): their gradients are exactly zero
+            dx[r0:tl].zero_()
+            other[r0:tl].zero_()
+            self.datt[r0:tl].zero_()
+        if M - tl > 0:
+            H.rmsnorm_bwd(dhb[tl:], self.xs[self.L][tl:], self.norm, self.rf[tl:], dx[tl:])
         aw = self.hq * self.hd
         for i in reversed(range(self.L)):
             ly, s = self.layers[i], self.sv[i]
-            H.gemm(dx[r0:], ly["wdT"], self.act[r0:], Mr, self.I, h)                          # d act
-            H.swiglu_bwd(s["gu"][r0:], self.act[r0:], self.dgu[r0:], Mr, self.I)
-            H.gemm(self.dgu[r0:], ly["wguT"], dhb[r0:], Mr, h, 2 * self.I)
-            H.rmsnorm_bwd(dhb[r0:], s["xm"][r0:], ly["n2"], s["r2"][r0:], other[r0:], dres=dx[r0:])   # other := d x_mid
-            H.gemm(other[r0:], ly["woT"], self.datt[r0:], Mr, aw, h)
+            a0 = tl if i == self.L - 1 else r0                                                # first row with a non-zero d(layer output)
+            Ma = M - a0
+            if Ma > 0:
+                H.gemm(dx[a0:], ly["wdT"], self.act[a0:], Ma, self.I, h)                      # d act
+                H.swiglu_bwd(s["gu"][a0:], self.act[a0:], self.dgu[a0:], Ma, self.I)
+                H.gemm(self.dgu[a0:], ly["wguT"], dhb[a0:], Ma, h, 2 * self.I)
+                H.rmsnorm_bwd(dhb[a0:], s["xm"][a0:], ly["n2"], s["r2"][a0:], other[a0:], dres=dx[a0:])   # other := d x_mid
+                H.gemm(other[a0:], ly["woT"], self.datt[a0:], Ma, aw, h)
             # attention backward runs on the whole grid (rows < r0 of datt stay zero; their dQ / the dK,dV of those keys are unused)
             fused = getattr(self, "_rope_fused", False)
             rcs = self.cos_sin_il if fused else None                 # fused: dQ / dK leave the attention backward already rotated back
@@ -1067,10 +1094,13 @@ class CausalLMHIP:
             if not fused:
                 H.rope(self.dqkv, self.qkvw, M, S, self.hq, self.hkv, self.hd, self.cos_sin, ly.get("qn"), ly.get("kn"), c.rms_norm_eps,
                        pre_norm=s.get("pre"), ld_pre=self.qkvw, backward=True, s_major_batch=smb)
-            H.gemm(self.dqkv[r0:], ly["wqkvT_il" if fused else "wqkvT"], dhb[r0:], Mr, h, self.qkvw)
+            o0, o1 = r0, M
+            if i == 0 and out_rows is not None and self.s_major and self.skip_dead_rows:
+                o0, o1 = max(r0, out_rows[0] * B), min(M, out_rows[1] * B)                    # d inputs_embeds is read at the audio rows only
+            H.gemm(self.dqkv[o0:], ly["wqkvT_il" if fused else "wqkvT"], dhb[o0:], o1 - o0, h, self.qkvw)
             if self.lora is not None:
                 self._lora_bwd(i, ly, s, dhb, M)
-            H.rmsnorm_bwd(dhb[r0:], self.xs[i][r0:], ly["n1"], s["r1"][r0:], dx[r0:], dres=other[r0:])   # dx := d x_in
+            H.rmsnorm_bwd(dhb[o0:o1], self.xs[i][o0:o1], ly["n1"], s["r1"][o0:o1], dx[o0:o1], dres=other[o0:o1])   # dx := d x_in
         return dx
 
 
@@ -1453,12 +1483,12 @@ class DeSTA25AudioModel:
         dev = self.device
         if self._tr_stream is None:
             self._tr_stream = torch.cuda.Stream(device=dev)
-            self._tr_count_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._tr_count_host = torch.zeros(2, dtype=torch.int32).pin_memory()     # (rows with a target, first position with a target)
         M = B * S
         if self._tr_idx is None or self._tr_idx.numel() < M:
             self._tr_idx = torch.empty(M, dtype=torch.int32, device=dev)
             self._tr_lab = torch.empty(M + 2, dtype=torch.int64, device=dev)
-            self._tr_count = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._tr_count = torch.zeros(2, dtype=torch.int32, device=dev)
         main = torch.cuda.current_stream(dev)
         lab_dev = labels.to(dev).contiguous()
         self._tr_labels_keep = lab_dev                                           # alive until the side stream has read it
@@ -1568,7 +1598,8 @@ class DeSTA25AudioModel:
         K, S, B = self.config.prompt_size, f["S"], f["B"]
         with torch.cuda.device(self.device):
             if f["s_major"] and f["starts"]:
-                dx0 = self.llm.backward(first_needed_pos=min(s for _, s in f["starts"]))
+                dx0 = self.llm.backward(first_needed_pos=min(s for _, s in f["starts"]),
+                                        out_rows=(min(s for _, s in f["starts"]), max(s for _, s in f["starts"]) + K))
             else:
                 dx0 = self.llm.backward()
             if f["N_audio"] == 0:

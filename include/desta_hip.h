@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DESTA_ABI_VERSION 4
+#define DESTA_ABI_VERSION 5
 
 int desta_abi_version(void);
 /* sizeof of the descriptor structs as this library was compiled (0 = desta_gemm_desc, 1 = desta_attn_desc,
@@ -327,7 +327,8 @@ int desta_dropout_mask_u8(uint64_t seed, int64_t n, float p, uint8_t* out, void*
 /* lm_head on target rows only.  `ForCausalLMLoss` (TF:loss/loss_utils.py:49-71) ignores every row whose shifted label is
  * -100, so the logits of those rows (context, audio span, last position: 20 % of the synthetic batch, more on real data)
  * and their zero gradients need not be computed.  desta_target_rows lists the rows of the [batch*seq] grid that carry a
- * target (idx, in order; *count = n) and lays their targets out as compact_labels[0] = -100, [1 + i] = target of compact
+ * target (idx, in order; count[0] = n, count[1] = the first POSITION s that carries a target in any sequence, seq if none:
+ * `count` is int32[2] since ABI 5) and lays their targets out as compact_labels[0] = -100, [1 + i] = target of compact
  * row i, [1 + n] = -100 (room for batch*seq + 2 entries): desta_causal_lm_loss(batch = 1, seq = n + 1) on a compact
  * [n + 1, vocab] logits buffer then gives the same loss / gradients as the full grid.  desta_scatter_rows_bf16 is the
  * inverse of desta_gather_rows_bf16 (out[idx[i]] = in[i]). */

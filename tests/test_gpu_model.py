@@ -583,3 +583,34 @@ def test_local_hf_checkpoint_directories_load_like_transformers_wrote_them(tmp_p
     m = batch["attention_mask"].bool()
     assert abs(float(out.loss) - float(loss_o)) < 2e-2, (float(out.loss), float(loss_o))
     assert rel_err(out.logits.float().cpu()[m], logits_o[m]) < 3e-2
+
+
+@pytest.mark.parametrize("name", ["llama", "qwen3"])
+def test_dead_row_skip_equals_every_row(name):
+    """Training fast path, position-major grid: the last decoder layer's o_proj / MLP / final norm (forward and backward) run on
+    the tail of rows from the first target position on, and layer 0's input gradient on the audio rows only.  Both cuts drop
+    rows whose values nothing reads (resp. whose gradient is exactly zero): loss and every gradient equal the run over every
+    row.  Batch with left padding (different audio starts per sequence) and target spans of different lengths."""
+    d = O.tiny_dims(name == "qwen3")
+    d.llm_layers = 3
+    model, w = _model(d)
+    batch = O.synthetic_batch(d, B=3, S_ctx=9, S_tgt=40, seed=5, pad=[0, 7, 2])
+    S = batch["input_ids"].shape[1]
+    batch["labels"][1, : S - 25] = -100                               # sequence 1: 25 targets, the others 40
+    batch["labels"][2, S - 3:] = -100                                 # sequence 2 ends with ignored positions
+    res = {}
+    model(**batch)                                                    # allocates the activation buffers
+    for skip in (True, False):
+        model.llm.skip_dead_rows = skip
+        for x in (model.llm.xs[-1], model.llm.hb, model.llm.act, model.llm.dxa, model.llm.dxb, model.llm.sv[-1]["xm"], model.llm.sv[-1]["gu"]):
+            x.fill_(float("nan"))                                     # anything that reads a skipped row would show
+        out = model(**batch)
+        assert (model.llm.tail0 == (S - 40 - 1) * 3) == skip, model.llm.tail0
+        model.backward()
+        res[skip] = (float(out.loss), model.arena.grads.clone())
+    assert res[True][0] == res[False][0]
+    ga, gb = res[True][1].double(), res[False][1].double()
+    assert torch.isfinite(ga).all()
+    assert float((ga - gb).norm() / gb.norm()) < 1e-3, float((ga - gb).norm() / gb.norm())
+    loss_o, _ = O.model_forward(w, d, batch)
+    assert abs(res[True][0] - float(loss_o)) < 2e-2

@@ -603,10 +603,11 @@ def test_target_rows_and_scatter(hip):
     labels[4] = -100
     idx = torch.full((B * S,), -1, dtype=torch.int32, device="cuda")
     lab = torch.full((B * S + 2,), 7, dtype=torch.int64, device="cuda")
-    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(2, dtype=torch.int32, device="cuda")            # (n, first position that carries a target in any sequence)
     hip.target_rows(labels.cuda(), B, S, idx, lab, cnt)
     ref = [(b * S + s, int(labels[b, s + 1])) for b in range(B) for s in range(S - 1) if labels[b, s + 1] != -100]
-    n = int(cnt)
+    n = int(cnt[0])
+    assert int(cnt[1]) == min(r % S for r, _ in ref) == 8
     assert n == len(ref) and idx[:n].cpu().tolist() == [r for r, _ in ref]
     assert lab[:n + 2].cpu().tolist() == [-100] + [t for _, t in ref] + [-100]
     # CE on compact logits == CE on the full grid (loss and the gradient rows)
@@ -628,7 +629,7 @@ def test_target_rows_and_scatter(hip):
     assert idx_s[:n].cpu().tolist() == [(r % S) * B + r // S for r, _ in ref]
     # no targets at all -> count 0
     hip.target_rows(torch.full((B, S), -100).cuda(), B, S, idx, lab, cnt)
-    assert int(cnt) == 0 and lab[:2].cpu().tolist() == [-100, -100]
+    assert cnt.cpu().tolist() == [0, S] and lab[:2].cpu().tolist() == [-100, -100]
 
 
 @pytest.mark.gpu
