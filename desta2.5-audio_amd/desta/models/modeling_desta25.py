@@ -1584,9 +1584,7 @@ class DeSTA25AudioModel:
         GEMMs, LayerNorms, cross-attention) leave most of the chip idle, and nothing of the NEXT batch's frozen Whisper forward
         depends on them: the trainer runs this half on its side stream beside that forward (`overlap_comm`)."""
         with torch.cuda.device(self.device):
-            if d_af is None:                       # use_lora, batch without audio: only the adapters have a gradient
-                end = min((self.arena.offsets[n] for n in self.arena.names if ".lora_" in n), default=self.arena.numel)
-                self.arena.grads[:end].zero_()
+            if d_af is None:                       # use_lora, batch without audio: `backward_llm` zeroed the connector's gradients
                 return
             self.connector.backward(d_af)
 
@@ -1602,7 +1600,9 @@ class DeSTA25AudioModel:
                                         out_rows=(min(s for _, s in f["starts"]), max(s for _, s in f["starts"]) + K))
             else:
                 dx0 = self.llm.backward()
-            if f["N_audio"] == 0:
+            if f["N_audio"] == 0:                  # use_lora, batch without audio: only the adapters have a gradient
+                end = min((self.arena.offsets[n] for n in self.arena.names if ".lora_" in n), default=self.arena.numel)
+                self.arena.grads[:end].zero_()
                 self._fwd = None
                 return None
             idx = self._audio_slots(f["starts"], B, S, f["s_major"])[2]

@@ -210,3 +210,30 @@ def test_lora_training_steps_checkpoint_keys_and_resume(tmp_path):
     tr2.resume_from_checkpoint(ck)
     rest2 = [float(tr2.training_step(b)) for b in batches[3:]]
     assert rest == rest2 and torch.equal(model.arena.params, model2.arena.params)
+
+
+def test_lora_batch_without_audio_trains_the_adapters_only():
+    """A text-only batch (no audio span): the connector has no gradient (zeros, where the reference leaves `.grad` None) and the
+    adapters get theirs — loss and adapter gradients against the oracle."""
+    d = _dims()
+    model, w = _model(d)
+    names = model.trainable_parameter_names
+    g = torch.Generator().manual_seed(4)
+    B, S = 2, 24
+    ids = torch.randint(3, d.vocab, (B, S), generator=g)
+    labels = ids.clone()
+    labels[:, :10] = -100
+    batch = {"input_ids": ids, "attention_mask": torch.ones(B, S, dtype=torch.long), "labels": labels, "batch_start_positions": [],
+             "batch_transcription_ids": [], "batch_features": torch.zeros(0, d.n_mels, 2 * d.enc_T)}
+    lora = [n for n in names if ".lora_" in n]
+    loss_o, _, grads = _oracle_grads(w, d, batch, lora)
+    model.arena.grads.fill_(7.0)
+    out = model(**batch)
+    assert abs(float(out.loss) - loss_o) < 2e-2
+    model.backward()
+    for n in names:
+        if ".lora_" not in n:
+            assert float(model.arena.grad(n).abs().max()) == 0.0, n
+    a = torch.cat([model.arena.grad(n).reshape(-1).double().cpu() for n in lora])
+    b = torch.cat([grads[n].reshape(-1).double() for n in lora])
+    assert float((a - b).norm() / b.norm()) < 3e-2 and float((a @ b) / (a.norm() * b.norm())) > 0.999
