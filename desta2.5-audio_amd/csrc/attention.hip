@@ -1310,6 +1310,227 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkdv_k(AttnArgs
         }
 }
 
+// ------------------------------------------------------------------------------------------ backward, ONE query tile (seq_q <= 64, D = 64): dQ, dK, dV in one pass
+// The Q-Former's cross-attention (64 queries over 1500 encoder frames, 640 (batch, head) pairs per launch) is HBM-bound: K / V
+// are 246 MB, dK / dV another 246 MB.  The two-kernel backward reads K / V twice (the dQ kernel re-computes S and dP) and
+// re-fetches Q / dO per 128-key block: 930 MB of traffic, 260 us.  With a single query tile a block can own the WHOLE query
+// range: it walks a chunk of key blocks, stages each K / V tile once (coalesced, through LDS), forms S and dP, emits dK / dV
+// of that block and keeps dQ = sum_keys dS K in registers across the walk.  The keys of a (batch, head) are cut into `nch`
+// chunks (work items = nch x batch x heads, equal length) whose dQ partials are summed in fixed order by attn_dq_sum_k:
+// K / V read once, dK / dV written once, + 2 x nch x 16 KB per (batch, head) of partials.  No atomics: bit-identical run to run.
+// block = 4 waves, wave w owns keys [128 kb + 32 w, +32) of every key block kb of its chunk.
+template <bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_q64_k(AttnArgs p, float* __restrict__ dq_part, int blocks_per_chunk) {
+    constexpr int D = 64, WREG = 12288;
+    __shared__ __attribute__((aligned(16))) char lds[2 * 64 * D * 2 + 4 * WREG + 2 * 64 * 4];
+    char* qimg = lds;                                                       // [64 q][64 d]
+    char* gimg = lds + 64 * D * 2;                                          // dO
+    char* wreg = lds + 2 * 64 * D * 2;                                      // per wave: its 32 K rows | its 32 V rows | dS [32 keys][64 q]  (= 12 KB, re-used as the 32 x 64 fp32 epilogue tile)
+    float* lse_s = (float*)(wreg + 4 * WREG);
+    float* dlt_s = lse_s + 64;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h2 = lane >> 5;
+    const int nbh = p.B * p.Hq;
+    const int chunk = blockIdx.x / nbh, bh = blockIdx.x % nbh, b = bh / p.Hq, h = bh % p.Hq;
+    const int nkb = (p.Sk + 127) / 128;
+    const int kb_lo = chunk * blocks_per_chunk, kb_hi = min(kb_lo + blocks_per_chunk, nkb);
+    const int kv_lo = p.kv_start ? max(0, min(p.kv_start[b], p.Sk)) : 0;
+    char* kimg_w = wreg + wave * WREG;
+    char* vimg_w = kimg_w + 4096;
+    char* dsimg_w = kimg_w + 8192;
+    const bf16_t* kbase = p.K + (long)b * p.k_bs + (long)h * D;
+    const bf16_t* vbase = p.V + (long)b * p.v_bs + (long)h * D;
+
+    // the query tile, once
+    {
+        const stage_t<D, 64> qr = tile_load<D, 64>(p.Q + (long)b * p.q_bs + (long)h * D, p.q_rs, 0, p.Sq - 1);
+        const stage_t<D, 64> gr = tile_load<D, 64>(p.dO + (long)b * p.do_bs + (long)h * D, p.do_rs, 0, p.Sq - 1);
+        tile_store<D, 64>(qimg, qr);
+        tile_store<D, 64>(gimg, gr);
+        if (threadIdx.x < 64) {
+            const long st_ = ((long)b * p.Hq + h) * p.Sq + min((int)threadIdx.x, p.Sq - 1);
+            lse_s[threadIdx.x] = p.lse[st_];
+            dlt_s[threadIdx.x] = p.delta[st_];
+        }
+    }
+    // dQ: wave w owns the 32 x 32 tile (query slice w >> 1, d half w & 1) over ALL 128 keys of a block (every wave's dS image and K rows
+    // are in LDS anyway): 16 accumulator registers instead of 64 for per-wave partials, and no cross-wave sum at the end
+    const int qa = wave >> 1, di = wave & 1;
+    f32x16 dq;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+
+    stage_t<D, 128> kst = {}, vst = {};
+    if (kb_lo < kb_hi) {
+        kst = tile_load<D, 128>(kbase, p.k_rs, kb_lo * 128, p.Sk - 1);
+        vst = tile_load<D, 128>(vbase, p.v_rs, kb_lo * 128, p.Sk - 1);
+    }
+    const unsigned long hb = ((unsigned long)b * p.Hq + h) * p.Sq;
+    bf16_t* dkp = p.dK + (long)b * p.dk_bs + (long)h * D;
+    bf16_t* dvp = p.dV + (long)b * p.dv_bs + (long)h * D;
+
+    for (int kb = kb_lo; kb < kb_hi; ++kb) {
+        __syncthreads();                                                    // every wave is done with its region (epilogue tile of the previous block) / the query images are written
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                                       // 128 x 64 tile: row r of the tile lives in the region of wave r >> 5
+            const int id = i * 256 + threadIdx.x, r = id >> 3, c = id & 7;
+            char* dst = wreg + (r >> 5) * WREG + img_off<D>(r & 31, c);
+            *(uint4*)dst = make_uint4(kst[4 * i + 0], kst[4 * i + 1], kst[4 * i + 2], kst[4 * i + 3]);
+            *(uint4*)(dst + 4096) = make_uint4(vst[4 * i + 0], vst[4 * i + 1], vst[4 * i + 2], vst[4 * i + 3]);
+        }
+        __syncthreads();
+        if (kb + 1 < kb_hi) {                                               // next tile: in flight during this block's arithmetic and epilogue
+            kst = tile_load<D, 128>(kbase, p.k_rs, (kb + 1) * 128, p.Sk - 1);
+            vst = tile_load<D, 128>(vbase, p.v_rs, (kb + 1) * 128, p.Sk - 1);
+        }
+        const int k0 = kb * 128 + wave * 32, kcol = k0 + (lane & 31);
+        const bool key_ok = kcol < p.Sk && kcol >= kv_lo;
+        f32x16 dk[2], dv[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+#pragma unroll 1
+        for (int sub = 0; sub < 2; ++sub) {                                 // (not unrolled: both slices in flight at once spill)
+            const int qb = sub * 32;
+            if (qb >= p.Sq) {                                                // (wave-uniform) slice past the end: its dS is zero
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *(uint2*)(dsimg_w + img_off<D>(lane & 31, sub * 4 + j) + 8 * h2) = make_uint2(0u, 0u);
+                continue;
+            }
+            unsigned keep = 0xffffu;                                         // (hashes first: nothing else is live yet)
+            if constexpr (DROP) {                                            // same element -> hash map as attn_bwd_dkdv_k (adjacent keys share one hash)
+                keep = 0;
+                const int half = lane & 1, kpair = k0 + (lane & 30);
+                unsigned hh[8];
+                const unsigned long e0 = (hb + qb) * p.Sk + kpair;            // element index of (query qb, key pair); rows >= Sq are masked below, their bits are unused
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int ql = (j & 3) + 8 * (2 * half + (j >> 2)) + 4 * h2;
+                    hh[j] = desta_rng32(p.seed_lo, p.seed_hi, (e0 + (unsigned)(ql * p.Sk)) >> 1);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned oth = (unsigned)__builtin_amdgcn_mov_dpp((int)hh[j], 0xB1, 0xf, 0xf, true);
+                    const unsigned mine = half ? (hh[j] >> 16) : (hh[j] & 0xffffu), theirs = half ? (oth >> 16) : (oth & 0xffffu);
+                    keep |= (mine >= p.drop_thresh ? 1u : 0u) << (8 * half + j);
+                    keep |= (theirs >= p.drop_thresh ? 1u : 0u) << (8 * (1 - half) + j);
+                }
+            }
+            if constexpr (DROP) asm volatile("" : "+v"(keep));               // keep the hash arithmetic in front of the accumulators' live range
+            f32x16 st, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ds = 0; ds < D / 16; ++ds) {
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(qimg, qb, ds, lane), frag_rows<D>(kimg_w, 0, ds, lane), st, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(gimg, qb, ds, lane), frag_rows<D>(vimg_w, 0, ds, lane), dp, 0, 0, 0);
+            }
+            // st[r]: S[q = qb + acc_row(r)][key = kcol]
+            const bool need_mask = (qb + 31 >= p.Sq) || (k0 + 31 >= p.Sk) || (k0 < kv_lo);
+            if (need_mask) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = key_ok && (qb + acc_row(r, lane)) < p.Sq;
+                    st[r] = ok ? st[r] : -INFINITY;
+                }
+            }
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {                                 // this lane's rows: 4 runs of 4 consecutive queries (acc_row)
+                const float4 a4 = *(const float4*)(lse_s + qb + 8 * q4 + 4 * h2);
+                const float4 b4 = *(const float4*)(dlt_s + qb + 8 * q4 + 4 * h2);
+                const float ls4[4] = {a4.x, a4.y, a4.z, a4.w}, dl4[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * q4 + e;
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(st[r], p.scale_log2, -ls4[e]));
+                    float ms = 1.0f;
+                    if constexpr (DROP) ms = ((keep >> r) & 1u) ? p.drop_scale : 0.f;
+                    st[r] = pv * ms;                                         // (dropped) P for dV
+                    dp[r] = pv * (ms * dp[r] - dl4[e]) * p.scale;            // dS
+                }
+            }
+            // dS of this slice -> the wave's [key][q] image (row = this lane's key): 4 runs of 4 consecutive query rows
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned lo = (unsigned)f2bf(dp[4 * j + 0]) | ((unsigned)f2bf(dp[4 * j + 1]) << 16);
+                const unsigned hi = (unsigned)f2bf(dp[4 * j + 2]) | ((unsigned)f2bf(dp[4 * j + 3]) << 16);
+                *(uint2*)(dsimg_w + img_off<D>(lane & 31, sub * 4 + j) + 8 * h2) = make_uint2(lo, hi);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pf = acc_frag(st, s2), dsf = acc_frag(dp, s2);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    dv[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, frag_tr<D>(gimg, qb + 16 * s2, i * 32, lane), dv[i], 0, 0, 0);
+                    dk[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf, frag_tr<D>(qimg, qb + 16 * s2, i * 32, lane), dk[i], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                                    // every wave's dS image is complete
+        // dQ[q][d] += sum over the block's 128 keys of dS[q][key] K[key][d]: both operands are transposed reads with the key as the row
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+                dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(wreg + wv * WREG + 8192, 16 * s2, qa * 32, lane),
+                                                             frag_tr<D>(wreg + wv * WREG, 16 * s2, di * 32, lane), dq, 0, 0, 0);
+        __syncthreads();                                                    // the regions are free: each becomes its wave's 32 x 64 fp32 transpose tile
+        {
+            float* tb = (float*)kimg_w;
+            auto emit = [&](const f32x16 (&acc)[2], bf16_t* base, long rs) __attribute__((always_inline)) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tb[acc_row(r, lane) * 64 + ii * 32 + (lane & 31)] = acc[ii][r];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = (lane >> 3) + 8 * j, key = k0 + row;
+                    const float4 x0 = *(const float4*)(tb + row * 64 + (lane & 7) * 8), x1 = *(const float4*)(tb + row * 64 + (lane & 7) * 8 + 4);
+                    u16x8 o;
+                    o[0] = f2bf(x0.x); o[1] = f2bf(x0.y); o[2] = f2bf(x0.z); o[3] = f2bf(x0.w);
+                    o[4] = f2bf(x1.x); o[5] = f2bf(x1.y); o[6] = f2bf(x1.z); o[7] = f2bf(x1.w);
+                    if (key < p.Sk) *(u16x8*)(base + (long)key * rs + (lane & 7) * 8) = o;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            };
+            emit(dk, dkp, p.dk_rs);
+            emit(dv, dvp, p.dv_rs);
+        }
+    }
+    // the four 32 x 32 tiles -> one [64 q][64 d] fp32 image -> one coalesced partial per work item
+    float* acc_s = (float*)wreg;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_s[(qa * 32 + acc_row(r, lane)) * 64 + di * 32 + (lane & 31)] = dq[r];
+    __syncthreads();
+    float* out = dq_part + ((long)chunk * nbh + bh) * (64 * 64);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = (i * 256 + threadIdx.x) * 4;
+        *(float4*)(out + e) = *(const float4*)(acc_s + e);
+    }
+}
+
+// dQ[b][q][h][:] = bf16(sum over the key chunks, in chunk order, of the fp32 partials of attn_bwd_q64_k)
+__global__ __launch_bounds__(256) void attn_dq_sum_k(AttnArgs p, const float* __restrict__ dq_part, int nch) {
+    const int nbh = p.B * p.Hq, bh = blockIdx.x, b = bh / p.Hq, h = bh % p.Hq;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = (i * 256 + threadIdx.x) * 4, q = e >> 6, d0 = e & 63;
+        float4 s = *(const float4*)(dq_part + (long)bh * 4096 + e);
+        for (int c = 1; c < nch; ++c) {
+            const float4 v = *(const float4*)(dq_part + ((long)c * nbh + bh) * 4096 + e);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        if (q < p.Sq) {
+            u16x4 o;
+            o[0] = f2bf(s.x); o[1] = f2bf(s.y); o[2] = f2bf(s.z); o[3] = f2bf(s.w);
+            *(u16x4*)(p.dQ + (long)b * p.dq_bs + (long)q * p.dq_rs + (long)h * 64 + d0) = o;
+        }
+    }
+}
+
 int fill_args(const desta_attn_desc* d, AttnArgs& a) {
     DESTA_CHECK_ARG(d && d->Q && d->K && d->V, "attention: null operand");
     DESTA_CHECK_ARG(d->head_dim == 64 || d->head_dim == 128, "attention: head_dim %d unsupported (64 or 128)", d->head_dim);
@@ -1341,7 +1562,7 @@ int fill_args(const desta_attn_desc* d, AttnArgs& a) {
 
 }  // namespace
 
-namespace { int g_attn_opt[8] = {1, 0, 0, 0, 0, 0, 0, 0}; }
+namespace { int g_attn_opt[8] = {1, 0, 0, 0, 1, 0, 0, 0}; }      // [4]: one-pass backward for a single query tile (seq_q <= 64, D = 64)
 extern "C" int desta_attention_set_option(int which, int value) {
     DESTA_CHECK_ARG(which >= 0 && which < 8, "attention_set_option: unknown option %d", which);
     g_attn_opt[which] = value;
@@ -1388,8 +1609,11 @@ extern "C" int desta_attention_fwd(const desta_attn_desc* d, void* stream) {
     return DESTA_OK;
 }
 
+// delta [batch][heads][seq_q], then (seq_q <= 64) up to ATTN_Q64_MAX_CHUNKS dQ partials of 64 x 64 floats per (batch, head)
+#define ATTN_Q64_MAX_CHUNKS 4
 extern "C" size_t desta_attention_bwd_workspace_floats(int batch, int n_q_heads, int seq_q) {
-    return (size_t)batch * n_q_heads * seq_q;
+    const size_t delta = ((size_t)batch * n_q_heads * seq_q + 3) / 4 * 4;
+    return delta + (seq_q <= 64 ? (size_t)ATTN_Q64_MAX_CHUNKS * batch * n_q_heads * 4096 : 0);
 }
 
 // dQ and dK/dV are independent given delta.  The dK/dV grid is makespan-bound under the causal mask (320 blocks of very
@@ -1466,6 +1690,22 @@ extern "C" int desta_attention_bwd(const desta_attn_desc* d, float* workspace, v
             else hipLaunchKernelGGL((attn_bwd_dq8_k<64, true, 1>), g8, dim3(512), 0, st, a, workspace);
             if (d->dK) hipLaunchKernelGGL((attn_bwd_dkdv_k<64, false>), gk_, dim3(256), 0, st, a);
         }
+        DESTA_CHECK_LAUNCH("attention_bwd");
+        return DESTA_OK;
+    }
+    if (g_attn_opt[4] && d->head_dim == 64 && a.Sq <= 64 && a.Sk >= 256 && !a.causal && a.Hq == a.Hkv && d->dK && !a.rope_cs &&
+        ((d->dk_row_stride | d->dv_row_stride | d->dk_batch_stride | d->dv_batch_stride | d->q_batch_stride | d->k_batch_stride |
+          d->v_batch_stride | d->do_batch_stride) & 7) == 0 && (((size_t)d->dK | (size_t)d->dV | (size_t)d->dO) & 15) == 0 &&
+        (d->dq_batch_stride & 3) == 0 && ((size_t)d->dQ & 7) == 0) {
+        // one query tile (the Q-Former's cross-attention): delta, then dQ / dK / dV in ONE pass over K / V, then the chunk sum
+        hipLaunchKernelGGL(attn_delta_k<64>, gd, dim3(256), 0, st, a, workspace);
+        const int nkb = (a.Sk + 127) / 128;
+        const int nch = nkb >= 8 ? ATTN_Q64_MAX_CHUNKS : (nkb >= 4 ? 2 : 1), bpc = (nkb + nch - 1) / nch;
+        float* part = workspace + (rows + 3) / 4 * 4;
+        dim3 gf((unsigned)(nch * a.B * a.Hq));
+        if (a.drop_thresh) hipLaunchKernelGGL((attn_bwd_q64_k<true>), gf, dim3(256), 0, st, a, part, bpc);
+        else hipLaunchKernelGGL((attn_bwd_q64_k<false>), gf, dim3(256), 0, st, a, part, bpc);
+        hipLaunchKernelGGL(attn_dq_sum_k, dim3((unsigned)(a.B * a.Hq)), dim3(256), 0, st, a, (const float*)part, nch);
         DESTA_CHECK_LAUNCH("attention_bwd");
         return DESTA_OK;
     }

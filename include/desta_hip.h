@@ -295,6 +295,8 @@ typedef struct desta_attn_desc {
                                        /* weight gradient (eager attention in the reference sums P * dP itself: no such term).        */
 } desta_attn_desc;
 int desta_attention_fwd(const desta_attn_desc* d, void* stream);
+/* floats of `workspace` for desta_attention_bwd: delta [batch][heads][seq_q] and, for seq_q <= 64 (one query tile: the one-pass
+ * dQ / dK / dV kernel), up to 4 fp32 dQ partials of 64 x 64 per (batch, head), summed in fixed order (no atomics). */
 size_t desta_attention_bwd_workspace_floats(int batch, int n_q_heads, int seq_q);
 int desta_attention_bwd(const desta_attn_desc* d, float* workspace, void* stream);
 /* D = 128 backward: run the dQ kernel on an internal side stream next to dK/dV (fork after delta, join on `stream`);
@@ -305,7 +307,9 @@ int desta_attention_set_concurrent_bwd(int on);
  *   which 1: head_dim 64 non-causal 8-wave forward at two blocks per CU (1) or one (0, default);
  *   which 2: 1 = the 8-wave forward WITH waves 4-7 half a tile behind waves 0-3 (LLM / Whisper shapes only; default 0);
  *   which 3: 1 = backward on round 2's path (separate delta launch, 4-wave dQ kernel on a side stream beside dK / dV) instead
- *            of the 8-wave dQ kernel that computes delta itself (default 0; not available with rope_cos_sin). */
+ *            of the 8-wave dQ kernel that computes delta itself (default 0; not available with rope_cos_sin);
+ *   which 4: 1 (default) = one query tile (seq_q <= 64, head_dim 64, seq_k >= 256, no GQA, dK / dV requested): dQ, dK, dV in ONE
+ *            pass over K / V; 0 = the separate dQ and dK / dV kernels. */
 int desta_attention_set_option(int which, int value);
 
 /* layer_prompts[j].expand(B,-1,-1) for all taps at once (modeling_desta25.py:589): prompts fp32

@@ -288,6 +288,11 @@ ATTN_CASES = [
     (2, 2, 1, 257, 257, 64, True, [0, 5]),       # head dim 64 causal, 2 heads per block
     (1, 2, 2, 1500, 1500, 64, False, None),      # Whisper: 1500 frames = 23.4 key tiles, 5.9 query blocks
     (1, 2, 2, 130, 700, 128, False, None),       # non-causal head dim 128, ragged both ways
+    # one query tile over many keys (the Q-Former's cross-attention): dQ / dK / dV in one pass, the keys cut into 1 / 2 / 4 chunks
+    (2, 3, 3, 64, 1500, 64, False, None),        # 12 key blocks -> 4 chunks of 3; last block ragged (1500 = 11 x 128 + 92)
+    (1, 2, 2, 64, 600, 64, False, [77]),         # 5 key blocks -> 2 chunks (3 + 2), left padding inside the first block
+    (2, 2, 2, 50, 300, 64, False, None),         # 3 key blocks -> 1 chunk; 50 query rows: the second 32-row slice is ragged
+    (1, 2, 2, 20, 1100, 64, False, [0]),         # 9 key blocks -> 4 chunks of 3 / 3 / 3 / 0: an EMPTY chunk; only one query slice
 ]
 
 
@@ -347,7 +352,15 @@ def test_attention_fwd_bwd(hip, case):
     # dQ-only variant (Whisper states carry no gradient)
     dq2 = torch.zeros(B * Sq, wq, dtype=torch.bfloat16, device="cuda")
     hip.attention_bwd(d, do.cuda(), dq2)
-    assert torch.equal(dq2.cpu(), gq.cpu().contiguous())
+    if D == 64 and Sq <= 64 and Sk >= 256 and not causal:
+        # the one-pass backward sums dQ over key chunks in its own (fixed) order: equal to the dQ-only kernel to rounding
+        assert rel_err(dq2.float().cpu(), gq.float().cpu().contiguous()) < 1e-2
+        dq3 = torch.zeros_like(dq2)
+        dkv3 = torch.zeros(B * Sk, 2 * wkv, dtype=torch.bfloat16, device="cuda")
+        hip.attention_bwd(d, do.cuda(), dq3, dkv3, dkv3, dk_off=0, dv_off=wkv)
+        assert torch.equal(dq3, gq) and torch.equal(dkv3[:, :wkv], gk) and torch.equal(dkv3[:, wkv:], gv)   # bit-identical run to run
+    else:
+        assert torch.equal(dq2.cpu(), gq.cpu().contiguous())
 
 
 def test_attention_forced_rescale(hip):
@@ -558,7 +571,7 @@ def test_dropout_mask_gemm_epilogue_and_backward_kernel(hip):
     torch.testing.assert_close(y.float().cpu(), x.float() * mask / (1 - pdrop), rtol=8e-3, atol=1e-6)
 
 
-@pytest.mark.parametrize("Sq,Sk", [(64, 64), (64, 200)])
+@pytest.mark.parametrize("Sq,Sk", [(64, 64), (64, 200), (64, 1500), (40, 520)])
 def test_attention_dropout_fwd_bwd(hip, Sq, Sk):
     B, H, D, pdrop, seed = 2, 3, 64, 0.1, (3 << 40) | 77
     g = torch.Generator().manual_seed(Sq + Sk)
