@@ -156,27 +156,31 @@ __global__ __launch_bounds__(256) void layernorm_bwd_k(const void* __restrict__ 
 
 // out[which][c] (+)= sum_b part[b][which][c];  also used for column sums (bias gradients).  64 columns per block, the
 // partial rows are split over the block's 4 waves (4 independent accumulators each) and combined in fixed order.
-__global__ __launch_bounds__(256) void reduce_partials_k(const float* __restrict__ part, int nblk, int width,
-                                                         float* __restrict__ out0, float* __restrict__ out1, int cols,
-                                                         int accumulate) {
-    __shared__ float comb[4][64];
+__global__ __launch_bounds__(1024) void reduce_partials_k(const float* __restrict__ part, int nblk, int width,
+                                                          float* __restrict__ out0, float* __restrict__ out1, int cols,
+                                                          int accumulate) {
+    // 16 wave groups x 4 independent accumulators: the partial rows are a chain of dependent loads per accumulator (256 rows:
+    // 4 rounds instead of the 16 that a 4-group block needs)
+    __shared__ float comb[16][64];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (c < width) {
         int b = grp;
-        for (; b + 12 < nblk; b += 16) {
+        for (; b + 48 < nblk; b += 64) {
             a0 += part[(long)b * width + c];
-            a1 += part[(long)(b + 4) * width + c];
-            a2 += part[(long)(b + 8) * width + c];
-            a3 += part[(long)(b + 12) * width + c];
+            a1 += part[(long)(b + 16) * width + c];
+            a2 += part[(long)(b + 32) * width + c];
+            a3 += part[(long)(b + 48) * width + c];
         }
-        for (; b < nblk; b += 4) a0 += part[(long)b * width + c];
+        for (; b < nblk; b += 16) a0 += part[(long)b * width + c];
     }
     comb[grp][lane] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (grp == 0 && c < width) {
-        const float s = (comb[0][lane] + comb[1][lane]) + (comb[2][lane] + comb[3][lane]);
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; g += 4) s += (comb[g][lane] + comb[g + 1][lane]) + (comb[g + 2][lane] + comb[g + 3][lane]);
         float* o = (c < cols) ? out0 + c : out1 + (c - cols);
         *o = accumulate ? *o + s : s;
     }
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(256) void colsum_partial_k(const bf16_t* __restrict
     float s[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) s[e] = 0.f;
-#pragma unroll 4
+#pragma unroll 8
     for (int r = r0; r < rows; r += nr) {
         const vec_t v = *(const vec_t*)(x + (long)r * ld + c);
 #pragma unroll
@@ -203,11 +207,12 @@ __global__ __launch_bounds__(256) void colsum_partial_k(const bf16_t* __restrict
     for (int e = 0; e < V; ++e) part[(long)r0 * cols + c + e] = s[e];
 }
 // row splits: enough blocks to fill the chip on tall matrices (the [48000, 2560] d(K|V) of the cross-attention ran at
-// 1.5 TB/s with 64 splits x 3 column blocks), at least ~32 rows per split
+// 1.5 TB/s with 64 splits x 3 column blocks), at least ~8 rows per split: the 2048-row bias gradients of the Q-Former are
+// latency-bound chains of row loads (32 rows per split = 8 dependent rounds of 4 loads: 17.8 us for 5 MB; 8 rows = one round)
 static int colsum_splits(int rows, int cols) {
     const int xb = (cols / 4 + 255) / 256;
     int nr = (2048 + xb - 1) / xb;
-    if (nr > rows / 32) nr = rows / 32;
+    if (nr > rows / 8) nr = rows / 8;
     if (nr > 512) nr = 512;
     if (nr < 1) nr = 1;
     return nr;
@@ -741,7 +746,7 @@ extern "C" int desta_layernorm_bwd(const void* dy, int dy_f32, const void* x, in
     else if (cols <= 1024) hipLaunchKernelGGL((layernorm_bwd_k<2>), dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, dy_f32, x, x_f32, gamma, stats, rows, cols, dx_f32, (bf16_t*)dx_bf16, part);
     else hipLaunchKernelGGL((layernorm_bwd_k<4>), dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, dy_f32, x, x_f32, gamma, stats, rows, cols, dx_f32, (bf16_t*)dx_bf16, part);
     if (dgamma)
-        hipLaunchKernelGGL(reduce_partials_k, dim3((2 * cols + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(reduce_partials_k, dim3((2 * cols + 63) / 64), dim3(1024), 0, (hipStream_t)stream,
                            (const float*)part, nb, 2 * cols, dgamma, dbeta, cols, accumulate);
     DESTA_CHECK_LAUNCH("layernorm_bwd");
     return DESTA_OK;
@@ -760,7 +765,7 @@ extern "C" int desta_colsum_bf16(const void* x, int rows, int cols, int64_t ld, 
     else
         hipLaunchKernelGGL(colsum_partial_k<4>, dim3((cols / 4 + 255) / 256, nr), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_t*)x, rows, cols, (long)ld, workspace);
-    hipLaunchKernelGGL(reduce_partials_k, dim3((cols + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(reduce_partials_k, dim3((cols + 63) / 64), dim3(1024), 0, (hipStream_t)stream,
                        (const float*)workspace, nr, cols, out, out, cols, accumulate);
     DESTA_CHECK_LAUNCH("colsum");
     return DESTA_OK;
