@@ -356,6 +356,7 @@ def main():
         H.attention_set_option(0, 0)
     if a.attn_q64_two_kernels:
         H.attention_set_option(4, 0)
+        model.connector.xattn_transposed = False
 
     B, S = a.batch, a.ctx + cfg.prompt_size + a.tgt
     n_mels = cfg.encoder_config.num_mel_bins

@@ -42,6 +42,7 @@ struct AttnArgs {
     float scale_log2;                                                // softmax scale * log2(e)
     float scale;
     unsigned drop_thresh, seed_lo, seed_hi; float drop_scale;       // attention-probability dropout (DROP kernels)
+    long dkv_t_ld;                                                   // one-query-tile backward: dK / dV stored transposed ([head * 64 + d][dkv_t_ld], column = batch * Sk + key); 0 = off
 };
 
 template <int D>
@@ -1319,8 +1320,10 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkdv_k(AttnArgs
 // chunks (work items = nch x batch x heads, equal length) whose dQ partials are summed in fixed order by attn_dq_sum_k:
 // K / V read once, dK / dV written once, + 2 x nch x 16 KB per (batch, head) of partials.  No atomics: bit-identical run to run.
 // block = 4 waves, wave w owns keys [128 kb + 32 w, +32) of every key block kb of its chunk.
-template <bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_bwd_q64_k(AttnArgs p, float* __restrict__ dq_part, int blocks_per_chunk) {
+// TR: dK / dV are written TRANSPOSED (the operand layout of the K / V projection's weight-gradient GEMM: no transpose pass over
+// the 246 MB) and their sums over keys (the projection's bias gradients) leave the kernel as one partial row per (chunk, batch).
+template <bool DROP, bool TR>
+__global__ __launch_bounds__(256, 2) void attn_bwd_q64_k(AttnArgs p, float* __restrict__ dq_part, float* __restrict__ bias_part, int blocks_per_chunk) {
     constexpr int D = 64, WREG = 12288;
     __shared__ __attribute__((aligned(16))) char lds[2 * 64 * D * 2 + 4 * WREG + 2 * 64 * 4];
     char* qimg = lds;                                                       // [64 q][64 d]
@@ -1365,8 +1368,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q64_k(AttnArgs p, float* __re
         vst = tile_load<D, 128>(vbase, p.v_rs, kb_lo * 128, p.Sk - 1);
     }
     const unsigned long hb = ((unsigned long)b * p.Hq + h) * p.Sq;
-    bf16_t* dkp = p.dK + (long)b * p.dk_bs + (long)h * D;
-    bf16_t* dvp = p.dV + (long)b * p.dv_bs + (long)h * D;
+    bf16_t* dkp = TR ? p.dK + (long)h * D * p.dkv_t_ld + (long)b * p.Sk : p.dK + (long)b * p.dk_bs + (long)h * D;
+    bf16_t* dvp = TR ? p.dV + (long)h * D * p.dkv_t_ld + (long)b * p.Sk : p.dV + (long)b * p.dv_bs + (long)h * D;
+    float bsum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};                            // TR: [K | V][d half]: sums over this lane's keys of every block
 
     for (int kb = kb_lo; kb < kb_hi; ++kb) {
         __syncthreads();                                                    // every wave is done with its region (epilogue tile of the previous block) / the query images are written
@@ -1475,7 +1479,34 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q64_k(AttnArgs p, float* __re
                 dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(wreg + wv * WREG + 8192, 16 * s2, qa * 32, lane),
                                                              frag_tr<D>(wreg + wv * WREG, 16 * s2, di * 32, lane), dq, 0, 0, 0);
         __syncthreads();                                                    // the regions are free: each becomes its wave's 32 x 64 fp32 transpose tile
-        {
+        if constexpr (TR) {
+            // transposed store: [d][key] through a wave-private [64 d][36] fp32 tile (a lane holds 4 runs of 4 consecutive keys of
+            // ONE d: float4 writes; then a lane reads 4 consecutive keys of one d: 8-byte bf16 stores, 64-byte row segments)
+            float* tb = (float*)kimg_w;
+            auto emit_t = [&](const f32x16 (&acc)[2], bf16_t* base, float (&bs)[2]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        *(float4*)(tb + (ii * 32 + (lane & 31)) * 36 + 8 * q4 + 4 * h2) =
+                            make_float4(acc[ii][4 * q4], acc[ii][4 * q4 + 1], acc[ii][4 * q4 + 2], acc[ii][4 * q4 + 3]);
+                        bs[ii] += (acc[ii][4 * q4] + acc[ii][4 * q4 + 1]) + (acc[ii][4 * q4 + 2] + acc[ii][4 * q4 + 3]);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int dr = 8 * j + (lane >> 3), key = k0 + 4 * (lane & 7);
+                    const float4 x = *(const float4*)(tb + dr * 36 + 4 * (lane & 7));
+                    u16x4 o;
+                    o[0] = f2bf(x.x); o[1] = f2bf(x.y); o[2] = f2bf(x.z); o[3] = f2bf(x.w);
+                    if (key < p.Sk) *(u16x4*)(base + (long)dr * p.dkv_t_ld + key) = o;        // Sk % 4 == 0 (host check): a group is whole or absent
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            };
+            emit_t(dk, dkp, bsum[0]);
+            emit_t(dv, dvp, bsum[1]);
+        } else {
             float* tb = (float*)kimg_w;
             auto emit = [&](const f32x16 (&acc)[2], bf16_t* base, long rs) __attribute__((always_inline)) {
 #pragma unroll
@@ -1510,6 +1541,41 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q64_k(AttnArgs p, float* __re
         const int e = (i * 256 + threadIdx.x) * 4;
         *(float4*)(out + e) = *(const float4*)(acc_s + e);
     }
+    if constexpr (TR) {
+        if (bias_part) {
+            // bias gradients: sum the 8 (wave, key half) rows in fixed order -> this (chunk, batch)'s partial row [K | V][head * 64 + d]
+            __syncthreads();
+            float* bs_s = (float*)wreg;                                     // [8][128]
+#pragma unroll
+            for (int kv = 0; kv < 2; ++kv)
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) bs_s[(wave * 2 + h2) * 128 + kv * 64 + ii * 32 + (lane & 31)] = bsum[kv][ii];
+            __syncthreads();
+            if (threadIdx.x < 128) {
+                float t = 0.f;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) t += bs_s[r * 128 + threadIdx.x];
+                const int kv = threadIdx.x >> 6, dd = threadIdx.x & 63, W = 2 * p.Hq * 64;
+                bias_part[((long)chunk * p.B + b) * W + kv * (p.Hq * 64) + h * 64 + dd] = t;
+            }
+        }
+    }
+}
+
+// bias[c] = sum over the (chunk, batch) partial rows, in row order
+__global__ __launch_bounds__(256) void attn_bias_sum_k(const float* __restrict__ part, int nrows, int width, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= width) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int r = 0;
+    for (; r + 3 < nrows; r += 4) {
+        a0 += part[(long)r * width + c];
+        a1 += part[(long)(r + 1) * width + c];
+        a2 += part[(long)(r + 2) * width + c];
+        a3 += part[(long)(r + 3) * width + c];
+    }
+    for (; r < nrows; ++r) a0 += part[(long)r * width + c];
+    out[c] = (a0 + a1) + (a2 + a3);
 }
 
 // dQ[b][q][h][:] = bf16(sum over the key chunks, in chunk order, of the fp32 partials of attn_bwd_q64_k)
@@ -1557,6 +1623,7 @@ int fill_args(const desta_attn_desc* d, AttnArgs& a) {
     a.drop_thresh = d->dropout_p > 0.f ? desta_drop_thresh(d->dropout_p) : 0u;
     a.drop_scale = 1.0f / (1.0f - d->dropout_p);
     a.seed_lo = (unsigned)d->dropout_seed; a.seed_hi = (unsigned)(d->dropout_seed >> 32);
+    a.dkv_t_ld = d->dkv_transposed ? d->dkv_t_ld : 0;
     return DESTA_OK;
 }
 
@@ -1613,7 +1680,7 @@ extern "C" int desta_attention_fwd(const desta_attn_desc* d, void* stream) {
 #define ATTN_Q64_MAX_CHUNKS 4
 extern "C" size_t desta_attention_bwd_workspace_floats(int batch, int n_q_heads, int seq_q) {
     const size_t delta = ((size_t)batch * n_q_heads * seq_q + 3) / 4 * 4;
-    return delta + (seq_q <= 64 ? (size_t)ATTN_Q64_MAX_CHUNKS * batch * n_q_heads * 4096 : 0);
+    return delta + (seq_q <= 64 ? (size_t)ATTN_Q64_MAX_CHUNKS * batch * n_q_heads * (4096 + 128) : 0);   // + the K | V bias-gradient partial rows
 }
 
 // dQ and dK/dV are independent given delta.  The dK/dV grid is makespan-bound under the causal mask (320 blocks of very
@@ -1693,18 +1760,28 @@ extern "C" int desta_attention_bwd(const desta_attn_desc* d, float* workspace, v
         DESTA_CHECK_LAUNCH("attention_bwd");
         return DESTA_OK;
     }
-    if (g_attn_opt[4] && d->head_dim == 64 && a.Sq <= 64 && a.Sk >= 256 && !a.causal && a.Hq == a.Hkv && d->dK && !a.rope_cs &&
-        ((d->dk_row_stride | d->dv_row_stride | d->dk_batch_stride | d->dv_batch_stride | d->q_batch_stride | d->k_batch_stride |
-          d->v_batch_stride | d->do_batch_stride) & 7) == 0 && (((size_t)d->dK | (size_t)d->dV | (size_t)d->dO) & 15) == 0 &&
-        (d->dq_batch_stride & 3) == 0 && ((size_t)d->dQ & 7) == 0) {
+    const bool q64 = d->head_dim == 64 && a.Sq <= 64 && a.Sk >= 256 && !a.causal && a.Hq == a.Hkv && d->dK && !a.rope_cs &&
+                     ((d->q_batch_stride | d->k_batch_stride | d->v_batch_stride | d->do_batch_stride) & 7) == 0 && ((size_t)d->dO & 15) == 0 &&
+                     (d->dq_batch_stride & 3) == 0 && ((size_t)d->dQ & 7) == 0;
+    if (d->dkv_transposed)
+        DESTA_CHECK_ARG(q64 && a.Sk % 4 == 0 && d->dkv_t_ld % 4 == 0 && d->dkv_t_ld >= (int64_t)a.B * a.Sk && (((size_t)d->dK | (size_t)d->dV) & 7) == 0,
+                        "attention_bwd: dkv_transposed needs the one-query-tile path (head_dim 64, seq_q <= 64, seq_k >= 256 and a multiple of 4, no GQA) and 8-byte aligned dK / dV");
+    if ((g_attn_opt[4] || d->dkv_transposed) && q64 &&
+        (d->dkv_transposed || (((d->dk_row_stride | d->dv_row_stride | d->dk_batch_stride | d->dv_batch_stride) & 7) == 0 && (((size_t)d->dK | (size_t)d->dV) & 15) == 0))) {
         // one query tile (the Q-Former's cross-attention): delta, then dQ / dK / dV in ONE pass over K / V, then the chunk sum
         hipLaunchKernelGGL(attn_delta_k<64>, gd, dim3(256), 0, st, a, workspace);
         const int nkb = (a.Sk + 127) / 128;
         const int nch = nkb >= 8 ? ATTN_Q64_MAX_CHUNKS : (nkb >= 4 ? 2 : 1), bpc = (nkb + nch - 1) / nch;
         float* part = workspace + (rows + 3) / 4 * 4;
+        float* bpart = d->dkv_bias_grad ? part + (size_t)ATTN_Q64_MAX_CHUNKS * a.B * a.Hq * 4096 : nullptr;
         dim3 gf((unsigned)(nch * a.B * a.Hq));
-        if (a.drop_thresh) hipLaunchKernelGGL((attn_bwd_q64_k<true>), gf, dim3(256), 0, st, a, part, bpc);
-        else hipLaunchKernelGGL((attn_bwd_q64_k<false>), gf, dim3(256), 0, st, a, part, bpc);
+        if (d->dkv_transposed) {
+            if (a.drop_thresh) hipLaunchKernelGGL((attn_bwd_q64_k<true, true>), gf, dim3(256), 0, st, a, part, bpart, bpc);
+            else hipLaunchKernelGGL((attn_bwd_q64_k<false, true>), gf, dim3(256), 0, st, a, part, bpart, bpc);
+            if (bpart) hipLaunchKernelGGL(attn_bias_sum_k, dim3((unsigned)((2 * a.Hq * 64 + 255) / 256)), dim3(256), 0, st, (const float*)bpart,
+                                          nch * a.B, 2 * a.Hq * 64, d->dkv_bias_grad);
+        } else if (a.drop_thresh) hipLaunchKernelGGL((attn_bwd_q64_k<true, false>), gf, dim3(256), 0, st, a, part, bpart, bpc);
+        else hipLaunchKernelGGL((attn_bwd_q64_k<false, false>), gf, dim3(256), 0, st, a, part, bpart, bpc);
         hipLaunchKernelGGL(attn_dq_sum_k, dim3((unsigned)(a.B * a.Hq)), dim3(256), 0, st, a, (const float*)part, nch);
         DESTA_CHECK_LAUNCH("attention_bwd");
         return DESTA_OK;

@@ -393,7 +393,8 @@ class AttnDesc(C.Structure):
                 ("dk_batch_stride", i64), ("dk_row_stride", i64), ("dv_batch_stride", i64), ("dv_row_stride", i64),
                 ("batch", i32), ("n_q_heads", i32), ("n_kv_heads", i32), ("seq_q", i32), ("seq_k", i32),
                 ("head_dim", i32), ("causal", i32), ("kv_start", vp), ("scale", f32),
-                ("dropout_p", f32), ("dropout_seed", C.c_uint64), ("rope_cos_sin", vp), ("O_f32", vp)]
+                ("dropout_p", f32), ("dropout_seed", C.c_uint64), ("rope_cos_sin", vp), ("O_f32", vp),
+                ("dkv_transposed", i32), ("dkv_t_ld", i64), ("dkv_bias_grad", vp)]
 
 
 _attn_fwd = _sig("desta_attention_fwd", C.POINTER(AttnDesc), vp)
@@ -452,7 +453,7 @@ def attention_fwd(d: AttnDesc):
 
 @_profiled(lambda d, *a, **k: "attn_bwd:" + _attn_tag(d), lambda d, *a, **k: _attn_flops(d, 2.5))     # dS, dP recompute, dQ, dK, dV
 def attention_bwd(d: AttnDesc, do, dq, dk=None, dv=None, *, do_rs=None, dq_off=0, dk_off=0, dv_off=0, dq_rs=None,
-                  dk_rs=None, dv_rs=None, do_bs=None, dq_bs=None, dk_bs=None, dv_bs=None, rope_cos_sin=None):
+                  dk_rs=None, dv_rs=None, do_bs=None, dq_bs=None, dk_bs=None, dv_bs=None, rope_cos_sin=None, dkv_t=None):
     """Backward of the attention described by `d` (O and lse filled by forward); *_bs override the batch strides
     (position-major token grids: row stride = batch * width, batch stride = width).  rope_cos_sin [seq, hd/2, 2] fp32: Q / K
     are rotary-embedded projections in the adjacent-pair layout; dQ / dK are rotated back before the store."""
@@ -462,7 +463,15 @@ def attention_bwd(d: AttnDesc, do, dq, dk=None, dv=None, *, do_rs=None, dq_off=0
     dq_rs = dq.shape[-1] if dq_rs is None else dq_rs
     d.dO, d.do_row_stride, d.do_batch_stride = p(do), do_rs, (d.seq_q * do_rs if do_bs is None else do_bs)
     d.dQ, d.dq_row_stride, d.dq_batch_stride = _elem_ptr(dq, dq_off), dq_rs, (d.seq_q * dq_rs if dq_bs is None else dq_bs)
-    if dk is not None:
+    d.dkv_transposed, d.dkv_t_ld, d.dkv_bias_grad = 0, 0, 0
+    if dkv_t is not None:
+        # one-query-tile path: dK | dV written transposed into `t` [2 * heads * 64, ld] (K rows first), bias gradients into `bias` [2 * heads * 64] fp32
+        t, ld, bias = dkv_t
+        assert dk is None and dv is None and t.dtype == torch.bfloat16 and (bias is None or bias.dtype == torch.float32)
+        d.dK, d.dV = p(t), _elem_ptr(t, d.n_q_heads * d.head_dim * ld)
+        d.dkv_transposed, d.dkv_t_ld, d.dkv_bias_grad = 1, ld, p(bias)
+        dk = dv = t
+    elif dk is not None:
         dk_rs = dk.shape[-1] if dk_rs is None else dk_rs
         dv_rs = dv.shape[-1] if dv_rs is None else dv_rs
         d.dK, d.dk_row_stride, d.dk_batch_stride = _elem_ptr(dk, dk_off), dk_rs, (d.seq_k * dk_rs if dk_bs is None else dk_bs)

@@ -389,6 +389,7 @@ class QformerConnectorHIP:
         self.B = 0
         self.p_drop = 0.0                      # set per forward by the model (cfg.qformer_dropout in training mode)
         self.overlap_dw = True                 # weight gradients on a side stream beside the dX chain
+        self.xattn_transposed = True           # cross-attention backward writes d(K|V) transposed + the bias sums itself (A/B: bench.py --attn-q64-two-kernels)
         self._dw_stream, self._dw_pending = None, False
         self.seed_base = 0
         # transposed bf16 weights for the dX GEMMs: name -> [in, out] (refreshed on the optimizer's side stream; reading W
@@ -466,7 +467,7 @@ class QformerConnectorHIP:
         self.tA = b16(max(3 * d, inter, self.h) * max(self.Rp, self.BKp))     # transposed dY  [N, Rp]
         self.tB = b16(max(d, inter) * max(self.Rp, self.BKp))                  # transposed X   [K, Rp]
         self.tE = b16(d, self.Ep)                                              # enc^T, shared by all layers
-        self.tKV = b16(2 * d, self.Ep)
+        self.tKV = torch.zeros(2 * d, self.Ep, dtype=BF16, device=dev)         # d(K|V)^T; pad columns stay zero (the one-pass attention backward writes the E real ones only)
         self.dmixed = f32(B * K, d)
         self.dpb = b16(B * K, d)
 
@@ -622,12 +623,19 @@ class QformerConnectorHIP:
             dm = self._drop_grad(dpre16, s, 3)
             self._dW(dm, s["a_c"], R, d, d, p + "crossattention.output.dense.weight", p + "crossattention.output.dense.bias", self.Rp)
             H.gemm(dm, self.wT[f"{i}.c.o"], da, R, d, d)
-            H.attention_bwd(s["ad_c"], da, dq, self.dkv, self.dkv, dk_off=0, dv_off=d)
+            # key/value projections of the encoder states (no dX into the frozen Whisper states): their weight gradient wants
+            # d(K|V) TRANSPOSED ([2d, E]) and their bias gradient its sums over the E rows
+            xt = self.xattn_transposed and K <= 64 and T >= 256 and T % 4 == 0 and self.heads * 64 == d
+            if xt:
+                # the one-pass backward writes d(K|V) in that layout itself and sums the bias gradients on the way
+                H.attention_bwd(s["ad_c"], da, dq, dkv_t=(self.tKV, self.Ep, self.G32(p + "crossattention.self.key.bias", 2 * d)))
+            else:
+                H.attention_bwd(s["ad_c"], da, dq, self.dkv, self.dkv, dk_off=0, dv_off=d)
             self._dW(dq, s["x1_16"], R, d, d, p + "crossattention.self.query.weight", p + "crossattention.self.query.bias", self.Rp)
-            # key/value projections of the encoder states (no dX into the frozen Whisper states)
-            H.transpose_to_bf16(self.dkv, E, 2 * d, self.tKV, self.Ep)
+            if not xt:
+                H.transpose_to_bf16(self.dkv, E, 2 * d, self.tKV, self.Ep)
+                H.colsum(self.dkv, E, 2 * d, 2 * d, self.G32(p + "crossattention.self.key.bias", 2 * d))
             H.gemm(self.tKV, self.tE, self._gwide(p + "crossattention.self.key.weight", 2 * d), 2 * d, d, self.Ep)
-            H.colsum(self.dkv, E, 2 * d, 2 * d, self.G32(p + "crossattention.self.key.bias", 2 * d))
             H.gemm(dq, self.wT[f"{i}.c.q"], dx, R, d, d, residual=dpre)                         # dx := d x1_32
             # --- self-attention block: x1 = LN(pre1), pre1 = a_s@Wo^T + b + x_in
             self._join_dw()

@@ -293,10 +293,17 @@ typedef struct desta_attn_desc {
                                        /* the error of delta is coherent over the keys of a row (dS_err = P * eps_q) and, where the   */
                                        /* softmax is flat over 1500 encoder frames, puts 10-13 % error on the cross-attention query   */
                                        /* weight gradient (eager attention in the reference sums P * dP itself: no such term).        */
+    int dkv_transposed;                /* optional (ABI 5), bwd on the one-query-tile path only (head_dim 64, seq_q <= 64, seq_k >= 256, */
+    int64_t dkv_t_ld;                  /* seq_k % 4 == 0, no GQA): dK and dV are written TRANSPOSED, as [n_heads * 64][dkv_t_ld] bf16    */
+    float* dkv_bias_grad;              /* matrices with element (h * 64 + d, b * seq_k + key) — the operand layout of the K / V          */
+                                       /* projection's weight-gradient GEMM (no transpose pass); dk_* / dv_* strides are ignored.       */
+                                       /* dkv_bias_grad (optional): fp32 [2][n_heads * 64] = sums over batch and keys of dK | dV (the   */
+                                       /* projection's bias gradients), overwritten.                                                    */
 } desta_attn_desc;
 int desta_attention_fwd(const desta_attn_desc* d, void* stream);
 /* floats of `workspace` for desta_attention_bwd: delta [batch][heads][seq_q] and, for seq_q <= 64 (one query tile: the one-pass
- * dQ / dK / dV kernel), up to 4 fp32 dQ partials of 64 x 64 per (batch, head), summed in fixed order (no atomics). */
+ * dQ / dK / dV kernel), up to 4 fp32 dQ partials of 64 x 64 and bias-gradient partials of 2 x 64 per (batch, head), summed in
+ * fixed order (no atomics). */
 size_t desta_attention_bwd_workspace_floats(int batch, int n_q_heads, int seq_q);
 int desta_attention_bwd(const desta_attn_desc* d, float* workspace, void* stream);
 /* D = 128 backward: run the dQ kernel on an internal side stream next to dK/dV (fork after delta, join on `stream`);

@@ -678,3 +678,35 @@ def test_context_create_info_destroy_and_attention_still_runs(hip):
     for a, b in zip(before, after):
         assert torch.equal(a, b)
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Sq,Sk,pdrop", [(64, 1500, 0.0), (64, 1500, 0.1), (40, 520, 0.1), (64, 300, 0.0)])
+def test_attention_bwd_transposed_dkv_and_bias_sums(hip, Sq, Sk, pdrop):
+    """`desta_attn_desc.dkv_transposed` (one-query-tile backward): dK / dV come out as [heads * 64][ld] matrices with column
+    batch * seq_k + key — bit-identical to the row-major outputs of the same kernel —, `dkv_bias_grad` = their sums over batch
+    and keys (fp32, from the unrounded accumulators), dQ unchanged; pad columns [batch * seq_k, ld) are not touched."""
+    B, H, D, seed = 3, 2, 64, (5 << 40) | 9
+    g = torch.Generator().manual_seed(Sq + Sk)
+    qb = bf(torch.randn(B * Sq, H * D, generator=g)).cuda()
+    kvb = bf(torch.randn(B * Sk, 2 * H * D, generator=g)).cuda()
+    do = bf(torch.randn(B * Sq, H * D, generator=g)).cuda()
+    o = torch.zeros(B * Sq, H * D, dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros(B, H, Sq, device="cuda")
+    d = hip.attn_desc(qb, kvb, kvb, o, lse, batch=B, hq=H, hkv=H, sq=Sq, sk=Sk, hd=D, scale=D ** -0.5, k_off=0, v_off=H * D,
+                      dropout_p=pdrop, dropout_seed=seed)
+    hip.attention_fwd(d)
+    dq = torch.zeros(B * Sq, H * D, dtype=torch.bfloat16, device="cuda")
+    dkv = torch.zeros(B * Sk, 2 * H * D, dtype=torch.bfloat16, device="cuda")
+    hip.attention_bwd(d, do, dq, dkv, dkv, dk_off=0, dv_off=H * D)
+    ld = (B * Sk + 63) // 64 * 64 + 64
+    t = torch.full((2 * H * D, ld), 7.0, dtype=torch.bfloat16, device="cuda")
+    bias = torch.full((2 * H * D,), -1.0, device="cuda")
+    dq2 = torch.zeros_like(dq)
+    hip.attention_bwd(d, do, dq2, dkv_t=(t, ld, bias))
+    torch.cuda.synchronize()
+    assert torch.equal(dq2, dq)
+    assert torch.equal(t[:, :B * Sk], dkv.t().contiguous())
+    assert float((t[:, B * Sk:].float() - 7.0).abs().max()) == 0.0
+    ref = dkv.float().sum(0)
+    assert rel_err(bias, ref) < 4e-3, rel_err(bias, ref)                     # (the reference sum is over bf16-rounded values)
