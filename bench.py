@@ -278,6 +278,7 @@ def main():
     ap.add_argument("--lora", action="store_true", help="NOT the headline config: the reference's optional use_lora=True (rank-16 adapters on q/k/v of every decoder layer, full-row backward)")
     ap.add_argument("--no-dead-row-skip", action="store_true", help="A/B: the last decoder layer's o_proj / MLP (forward and backward) on every row instead of the target tail, layer 0's input gradient on every row instead of the audio rows")
     ap.add_argument("--attn-q64-two-kernels", action="store_true", help="A/B: the Q-Former's cross-attention backward on the separate dQ and dK/dV kernels instead of the one-pass kernel")
+    ap.add_argument("--no-kv-side", action="store_true", help="A/B: the Q-Former's K | V projections inside the layer loop on the main stream instead of up front on a second stream")
     ap.add_argument("--full-lm-head", action="store_true", help="A/B: lm_head / CE over the whole token grid, not only the target rows")
     a = ap.parse_args()
 
@@ -354,6 +355,8 @@ def main():
         H.attention_set_option(3, 1)
     if a.attn_r2_forward:
         H.attention_set_option(0, 0)
+    if a.no_kv_side:
+        model.connector.kv_side = False
     if a.attn_q64_two_kernels:
         H.attention_set_option(4, 0)
         model.connector.xattn_transposed = False

@@ -389,6 +389,8 @@ class QformerConnectorHIP:
         self.B = 0
         self.p_drop = 0.0                      # set per forward by the model (cfg.qformer_dropout in training mode)
         self.overlap_dw = True                 # weight gradients on a side stream beside the dX chain
+        self.kv_side = True                    # every layer's K | V projection on a second stream beside the query path (A/B: bench.py --no-kv-side)
+        self._kv_stream = None
         self.xattn_transposed = True           # cross-attention backward writes d(K|V) transposed + the bias sums itself (A/B: bench.py --attn-q64-two-kernels)
         self._dw_stream, self._dw_pending = None, False
         self.seed_base = 0
@@ -482,6 +484,22 @@ class QformerConnectorHIP:
         x32, x16 = self.x0_32, self.x0_16
         scale = 64 ** -0.5
         pd = self.p_drop
+        kv_ev = None
+        if self.kv_side:
+            # the K | V projections of the encoder states depend on nothing of the query path: all layers' projections go to a second
+            # stream up front and run beside the chain of small (2048-row) kernels, which leave 40 % of the CUs idle
+            if self._kv_stream is None:
+                self._kv_stream = torch.cuda.Stream(device=self.dev)
+            main = torch.cuda.current_stream(self.dev)
+            self._kv_stream.wait_stream(main)
+            kv_ev = []
+            with torch.cuda.stream(self._kv_stream):
+                for i in range(self.Lq):
+                    p = f"{CON}qformer.layer.{i}."
+                    H.gemm(self.enc, self.W16(p + "crossattention.self.key.weight", 2 * d), self.sv[i]["kv"], E, 2 * d, d, bias=self.P32(p + "crossattention.self.key.bias", 2 * d))
+                    ev = torch.cuda.Event()
+                    ev.record(self._kv_stream)
+                    kv_ev.append(ev)
         for i in range(self.Lq):
             p, s = f"{CON}qformer.layer.{i}.", self.sv[i]
             sd = [(self.seed_base + 16 * i + k) & 0xFFFFFFFFFFFFFFFF for k in range(5)]   # attn-self, out1, attn-cross, out2, out3
@@ -498,7 +516,10 @@ class QformerConnectorHIP:
                             y16=s["x1_16"], y32=s["x1_32"], stats=s["st1"])
             # cross-attention: K queries x T encoder states (unmasked)
             H.gemm(s["x1_16"], self.W16(p + "crossattention.self.query.weight"), s["qc"], R, d, d, bias=self.P32(p + "crossattention.self.query.bias"))
-            H.gemm(self.enc, self.W16(p + "crossattention.self.key.weight", 2 * d), s["kv"], E, 2 * d, d, bias=self.P32(p + "crossattention.self.key.bias", 2 * d))
+            if kv_ev is None:
+                H.gemm(self.enc, self.W16(p + "crossattention.self.key.weight", 2 * d), s["kv"], E, 2 * d, d, bias=self.P32(p + "crossattention.self.key.bias", 2 * d))
+            else:
+                torch.cuda.current_stream(self.dev).wait_event(kv_ev[i])
             ad = H.attn_desc(s["qc"], s["kv"], s["kv"], s["a_c"], s["lse_c"], batch=nt * B, hq=self.heads, hkv=self.heads, sq=K, sk=T,
                              hd=64, scale=scale, q_off=0, k_off=0, v_off=d, dropout_p=pd, dropout_seed=sd[2], o_f32=s["a_c32"])
             H.attention_fwd(ad)
@@ -635,6 +656,7 @@ class QformerConnectorHIP:
             if not xt:
                 H.transpose_to_bf16(self.dkv, E, 2 * d, self.tKV, self.Ep)
                 H.colsum(self.dkv, E, 2 * d, 2 * d, self.G32(p + "crossattention.self.key.bias", 2 * d))
+            # (this GEMM on the dW side stream beside the dX chain: connector backward 6.11 -> 6.29 ms, slower; it stays here)
             H.gemm(self.tKV, self.tE, self._gwide(p + "crossattention.self.key.weight", 2 * d), 2 * d, d, self.Ep)
             H.gemm(dq, self.wT[f"{i}.c.q"], dx, R, d, d, residual=dpre)                         # dx := d x1_32
             # --- self-attention block: x1 = LN(pre1), pre1 = a_s@Wo^T + b + x_in
