@@ -656,7 +656,8 @@ class QformerConnectorHIP:
             if not xt:
                 H.transpose_to_bf16(self.dkv, E, 2 * d, self.tKV, self.Ep)
                 H.colsum(self.dkv, E, 2 * d, 2 * d, self.G32(p + "crossattention.self.key.bias", 2 * d))
-            # (this GEMM on the dW side stream beside the dX chain: connector backward 6.11 -> 6.29 ms, slower; it stays here)
+            # (this GEMM on the dW side stream beside the dX chain: connector backward 6.11 -> 6.29 ms, slower; on a third stream with a
+            #  double-buffered d(K|V)^T: 6.01 / 6.11 vs 6.09 / 6.07 ms, equal — the backward is bound by its total work, not by exposed latency)
             H.gemm(self.tKV, self.tE, self._gwide(p + "crossattention.self.key.weight", 2 * d), 2 * d, d, self.Ep)
             H.gemm(dq, self.wT[f"{i}.c.q"], dx, R, d, d, residual=dpre)                         # dx := d x1_32
             # --- self-attention block: x1 = LN(pre1), pre1 = a_s@Wo^T + b + x_in
