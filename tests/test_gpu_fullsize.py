@@ -223,3 +223,41 @@ def test_turbo_variant_is_the_same_encoder_problem():
     # resolved by NAME too when no explicit target_layer_ids / depth table entry would apply
     assert DeSTA25Config(llm_config=FULL_CONFIGS["desta25_llama31-8B_Qformer6L"]["llm_config"], encoder_model_id="/models/whisper-large-v3-turbo",
                          encoder_config=dict(FULL_CONFIGS["desta25_llama31-8B_Qformer6L"]["encoder_config"])).target_layer_ids == [7, 15, 23, 31]
+
+
+@pytest.mark.gpu
+def test_cross_attention_backward_one_pass_at_full_size():
+    """The Q-Former's cross-attention backward at the headline size (32 (tap, batch) groups x 20 heads, 64 queries over 1500
+    encoder frames, dropout on; K | V 246 MB): the one-pass kernel — row-major outputs and transposed outputs + bias sums — against
+    the separate dQ and dK / dV kernels on the same inputs.  Same arithmetic per element, different summation order for dQ only."""
+    from desta import _hip as H
+    B, Hh, Sq, Sk, D = 32, 20, 64, 1500, 64
+    g = torch.Generator(device="cuda").manual_seed(3)
+    q = (torch.randn(B * Sq, Hh * D, generator=g, device="cuda") * 0.5).to(torch.bfloat16)
+    kv = (torch.randn(B * Sk, 2 * Hh * D, generator=g, device="cuda") * 0.5).to(torch.bfloat16)
+    do = torch.randn(B * Sq, Hh * D, generator=g, device="cuda").to(torch.bfloat16)
+    o = torch.zeros(B * Sq, Hh * D, dtype=torch.bfloat16, device="cuda")
+    o32 = torch.zeros(B * Sq, Hh * D, dtype=torch.float32, device="cuda")
+    lse = torch.zeros(B, Hh, Sq, device="cuda")
+    d = H.attn_desc(q, kv, kv, o, lse, batch=B, hq=Hh, hkv=Hh, sq=Sq, sk=Sk, hd=D, scale=D ** -0.5, k_off=0, v_off=Hh * D,
+                    dropout_p=0.1, dropout_seed=(7 << 40) | 5, o_f32=o32)
+    H.attention_fwd(d)
+    res = {}
+    for one_pass in (1, 0):
+        H.attention_set_option(4, one_pass)
+        dq = torch.zeros(B * Sq, Hh * D, dtype=torch.bfloat16, device="cuda")
+        dkv = torch.zeros(B * Sk, 2 * Hh * D, dtype=torch.bfloat16, device="cuda")
+        H.attention_bwd(d, do, dq, dkv, dkv, dk_off=0, dv_off=Hh * D)
+        res[one_pass] = (dq, dkv)
+    H.attention_set_option(4, 1)
+    assert torch.equal(res[1][1], res[0][1])                              # dK / dV: the same sums in the same order, bit for bit
+    e = float((res[1][0].float() - res[0][0].float()).norm() / res[0][0].float().norm())
+    assert e < 5e-3, e
+    t = torch.zeros(2 * Hh * D, B * Sk, dtype=torch.bfloat16, device="cuda")
+    bias = torch.zeros(2 * Hh * D, device="cuda")
+    dq_t = torch.zeros_like(res[1][0])
+    H.attention_bwd(d, do, dq_t, dkv_t=(t, B * Sk, bias))
+    assert torch.equal(dq_t, res[1][0]) and torch.equal(t, res[1][1].t().contiguous())
+    ref = res[1][1].float().sum(0)
+    assert float((bias - ref).norm() / ref.norm()) < 4e-3
+    assert torch.isfinite(bias).all()
