@@ -1094,10 +1094,14 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq8_k(AttnArgs p, float* __re
 
 // D = 64: two blocks per CU (<= 256 VGPR + AGPR; the dropout variant took 284 and ran ONE block per CU: 250 us per cross-attention
 // launch); D = 128 keeps its 384 registers and one block per CU
-template <int D, bool DROP>
-__global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkdv_k(AttnArgs p) {
+// NW = waves per block (32 keys each).  NW = 2 (64-key blocks, D = 128 causal): twice as many, half as long work items — the
+// 128-key form's 320 blocks of length 5..1 on 256 CUs run at 0.75 of the balanced makespan, 640 blocks of length 10..1 at 0.93 —
+// for twice the Q / dO staging per wave.
+template <int D, bool DROP, int NW = 4>
+__global__ __launch_bounds__(64 * NW, (NW == 4 && D == 64) ? 2 : 1) void attn_bwd_dkdv_k(AttnArgs p) {   // (NW = 2: 384 registers = one wave per SIMD, so two 2-wave blocks share a CU anyway)
     constexpr int QR = (D == 128) ? ATTN_DKDV_QR : 32;
-    constexpr int LDS_LOOP = 2 * QR * D * 2 + 2 * QR * 4, LDS_EPI = 4 * 32 * 64 * 4;     // epilogue: a 32 x 64 fp32 transpose tile per wave
+    constexpr int NT = 64 * NW, KB = 32 * NW;
+    constexpr int LDS_LOOP = 2 * QR * D * 2 + 2 * QR * 4, LDS_EPI = NW * 32 * 64 * 4;     // epilogue: a 32 x 64 fp32 transpose tile per wave
     __shared__ __attribute__((aligned(16))) char lds[LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI];
     char* qimg = lds;
     char* gimg = lds + QR * D * 2;
@@ -1107,7 +1111,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkdv_k(AttnArgs
     // 1-D grid with the key block as the SLOWEST index: under the causal mask low key blocks sweep the
     // most query tiles, so the heaviest work items are dispatched first (longest-processing-time order)
     const int nhb = p.Hkv * p.B;
-    const int kb0 = (blockIdx.x / nhb) * 128, k0 = kb0 + wave * 32;
+    const int kb0 = (blockIdx.x / nhb) * KB, k0 = kb0 + wave * 32;
     const int hk = (blockIdx.x % nhb) % p.Hkv, b = (blockIdx.x % nhb) / p.Hkv, group = p.Hq / p.Hkv;
     const int kcol = k0 + (lane & 31), kc = min(kcol, p.Sk - 1);
     const int kv_lo = p.kv_start ? max(0, min(p.kv_start[b], p.Sk)) : 0;
@@ -1135,13 +1139,13 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkdv_k(AttnArgs
     // (query head of the GQA group, QR-row query slice) flattened into one iteration space; the Q / dO
     // tiles and their lse / delta rows are register-staged TWO iterations ahead.
     const int nq = qt_hi - qt_lo, n_it = group * nq;
-    stage_t<D, QR> qr0 = {}, gr0 = {}, qr1 = {}, gr1 = {};
+    stage_t<D, QR, NT> qr0 = {}, gr0 = {}, qr1 = {}, gr1 = {};
     float ls0 = 0.f, dl0 = 0.f, ls1 = 0.f, dl1 = 0.f;
 #define DESTA_Q_FETCH(IT, QR_, GR, LS, DL)                                                                      \
     {                                                                                                          \
         const int h_ = hk * group + (IT) / nq, qt_ = qt_lo + (IT) % nq;                                        \
-        QR_ = tile_load<D, QR>(p.Q + (long)b * p.q_bs + (long)h_ * D, p.q_rs, qt_ * QR, p.Sq - 1);            \
-        GR = tile_load<D, QR>(p.dO + (long)b * p.do_bs + (long)h_ * D, p.do_rs, qt_ * QR, p.Sq - 1);          \
+        QR_ = tile_load<D, QR, NT>(p.Q + (long)b * p.q_bs + (long)h_ * D, p.q_rs, qt_ * QR, p.Sq - 1);        \
+        GR = tile_load<D, QR, NT>(p.dO + (long)b * p.do_bs + (long)h_ * D, p.do_rs, qt_ * QR, p.Sq - 1);      \
         if (threadIdx.x < QR) {                                                                                \
             const long st_ = ((long)b * p.Hq + h_) * p.Sq + min(qt_ * QR + (int)threadIdx.x, p.Sq - 1);       \
             LS = p.lse[st_];                                                                                   \
@@ -1151,8 +1155,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkdv_k(AttnArgs
 #define DESTA_Q_STAGE(IT, QR_, GR, LS, DL)                                                                      \
     __syncthreads();                                                                                           \
     asm volatile("; stage " #QR_ ::: "memory");                                                                \
-    tile_store<D, QR>(qimg, QR_);                                                                              \
-    tile_store<D, QR>(gimg, GR);                                                                               \
+    tile_store<D, QR, NT>(qimg, QR_);                                                                          \
+    tile_store<D, QR, NT>(gimg, GR);                                                                           \
     if (threadIdx.x < QR) { lse_s[threadIdx.x] = LS; dlt_s[threadIdx.x] = DL; }                                \
     __syncthreads();                                                                                           \
     if ((IT) + 2 < n_it) DESTA_Q_FETCH((IT) + 2, QR_, GR, LS, DL)
@@ -1755,7 +1759,12 @@ extern "C" int desta_attention_bwd(const desta_attn_desc* d, float* workspace, v
             else if (hpb == 4) hipLaunchKernelGGL((attn_bwd_dq8_k<128, true, 4>), g8, dim3(512), 0, st, a, workspace);
             else if (hpb == 2) hipLaunchKernelGGL((attn_bwd_dq8_k<128, true, 2>), g8, dim3(512), 0, st, a, workspace);
             else hipLaunchKernelGGL((attn_bwd_dq8_k<128, true, 1>), g8, dim3(512), 0, st, a, workspace);
-            if (d->dK) hipLaunchKernelGGL((attn_bwd_dkdv_k<128, false>), gk_, dim3(256), 0, st, a);
+            if (d->dK) {
+                if (g_attn_opt[5] && a.causal) {                            // 64-key blocks: better balanced under the causal mask
+                    dim3 gk2((unsigned)((a.Sk + 63) / 64) * a.Hkv * a.B);
+                    hipLaunchKernelGGL((attn_bwd_dkdv_k<128, false, 2>), gk2, dim3(128), 0, st, a);
+                } else hipLaunchKernelGGL((attn_bwd_dkdv_k<128, false>), gk_, dim3(256), 0, st, a);
+            }
         } else {
             if (!a.causal) hipLaunchKernelGGL((attn_bwd_dq8_k<64, false, 1>), g8, dim3(512), 0, st, a, workspace);
             else if (hpb == 2) hipLaunchKernelGGL((attn_bwd_dq8_k<64, true, 2>), g8, dim3(512), 0, st, a, workspace);

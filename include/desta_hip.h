@@ -316,7 +316,9 @@ int desta_attention_set_concurrent_bwd(int on);
  *   which 3: 1 = backward on round 2's path (separate delta launch, 4-wave dQ kernel on a side stream beside dK / dV) instead
  *            of the 8-wave dQ kernel that computes delta itself (default 0; not available with rope_cos_sin);
  *   which 4: 1 (default) = one query tile (seq_q <= 64, head_dim 64, seq_k >= 256, no GQA, dK / dV requested): dQ, dK, dV in ONE
- *            pass over K / V; 0 = the separate dQ and dK / dV kernels. */
+ *            pass over K / V; 0 = the separate dQ and dK / dV kernels;
+ *   which 5: 1 = causal head_dim-128 dK / dV on 64-key blocks of two waves (640 shorter work items instead of 320; measured
+ *            SLOWER on the LLM shape, 207 vs 194 us: default 0). */
 int desta_attention_set_option(int which, int value);
 
 /* layer_prompts[j].expand(B,-1,-1) for all taps at once (modeling_desta25.py:589): prompts fp32
