@@ -74,10 +74,10 @@ for name, (B, Hq, Hkv, S, D, causal) in {"llm S=640 D=128 causal GQA": (8, 32, 8
     extra += "]"
     bw = t_us(lambda: hip.attention_bwd(d, do, dqkv, dqkv, dqkv, dq_off=0, dk_off=wq, dv_off=wq + wkv))
     if causal and D == 128:
-        hip.attention_set_option(5, 1 - int(os.environ.get("ATTN_DKDV64_DEFAULT", "1")))
+        hip.attention_set_option(5, 1)                                       # 64-key dK / dV blocks of two waves (default off)
         other = t_us(lambda: hip.attention_bwd(d, do, dqkv, dqkv, dqkv, dq_off=0, dk_off=wq, dv_off=wq + wkv))
-        hip.attention_set_option(5, int(os.environ.get("ATTN_DKDV64_DEFAULT", "1")))
-        print(f"   backward with option 5 (64-key dK / dV blocks) flipped: {other:7.1f} us (default above: {bw:7.1f} us)", flush=True)
+        hip.attention_set_option(5, 0)
+        print(f"   backward with option 5 (64-key dK / dV blocks): {other:7.1f} us (default above: {bw:7.1f} us)", flush=True)
     hip.attention_set_concurrent_bwd(False)
     bw_serial = t_us(lambda: hip.attention_bwd(d, do, dqkv, dqkv, dqkv, dq_off=0, dk_off=wq, dv_off=wq + wkv))
     hip.attention_set_concurrent_bwd(True)
