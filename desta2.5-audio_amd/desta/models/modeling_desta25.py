@@ -781,14 +781,17 @@ class CausalLMHIP:
     def _lora_fwd(self, i: int, ly, s, M: int) -> None:
         """s["qkv"] (plain layout, before the rotary embedding) += adapters of layer i applied to self.hb."""
         lo, h, KP = self.lora, self.h, self.LORA_KP
-        t = s["lt"]
-        if lo["p_now"] > 0.0:                                                    # peft: every adapted module has its OWN dropout
-            for j in range(len(LORA_TARGETS)):
-                H.dropout_bf16(self.hb, self.lxd, M, h, h, lo["p_now"], self._lora_seed(i, j))
-                H.gemm(self.lxd, ly["a16"][16 * j:16 * j + 16], t[:, 16 * j:], M, 16, h, ldc=KP)
-        else:
-            H.gemm(self.hb, ly["a16"], t, M, KP, h)
-        H.gemm(t, ly["b16"], s["qkv"], M, self.qkvw, KP, residual=s["qkv"])
+        tT = s["lt"]                                                             # t^T [64, Mp]: rows 16p.. = A_p drop_p(x)^T
+        for j in range(len(LORA_TARGETS)):
+            xin = self.hb
+            if lo["p_now"] > 0.0:                                                # peft: every adapted module has its OWN dropout
+                xin = s["lxd"][j]                                                # kept for the backward's dA (3 x [M, h] bf16 per layer)
+                H.dropout_bf16(self.hb, xin, M, h, h, lo["p_now"], self._lora_seed(i, j))
+            # 16 output rows: the weight-streaming (decode) kernel, with the TOKENS as its streamed operand (x is read at HBM
+            # rate; as t = x A^T with N = 16 the tile kernel ran 40 blocks at 0.7 TB/s)
+            H.gemm(ly["a16"][16 * j:16 * j + 16], xin, tT[16 * j:16 * j + 16], 16, self.Mp, h, ldc=self.Mp)
+        Mg = M if M % 8 == 0 else self.Mp                                         # transposed-storage A wants a multiple of 8 rows: the pad rows of t^T are zero, q|k|v has Mp rows
+        H.gemm(tT, ly["b16"], s["qkv"], Mg, self.qkvw, KP, trans_a=True, lda=self.Mp, residual=s["qkv"])
 
     def _lora_bwd(self, i: int, ly, s, dhb, M: int) -> None:
         """Adapter gradients of layer i into the arena, and dhb [M, h] += their input gradient.  self.dqkv = d(q|k|v) of the
@@ -796,21 +799,20 @@ class CausalLMHIP:
         lo, h, KP, Mp = self.lora, self.h, self.LORA_KP, self.Mp
         ar, r = lo["arena"], lo["r"]
         t, dt = s["lt"], self.ldt
-        H.rmsnorm_fwd(self.xs[i], ly["n1"], self.c.rms_norm_eps, self.lhb, self.lr1)           # the projection's input again (not kept by the forward)
+        if lo["p_now"] <= 0.0:
+            H.rmsnorm_fwd(self.xs[i], ly["n1"], self.c.rms_norm_eps, self.lhb, self.lr1)       # the projection's input again (not kept by the forward)
         outs = (self.hq * self.hd, self.hkv * self.hd, self.hkv * self.hd)
         col = 0
         for j, nb in enumerate(self._lora_names(i, "B")):                                      # dB_p = scaling * dY_p^T t_p
-            H.gemm(self.dqkv[:, col:], t[:, 16 * j:], ar.grad(nb), outs[j], r, Mp, trans_a=True, trans_b=True, lda=self.qkvw, ldb=KP, alpha=lo["scaling"])
+            H.gemm(self.dqkv[:, col:], t[16 * j:16 * j + 16], ar.grad(nb), outs[j], r, Mp, trans_a=True, lda=self.qkvw, ldb=Mp, alpha=lo["scaling"])
             col += outs[j]
         H.gemm(self.dqkv, ly["b16"], dt, M, KP, self.qkvw, trans_b=True, ldb=KP)                # dt = dY (scaling B)
         na = self._lora_names(i, "A")
         if lo["p_now"] > 0.0:
             for j in range(len(LORA_TARGETS)):
-                H.dropout_bf16(self.lhb, self.lxd, M, h, h, lo["p_now"], self._lora_seed(i, j))
-                H.gemm(dt[:, 16 * j:], self.lxd, ar.grad(na[j]), r, h, Mp, trans_a=True, trans_b=True, lda=KP, ldb=h)
-                H.gemm(dt, ly["a16p"][j], self.lxd, M, h, KP, trans_b=True, ldb=h)            # d drop_p(x) = dt_p A_p
-                H.dropout_bf16(self.lxd, self.lxd, M, h, h, lo["p_now"], self._lora_seed(i, j))
-                dhb[:M].add_(self.lxd[:M])
+                H.gemm(dt[:, 16 * j:], s["lxd"][j], ar.grad(na[j]), r, h, Mp, trans_a=True, trans_b=True, lda=KP, ldb=h)
+                # dhb += drop_p'(dt_p A_p): the mask and the accumulation ride in the GEMM's epilogue (element index m * h + n, as forward)
+                H.gemm(dt, ly["a16p"][j], dhb, M, h, KP, trans_b=True, ldb=h, residual=dhb, dropout_p=lo["p_now"], dropout_seed=self._lora_seed(i, j))
         else:
             ga = ar.grads[ar.offsets[na[0]]:ar.offsets[na[0]] + 3 * r * h].view(3 * r, h) if r == 16 else None
             if ga is not None:
@@ -840,7 +842,7 @@ class CausalLMHIP:
                 s["pre"] = b16(M, self.qkvw)
             self.sv.append(s)
         self.rf = torch.empty(M, dtype=F32, device=dev)
-        self.hb = b16(M, h)
+        self.hb = torch.zeros(_r64(M), h, dtype=BF16, device=dev)                           # (rows >= M stay zero: the adapters' token-streaming GEMM reads whole 64-row groups)
         self.hbc = b16(M, h)                                                                 # compact target rows (lm_head in / dX out)
         self.act = b16(M, self.I)
         self.logits = torch.zeros(M, self.Vp, dtype=BF16, device=dev)                        # pad columns stay 0
@@ -854,10 +856,13 @@ class CausalLMHIP:
         if self.lora is not None:
             # token-reduction operands of the adapter gradients: Mp rows, pad rows zero for good (kernels write rows < M only)
             z = lambda *sh: torch.zeros(*sh, dtype=BF16, device=dev)
-            self.lhb, self.lxd, self.ldt = z(self.Mp, h), z(self.Mp, h), z(self.Mp, self.LORA_KP)
+            self.lhb, self.ldt = z(self.Mp, h), z(self.Mp, self.LORA_KP)
             self.lr1 = torch.empty(M, dtype=F32, device=dev)
             for s in self.sv:
-                s["lt"] = z(self.Mp, self.LORA_KP)
+                s["lt"] = z(self.LORA_KP, self.Mp)                             # t^T
+                s["qkv"] = z(self.Mp, self.qkvw)                               # (Mp rows: see `_lora_fwd`)
+                if self.lora["p"] > 0.0:
+                    s["lxd"] = [z(self.Mp, h) for _ in LORA_TARGETS]         # the three dropped inputs of the layer (training)
 
     def forward(self, x0_filler, B: int, S: int, kv_start: Optional[torch.Tensor], labels: Optional[torch.Tensor], need_grad: bool,
                 pos_shift: Optional[torch.Tensor] = None, cos_sin: Optional[torch.Tensor] = None, last_logits: Optional[torch.Tensor] = None,
@@ -904,7 +909,7 @@ class CausalLMHIP:
                 H.gemm(self.hb, ly["wqkv"], s["qkv"], M, self.qkvw, h)
                 self._lora_fwd(i, ly, s, M)
                 if "pre" in s:
-                    s["pre"].copy_(s["qkv"])                                  # q/k-norm backward wants the projection before the norm
+                    s["pre"].copy_(s["qkv"][:M])                              # q/k-norm backward wants the projection before the norm
             else:
                 H.gemm(self.hb, ly["wqkv"] if self.lora is None else self._lora_merged(i), s["qkv"], M, self.qkvw, h, preact=s.get("pre"))
             if fused:
