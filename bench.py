@@ -120,7 +120,7 @@ def cpu_baseline(cfg, B, S_ctx, S_tgt, threads):
             "value_fastest_precision_mix": 1.0 / full_mix}
 
 
-def cpu_full_step(cfg, S_ctx, S_tgt, threads):
+def cpu_full_step(cfg, S_ctx, S_tgt, threads, steps=2):
     """One REAL full-depth oracle step at true shapes, B = 1 (32 Whisper + 4 x 6 Q-Former + 32 LLM layers, lm_head, CE, backward,
     clip, Adafactor), fp32: validates the one-layer extrapolation of `cpu_baseline`.  Minutes of CPU time and ~45 GB of host
     memory: not part of the default run."""
@@ -143,7 +143,7 @@ def cpu_full_step(cfg, S_ctx, S_tgt, threads):
     batch = O.synthetic_batch(d, B=1, S_ctx=S_ctx, S_tgt=S_tgt, seed=1)
     wave = (0.1 * torch.randn(1, 480000)).clamp(-1, 1)
     ts = []
-    for i in range(2):
+    for i in range(steps):
         t0 = time.perf_counter()
         batch["batch_features"] = O.logmel(wave, d.n_mels)
         loss, _, _, _ = O.train_step(w, d, batch, st, 1e-4)
@@ -258,7 +258,8 @@ def main():
     ap.add_argument("--tgt", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
-    ap.add_argument("--encoder-overlap", action="store_true", help="A/B: next batch's Whisper forward on its own stream beside the LLM instead of at the end of the step")
+    ap.add_argument("--encoder-overlap", action=argparse.BooleanOptionalAction, default=True,
+                    help="next batch's frozen Whisper forward on its own HIP stream beside the LLM (default on; --no-encoder-overlap: at the end of the step on the main stream)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for rehearsals)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--persistent-gemm", action="store_true", help="A/B: enable the persistent GEMM kernel")
@@ -266,7 +267,9 @@ def main():
     ap.add_argument("--repeat", type=int, default=1, help="repeat the timed region (reports the best), for A/B runs")
     ap.add_argument("--no-dw-overlap", action="store_true", help="A/B: Q-Former weight gradients on the main stream")
     ap.add_argument("--gemm-4phase", action="store_true", help="A/B: the 4-phase (16 MFMAs per phase) GEMM schedule")
-    ap.add_argument("--connector-overlap", action="store_true", help="A/B: the connector's backward joins all-reduce + Adafactor on the side stream beside the next Whisper forward (measured -0.4 ms per step)")
+    ap.add_argument("--connector-overlap", action=argparse.BooleanOptionalAction, default=True,
+                    help="the connector's backward joins all-reduce + Adafactor on the side stream beside the next batch's frozen Whisper forward (default on)")
+    ap.add_argument("--timed-gemm-events", action="store_true", help="A/B: HIP events around every GEMM launch INSIDE the timed region too (rounds 1-3 did; ~800 event records per step)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group and run the gradient all-reduce even at WORLD_SIZE 1 (one-GPU rehearsal of the N > 1 path over RCCL)")
     ap.add_argument("--small-gemm-ring", type=int, default=None, help="A/B: option 6 of desta_gemm_set_option (0 = the 128x128 GEMM never takes its four-slot ring form, 1 = default, 2 = always)")
     ap.add_argument("--splitk-inkernel", action="store_true", help="A/B: reduce the K-slices of tail tiles inside the GEMM launch (scattered, ticketed) instead of by the fix-up launch")
@@ -340,7 +343,7 @@ def main():
     t0 = time.time()
     model = DeSTA25AudioModel(cfg, weights=RandomWeights(cfg, dev, seed=0), device=dev)
     args = TrainingArguments(learning_rate=1e-4, weight_decay=0.01, warmup_steps=5000, max_steps=10 ** 6, logging_steps=10 ** 9,
-                             overlap_comm=not a.no_overlap, overlap_encoder=a.encoder_overlap,
+                             overlap_comm=not a.no_overlap, overlap_encoder=a.encoder_overlap and not a.no_overlap,
                              overlap_connector_backward=a.connector_overlap)
     trainer = DeSTA25Trainer(model, args=args)
     if a.no_dw_overlap:
@@ -414,26 +417,35 @@ def main():
     run(a.warmup, 0)
     fence()
     trainer.comm_profile = [] if (world > 1 or a.force_dist) else None     # HIP events around the collective / the main stream's wait
-    H.gemm_profile_start()
+    if a.timed_gemm_events:
+        H.gemm_profile_start()
     t0 = time.perf_counter()
     loss = run(a.steps, a.warmup, mark=True)
     fence()
     elapsed = time.perf_counter() - t0
-    prof = H.gemm_profile_stop(by_kernel=True)
+    prof_timed = H.gemm_profile_stop(by_kernel=True) if a.timed_gemm_events else None
     comm, trainer.comm_profile = trainer.comm_profile, None
     per_step = [x.elapsed_time(y) for x, y in zip(step_events[:-1], step_events[1:])]
-    # untimed extra pass: HIP events around every HBM-bound / attention launch (algorithmic bytes / FLOP per call from the wrappers)
-    kprof, kp_steps = {}, 3
+    # UNTIMED, UN-OVERLAPPED pass (the `roofline` leg): the same steps with EVERY side stream off — optimizer tail, connector backward,
+    # encoder prefetch, K | V projections and weight gradients all in line on the main stream — and HIP events around every GEMM
+    # launch and every tagged HBM-bound / attention launch.  Beside another stream two kernels time-share the chip and each one's
+    # duration reads long for a step that is SHORTER; the timed region above keeps every overlap (steps/s is the metric), the
+    # per-kernel rates come from here (a kernel alone on the device, in situ: same operands, same cache state as in the step).
+    prof, kprof, kp_steps = {}, {}, 3
     if not a.no_kernel_pass:                             # every rank steps (the all-reduce is collective); rank 0 records
-        # ... with the optimizer tail on the MAIN stream for these steps: beside the next Whisper forward (the timed region's
-        # overlap) the two time-share the chip and every per-kernel duration of either stream reads long
-        side, trainer._side = trainer._side, None
+        saved = (trainer._side, trainer._enc_stream, model.connector.kv_side, model.connector.overlap_dw)
+        trainer.wait_update()
+        torch.cuda.synchronize()
+        trainer._side, trainer._enc_stream, model.connector.kv_side, model.connector.overlap_dw = None, None, False, False
+        run(1, a.warmup + a.steps)                       # one un-recorded step: the overlapped pipeline's in-flight prefetch drains
         if rank == 0:
+            H.gemm_profile_start()
             H.kernel_profile_start()
-        run(kp_steps, a.warmup + a.steps)
+        run(kp_steps, a.warmup + a.steps + 1)
         if rank == 0:
             kprof = H.kernel_profile_stop()
-        trainer._side = side
+            prof = H.gemm_profile_stop(by_kernel=True)
+        trainer._side, trainer._enc_stream, model.connector.kv_side, model.connector.overlap_dw = saved
     fence()
     n_launch, flops, gemm_ms = prof.get(2, (0, 0.0, 0.0))                 # the dominant kernel: gemm_bf16_nt_256_kernel
     n_other = sum(v[0] for k, v in prof.items() if k != 2)
@@ -447,15 +459,19 @@ def main():
 
     if rank == 0:
         achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        # HBM bytes per launch of the dominant kernel: from the separate rocprofv3 --pmc passes of this same
-        # command (profiles/, FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes); null if absent
-        traffic = None
-        tpath = next((pth for pth in (os.path.join(ROOT, "profiles", f) for f in ("r03_gemm_hbm_traffic.json", "r02_gemm_hbm_traffic.json",
-                                                                                    "r01_c_gemm_hbm_traffic.json")) if os.path.isfile(pth)), "")
+        # L2-boundary bytes per launch of the dominant kernel: from separate rocprofv3 --pmc passes of this same command, committed
+        # under profiles/ (FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes) — a STORED record, not a counter of
+        # this run (hardware counters need the profiler around the process); null if absent
+        traffic, traffic_src = None, None
+        tpath = next((pth for pth in (os.path.join(ROOT, "profiles", f) for f in ("r04_gemm_hbm_traffic.json", "r03_gemm_hbm_traffic.json",
+                                                                                    "r02_gemm_hbm_traffic.json")) if os.path.isfile(pth)), "")
         if a.config == "desta25_llama31-8B_Qformer6L" and os.path.isfile(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
             traffic = tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"]
+            traffic_src = {"measured_in_this_run": False, "file": os.path.relpath(tpath, ROOT),
+                           "what": "TCC FETCH_SIZE x 2 + WRITE_SIZE per launch (L2 boundary: Infinity-Cache hits included), separate --pmc passes",
+                           "hbm_side": {k: tj[k] for k in ("dram_read_bytes_per_launch", "dram_read_counter", "hbm_read_fraction_of_fetch") if k in tj} or None}
         ms_step = 1e3 * elapsed / a.steps
         # reference point measured on the same hardware with tools/hf_step_bench.py (the step composed from stock PyTorch-ROCm /
         # transformers modules, as the reference composes it); NOT `vs_baseline` (BASELINE.md publishes no number for this metric)
@@ -470,11 +486,11 @@ def main():
                                  "(profiles/r02_hf_pytorch_step.log); only the ratio uses this run's ms_per_step")
         mean_ps = sum(per_step) / max(1, len(per_step))
         sd_ps = (sum((x - mean_ps) ** 2 for x in per_step) / max(1, len(per_step) - 1)) ** 0.5
-        # executed FLOP per step: every GEMM launch of the timed region (HIP-event records carry 2MNK) + the attention kernels'
-        # MFMA FLOP from the kernel pass (4 Sq Sk D per head forward, x2.5 backward, halved under the causal mask)
+        # executed FLOP per step: every GEMM launch of a step (HIP-event records carry 2MNK) + the attention kernels'
+        # MFMA FLOP (4 Sq Sk D per head forward, x2.5 backward, halved under the causal mask), both from the un-overlapped pass
         attn = {t: v for t, v in kprof.items() if t.startswith("attn_")}
         attn_flop_step = sum(v[1] for v in attn.values()) / kp_steps
-        gemm_flop_step = (flops + flops_other) / a.steps
+        gemm_flop_step = (flops + flops_other) / kp_steps
         exec_flop = gemm_flop_step + attn_flop_step
         hbm_kernels = {t: {"calls_per_step": v[0] / kp_steps, "algorithmic_GB_per_step": v[1] / kp_steps / 1e9, "ms_per_step": v[2] / kp_steps,
                            "GBps": v[1] / (v[2] * 1e-3) / 1e9 if v[2] > 0 else 0.0, "frac_of_hbm_peak": (v[1] / (v[2] * 1e-3) / 1e9 / HBM_PEAK_GBS) if v[2] > 0 else 0.0}
@@ -483,9 +499,21 @@ def main():
                             "TFLOPs": v[1] / (v[2] * 1e-3) / 1e12 if v[2] > 0 else 0.0,
                             "frac_of_mfma_peak": (v[1] / (v[2] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS) if v[2] > 0 else 0.0}
                         for t, v in sorted(attn.items())}
+        overlaps = []
+        if not a.no_overlap:
+            overlaps.append("all-reduce + clip + Adafactor + weight re-cast of step t on a side stream")
+            if a.connector_overlap:
+                overlaps.append("the connector's backward of step t on that side stream too")
+        if a.encoder_overlap:
+            overlaps.append("the frozen Whisper forward of batch t+1 on its own HIP stream beside the connector / LLM of batch t")
+        elif not a.no_overlap:
+            overlaps.append("the frozen Whisper forward of batch t+1 on the main stream at the end of step t, beside the side-stream tail")
         out = {
             "metric": "train steps/sec (node) Whisper-v3+Llama3.1-8B Q-Former6L at 1/2/4/8 MI355X",
-            "value": world * a.steps / elapsed, "unit": "steps/s",
+            # OPTIMIZER steps per second of the node; one step = one update with per-GPU batch B, global batch B x N
+            "value": a.steps / elapsed, "unit": "steps/s",
+            "samples_per_s": world * B * a.steps / elapsed,
+            "gpu_batch_steps_per_s": world * a.steps / elapsed,           # per-GPU batch-steps summed over the node (what rounds 1-3 printed as `value`)
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
             "ms_per_step_mean_sd": [mean_ps, sd_ps], "ms_per_step_min_max": [min(per_step), max(per_step)] if per_step else None,
             "ms_per_step_each": [round(x, 2) for x in per_step],        # main-stream event deltas, in order
@@ -495,11 +523,11 @@ def main():
                                    f"S={S} ({a.ctx} ctx + {cfg.prompt_size} audio + {a.tgt} target tokens), random-init weights at true shapes"
                                    + (" + use_lora (rank-16 q/k/v adapters trainable: NOT the headline config)" if a.lora else ""),
                        "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}",
-                       "step_definition": "one pass of the hot path over one per-GPU batch; value = per-GPU batch-steps per second "
-                                          "summed over the node (N x K / max-over-ranks time), weak scaling",
-                       "stream_overlap": ("--encoder-overlap: the frozen Whisper forward of batch t+1 on its own HIP stream beside the LLM of batch t; "
-                                          if a.encoder_overlap else "") +
-                                         "all-reduce + Adafactor + weight re-cast of step t on a side stream beside the Whisper forward of batch t+1",
+                       "step_definition": "one optimizer step of the node: every GPU runs the hot path over its own batch of "
+                                          f"{B} clips (global batch {B * world}), one mean all-reduce of the gradient arena, one update; "
+                                          "value = K / max-over-ranks time (weak scaling: ideal is a constant value as N grows; "
+                                          "samples_per_s = value x global batch is the throughput that grows with N)",
+                       "stream_overlap": "; ".join(overlaps) if overlaps else "none",
                        "training_fast_path": ("off (--full-lm-head): lm_head / CE over the whole token grid, backward over every row"
                                               if a.full_lm_head else
                                               "on: lm_head / CE on the rows that carry a target, LLM backward from the first audio span "
@@ -509,25 +537,31 @@ def main():
             "box_calibration": calib,
             "pytorch_rocm_reference_point": torch_ref,
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_256_kernel", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
+                         "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "measured_in": (f"untimed pass of {kp_steps} steps right after the timed region with every side stream OFF (a kernel's HIP-event "
+                                         "duration beside another stream includes the time-sharing); the timed region runs WITH the overlaps"),
                          # in-situ rate of the dominant kernel / the same kernel alone on this box right before the run (gate_up shape)
-                         "frac_normalised": (achieved / calib["gemm_gate_up_tflops"]) if calib else None,
-                         "launches_per_step": n_launch / a.steps, "avg_launch_us": 1e3 * gemm_ms / max(n_launch, 1),
-                         "flop_per_launch": flops / max(n_launch, 1), "gemm_ms_per_step": gemm_ms / a.steps,
-                         "other_gemm_kernels": {"launches_per_step": n_other / a.steps, "ms_per_step": ms_other / a.steps,
+                         "frac_normalised": (achieved / calib["gemm_gate_up_tflops"]) if calib and achieved > 0 else None,
+                         "launches_per_step": n_launch / kp_steps, "avg_launch_us": 1e3 * gemm_ms / max(n_launch, 1),
+                         "flop_per_launch": flops / max(n_launch, 1), "gemm_ms_per_step": gemm_ms / kp_steps,
+                         "other_gemm_kernels": {"launches_per_step": n_other / kp_steps, "ms_per_step": ms_other / kp_steps,
                                                 "tflops": (flops_other / (ms_other * 1e-3) / 1e12) if ms_other > 0 else 0.0,
-                                                "note": "gemm_bf16_nt_kernel (128x128, incl. transposed-storage dW on a side stream)"},
+                                                "note": "gemm_bf16_nt_kernel family (128x128 and the connector's small-GEMM kernels, incl. transposed-storage dW)"},
                          # the WHOLE step against the same peak: executed FLOP (GEMMs + attention MFMA work; the fast path skips
-                         # lm_head rows without a target and the backward in front of the first audio span) / wall time
+                         # lm_head rows without a target and the backward in front of the first audio span) / wall time of the TIMED region
                          "whole_step": {"executed_flop_per_step": exec_flop, "gemm_flop_per_step": gemm_flop_step,
                                         "attention_flop_per_step": attn_flop_step, "achieved": exec_flop / (ms_step * 1e-3) / 1e12,
                                         "frac": exec_flop / (ms_step * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                                         "reference_flop_per_step": 1.82e14,
                                         "frac_on_reference_flop": 1.82e14 / (ms_step * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS
                                         if a.config.startswith("desta25_llama31-8B") and (B, a.ctx, a.tgt) == (8, 64, 512) else None},
-                         # HBM-bound kernels of the step: ALGORITHMIC bytes / HIP-event time of an untimed 3-step pass, vs 8 TB/s
+                         # HBM-bound kernels of the step: ALGORITHMIC bytes / HIP-event time of the same untimed pass, vs 8 TB/s
                          "hbm_kernels": hbm_kernels, "attention_kernels": attn_kernels},
         }
+        if prof_timed is not None:                                        # --timed-gemm-events: the rounds-1-3 bookkeeping, for comparison
+            n2, f2, m2 = prof_timed.get(2, (0, 0.0, 0.0))
+            out["roofline"]["in_timed_region_with_overlaps"] = {"achieved": f2 / (m2 * 1e-3) / 1e12 if m2 > 0 else 0.0, "gemm_ms_per_step": m2 / a.steps,
+                                                                 "launches_per_step": n2 / a.steps}
         if comm is not None:
             # data-parallel exchange of the timed region (rank 0's events): the flat fp32 gradient arena, one collective per step
             ar = [x.elapsed_time(y) for kind, x, y in comm if kind == "allreduce"]
@@ -536,14 +570,27 @@ def main():
             out["allreduce_ms_min_max"] = [min(ar), max(ar)] if ar else None
             out["bytes_allreduced"] = int(model.arena.grads.numel() * 4)
             out["allreduce_busbw_GBps"] = (2 * (world - 1) / world * out["bytes_allreduced"] / (out["allreduce_ms"] * 1e-3) / 1e9) if ar and world > 1 and out["allreduce_ms"] > 0 else None
-            out["wait_update_stall_ms"] = sum(st) / max(1, len(st))        # main stream idle in front of the connector forward, waiting for the side-stream tail (all-reduce + Adafactor + re-cast) of the previous step
+            out["wait_update_stall_ms"] = sum(st) / max(1, len(st))        # main stream idle in front of the connector forward, waiting for the side-stream tail (connector backward + all-reduce + Adafactor + re-cast) of the previous step
             out["comm_hidden"] = bool(st) and out["wait_update_stall_ms"] < 0.05
             out["comm_backend"] = dist.get_backend() if dist.is_initialized() else None
         if not a.no_cpu_baseline and world == 1:
+            del trainer, model                                            # the host legs below need none of it
+            torch.cuda.empty_cache()
             try:
                 threads = min(len(os.sched_getaffinity(0)), 64)
                 out["cpu_baseline"] = cpu_baseline(cfg, B, a.ctx, a.tgt, threads)
                 out["cpu_baseline"]["debug_config"] = cpu_baseline_debug(threads)
+                if a.steps >= 20 and a.config == "desta25_llama31-8B_Qformer6L" and not a.lora:
+                    # ONE real full-depth step of the oracle at true shapes (B = 1, fp32) in THIS run: `value` is taken from it
+                    # (x B samples per step), the one-layer extrapolation stays beside it as a cross-check
+                    full = cpu_full_step(cfg, a.ctx, a.tgt, threads, steps=1)
+                    cb = out["cpu_baseline"]
+                    cb["value_extrapolated_from_one_layer"] = cb["value"]
+                    cb["value"] = 1.0 / (B * full["seconds_per_sample_step"])
+                    cb["full_step"] = full
+                    cb["sample"] = (f"ONE real full-depth oracle step in this run: B=1, fp32, {threads} threads, "
+                                    f"{full['seconds_per_sample_step']:.1f} s (32 Whisper + 4x6 Q-Former + 32 LLM layers, lm_head, CE, backward, clip, "
+                                    f"Adafactor); value = 1 / (B={B} x that).  Cross-check, one layer per stack scaled up: " + cb["sample"])
             except Exception as ex:                                   # noqa: BLE001
                 out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": 0, "kind": "port", "sample": f"failed: {ex}"}
         print(json.dumps(out))

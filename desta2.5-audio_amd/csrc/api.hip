@@ -46,7 +46,7 @@ extern "C" int desta_create(int device, desta_handle* out) {
     if (hipSetDevice(device) != hipSuccess) { desta_set_error("desta_create: hipSetDevice(%d) failed", device); return DESTA_ELAUNCH; }
     if (desta_internal_reserve() != DESTA_OK) { desta_set_error("desta_create: could not create the internal stream / events"); return DESTA_ELAUNCH; }
     desta_context* c = new (std::nothrow) desta_context();
-    if (!c) { desta_set_error("desta_create: out of host memory"); return DESTA_ELAUNCH; }
+    if (!c) { (void)desta_internal_release(); desta_set_error("desta_create: out of host memory"); return DESTA_ELAUNCH; }
     c->magic = kCtxMagic; c->device = device; c->compute_units = pr.multiProcessorCount;
     snprintf(c->arch, sizeof(c->arch), "%s", pr.gcnArchName);
     c->err[0] = 0;

@@ -17,6 +17,7 @@
 //
 // Fully masked query rows (left-pad positions) produce O = 0 and lse = +inf (their gradients are 0).
 #include "common.h"
+#include <mutex>
 #include "desta_hip.h"
 
 #ifndef ATTN_ABL
@@ -1697,28 +1698,54 @@ extern "C" size_t desta_attention_bwd_workspace_floats(int batch, int n_q_heads,
 // is launched on a side stream (fork after delta, join before returning to the caller's stream) and its blocks fill
 // the CUs that dK/dV leaves idle.  Results are unchanged (no shared outputs, no atomics).
 namespace {
-struct BwdFork { hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+struct BwdFork { hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; int handles = 0; };
 BwdFork g_bwd_fork[16];
+std::mutex g_bwd_fork_mu;                    // creation / release only; the data path reads a fully built entry
 int g_bwd_concurrent = 1;
-BwdFork* bwd_fork() {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+BwdFork* bwd_fork_locked(int dev) {
     BwdFork& f = g_bwd_fork[dev];
     if (!f.side) {
-        if (hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) != hipSuccess) { f.side = nullptr; return nullptr; }
-        if (hipEventCreateWithFlags(&f.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&f.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+        hipStream_t s = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) {
+            if (e0) (void)hipEventDestroy(e0);
+            (void)hipStreamDestroy(s);
+            return nullptr;
+        }
+        f.fork = e0; f.join = e1; f.side = s;      // published last: a half-built entry is never visible
     }
     return &f;
 }
+BwdFork* bwd_fork() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (g_bwd_fork[dev].side) return &g_bwd_fork[dev];
+    std::lock_guard<std::mutex> lk(g_bwd_fork_mu);
+    return bwd_fork_locked(dev);
+}
 }  // namespace
 extern "C" int desta_attention_set_concurrent_bwd(int on) { g_bwd_concurrent = on; return DESTA_OK; }
-// desta_create / desta_destroy (api.hip): make / release the current device's internal fork stream and events
-int desta_internal_reserve(void) { return bwd_fork() ? DESTA_OK : DESTA_ELAUNCH; }
+// desta_create / desta_destroy (api.hip): the current device's internal fork stream and events are shared by every stateless
+// desta_attention_bwd caller of the process, so handles only COUNT references: the stream is made with the first handle (or
+// lazily by the first backward call) and destroyed when the LAST handle of the device goes, never under another live handle.
+// A process that never creates a handle keeps the lazily made stream for its lifetime.  desta_destroy must still not race a
+// data-path call of the same device that is inside desta_attention_bwd (documented in include/desta_hip.h).
+int desta_internal_reserve(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return DESTA_EINVAL;
+    std::lock_guard<std::mutex> lk(g_bwd_fork_mu);
+    BwdFork* f = bwd_fork_locked(dev);
+    if (!f) return DESTA_ELAUNCH;
+    ++f->handles;
+    return DESTA_OK;
+}
 int desta_internal_release(void) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return DESTA_EINVAL;
+    std::lock_guard<std::mutex> lk(g_bwd_fork_mu);
     BwdFork& f = g_bwd_fork[dev];
+    if (f.handles > 0 && --f.handles > 0) return DESTA_OK;      // another handle of this device is alive
     if (f.side) { (void)hipStreamSynchronize(f.side); (void)hipStreamDestroy(f.side); }
     if (f.fork) (void)hipEventDestroy(f.fork);
     if (f.join) (void)hipEventDestroy(f.join);

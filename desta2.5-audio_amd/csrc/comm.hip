@@ -10,6 +10,8 @@
 #include "desta_hip.h"
 #include <dlfcn.h>
 #include <string.h>
+#include <atomic>
+#include <mutex>
 
 namespace {
 typedef int (*get_uid_fn)(void*);
@@ -21,24 +23,32 @@ struct Rccl { void* h = nullptr; get_uid_fn uid = nullptr; init_rank_fn init = n
 Rccl g_rccl;
 constexpr int kNcclFloat32 = 7, kNcclAvg = 4;               // rccl.h: ncclFloat32 = 7, ncclAvg = 4
 
+std::mutex g_rccl_mu;
+std::atomic<bool> g_rccl_ready{false};
+// Thread-safe: the table is resolved into a LOCAL struct under a mutex and published whole (release store of the ready flag);
+// readers take the acquire load first, so no thread ever sees a half-filled table.
 int rccl_load() {
-    if (g_rccl.ar) return DESTA_OK;
+    if (g_rccl_ready.load(std::memory_order_acquire)) return DESTA_OK;
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl_ready.load(std::memory_order_relaxed)) return DESTA_OK;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;
     for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (h) break; }      // a copy the process already holds (torch's)
     if (!h) for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) break; }
     if (!h) { desta_set_error("desta_comm: cannot load librccl (%s)", dlerror()); return DESTA_ELAUNCH; }
-    g_rccl.h = h;
-    g_rccl.uid = (get_uid_fn)dlsym(h, "ncclGetUniqueId");
-    g_rccl.init = (init_rank_fn)dlsym(h, "ncclCommInitRank");
-    g_rccl.ar = (allreduce_fn)dlsym(h, "ncclAllReduce");
-    g_rccl.destroy = (destroy_fn)dlsym(h, "ncclCommDestroy");
-    g_rccl.err = (errstr_fn)dlsym(h, "ncclGetErrorString");
-    if (!g_rccl.uid || !g_rccl.init || !g_rccl.ar || !g_rccl.destroy) {
-        g_rccl = Rccl();
+    Rccl t;
+    t.h = h;
+    t.uid = (get_uid_fn)dlsym(h, "ncclGetUniqueId");
+    t.init = (init_rank_fn)dlsym(h, "ncclCommInitRank");
+    t.ar = (allreduce_fn)dlsym(h, "ncclAllReduce");
+    t.destroy = (destroy_fn)dlsym(h, "ncclCommDestroy");
+    t.err = (errstr_fn)dlsym(h, "ncclGetErrorString");
+    if (!t.uid || !t.init || !t.ar || !t.destroy) {
         desta_set_error("desta_comm: librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy");
         return DESTA_ELAUNCH;
     }
+    g_rccl = t;
+    g_rccl_ready.store(true, std::memory_order_release);
     return DESTA_OK;
 }
 int rccl_check(int rc, const char* what) {

@@ -103,13 +103,19 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 // * 0x846ca68b / xorshift 16): 32-bit integer multiplies are quarter rate on CDNA4 and the previous murmur3-style mix (5 of them)
 // was a large part of the dropout attention kernels' time (cross-attention forward 42 us without dropout, 80 us with; 70 us now).
 // The seed words and the high index word enter ADDITIVELY through two more multiplies that are wave-uniform in every caller
-// (scalar unit): streams of neighbouring seeds (layer / site ids) are far-shifted copies of the sequence, not pair-swapped ones
-// as with counter ^ seed.  Checked on the host (4 M pairs, p = 0.1): keep fraction 0.8998 / 0.9001, correlation between seeds
-// s, s + 1 and s, s + 16: 3e-4, between adjacent elements 1e-4, every output bit 0.4995..0.5004, row / column keep rates of a
-// [2000, 1500] mask at the binomial spread.
+// (scalar unit) — which alone makes every stream a SHIFTED COPY of one 2^32-pair sequence (mask(seed + d, idx) == mask(seed, idx +
+// d * 0x9e3779b9): with the per-forward seed step of round 3, the masks of step t + 60 were the masks of step t shifted by 8.87 M
+// pairs, inside the 30.7 M-pair cross-attention tensor).  Round 4: a second, independently mixed word of the seed (`key`,
+// wave-uniform as well) is xored in BETWEEN the two multiplies of the finaliser, so two seeds select two different functions of the
+// index, and the host derives every site's seed with splitmix64 from (rank seed, forward count, layer, site) instead of packing
+// bit fields.  Checked on the host (numpy restatement, p = 0.1, 4-10 M pairs): keep fraction 0.90004; correlation between the
+// streams of seeds s and s + d for d = 1, 16, 256, 512, 256 * 60, 256 * 120, 256 * 1000 all |r| < 6e-4, and at the shift the
+// additive offset implies (d = 256 * 60: 8 870 912 pairs) 1e-3 — it was exactly 1.0 without the key; seed_hi neighbours 4e-5;
+// adjacent elements 4e-4; every output bit 0.4998..0.5005.
 __device__ __forceinline__ unsigned desta_rng32(unsigned seed_lo, unsigned seed_hi, unsigned long idx) {
+    const unsigned key = (seed_lo ^ (seed_hi * 0x632be5abu)) * 0xc2b2ae35u;
     unsigned x = (unsigned)idx + seed_lo * 0x9e3779b9u + ((unsigned)(idx >> 32) + seed_hi) * 0x85ebca6bu;
-    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= (x >> 15) ^ key; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
 // Dropout decision of element `idx`: ONE 32-bit hash serves the element PAIR (idx >> 1) — the even element takes the low 16

@@ -47,6 +47,23 @@ def _r64(n: int) -> int:
     return (n + 63) // 64 * 64
 
 
+_M64 = 0xFFFFFFFFFFFFFFFF
+
+
+def _splitmix64(x: int) -> int:
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _M64
+    return x ^ (x >> 31)
+
+
+def site_seed(seed_base: int, domain: int, layer: int, site: int) -> int:
+    """64-bit seed of ONE dropout site of one forward: splitmix64 over (per-forward base, domain, layer, site).  The device RNG
+    (csrc/common.h `desta_rng32`) folds a seed into a 32-bit offset + a 32-bit key; hashing on the host means no two sites /
+    forwards / ranks are related by a small additive step (packed bit fields made step t + 60 a shifted copy of step t)."""
+    return _splitmix64(_splitmix64(seed_base ^ (domain << 56)) + ((layer & 0xFFFFFF) << 8) + (site & 0xFF))
+
+
 @dataclass
 class EncoderConfig:
     num_mel_bins: int = 128
@@ -502,7 +519,7 @@ class QformerConnectorHIP:
                     kv_ev.append(ev)
         for i in range(self.Lq):
             p, s = f"{CON}qformer.layer.{i}.", self.sv[i]
-            sd = [(self.seed_base + 16 * i + k) & 0xFFFFFFFFFFFFFFFF for k in range(5)]   # attn-self, out1, attn-cross, out2, out3
+            sd = [site_seed(self.seed_base, 1, i, k) for k in range(5)]   # attn-self, out1, attn-cross, out2, out3
             s["seeds"], s["pd"] = sd, pd
             # self-attention over the K queries (bidirectional, H5)
             H.gemm(x16, self.W16(p + "attention.self.query.weight", 3 * d), s["qkv"], R, 3 * d, d, bias=self.P32(p + "attention.self.query.bias", 3 * d))
@@ -706,7 +723,7 @@ class CausalLMHIP:
             wd = g(p + "mlp.down_proj.weight").to(BF16).contiguous()
             ly = dict(n1=g(p + "input_layernorm.weight").float().contiguous(), n2=g(p + "post_attention_layernorm.weight").float().contiguous(),
                       wqkv=wqkv, wqkvT=T(wqkv), wo=wo, woT=T(wo), wgu=wgu, wguT=T(wgu), wd=wd, wdT=T(wd))
-            if not c.qk_norm:
+            if not c.qk_norm and not cfg.use_lora:            # (with adapters the fused-rope path is never taken: no second copy)
                 # rotary embedding fused into the q|k|v projection (frozen weights, so a re-layout at load is free): the rows of
                 # every q / k head in the order 0, hd/2, 1, hd/2+1, ... put HF's rotate_half pair (i, i + hd/2) on ADJACENT output
                 # columns, which one lane of the GEMM epilogue owns; q.k is invariant under a permutation of the head dim applied
@@ -776,7 +793,7 @@ class CausalLMHIP:
         return self.layers[i]["wqkv_m"]
 
     def _lora_seed(self, i: int, j: int) -> int:
-        return ((self.lora["seed_base"] ^ (1 << 39)) + 4 * i + j) & 0xFFFFFFFFFFFFFFFF      # bit 39: apart from the Q-Former's sites of any forward
+        return site_seed(self.lora["seed_base"], 2, i, j)                    # domain 2: apart from the Q-Former's sites (domain 1) of any forward
 
     def _lora_fwd(self, i: int, ly, s, M: int) -> None:
         """s["qkv"] (plain layout, before the rotary embedding) += adapters of layer i applied to self.hb."""
@@ -1321,7 +1338,7 @@ class DeSTA25AudioModel:
                 self.refresh_weights()
                 self._weights_dirty = False
             af = None
-            seed_base = ((self.dropout_seed & 0xFFFFFF) << 40) | ((self._fwd_count & 0xFFFFFFFF) << 8)
+            seed_base = _splitmix64(((self.dropout_seed & 0xFFFFFFFF) << 32) | (self._fwd_count & 0xFFFFFFFF))   # (rank stream, forward)
             if self.llm.lora is not None:
                 self.llm.lora["seed_base"] = seed_base
             if N_audio > 0 or self.llm.lora is not None:

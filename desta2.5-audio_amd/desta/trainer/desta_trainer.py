@@ -43,8 +43,8 @@ class TrainingArguments:
     optim: str = "adafactor"
     bf16: bool = True
     overlap_comm: bool = True
-    overlap_connector_backward: bool = False       # with overlap_comm: the connector's backward ALSO runs on the side stream beside the next batch's Whisper forward (A/B: -0.4 ms per step, and it inflates the per-kernel durations of both streams: off)
-    overlap_encoder: bool = False                  # next batch's frozen Whisper forward on its own HIP stream beside the LLM (A/B: -1.2 % step time, see DESIGN)
+    overlap_connector_backward: bool = True        # with overlap_comm: the connector's backward ALSO runs on the side stream beside the next batch's frozen Whisper forward (bit-identical results; default since round 4)
+    overlap_encoder: bool = True                   # next batch's frozen Whisper forward on its own HIP stream beside the connector / LLM of the current batch (bit-identical results; default since round 4)
     save_strategy: str = "no"                      # "epoch" (train_desta.py:146, enable_checkpointing) | "no"
     steps_per_epoch: Optional[int] = None          # len(train dataloader) = MICRO-batches per epoch when the dataset is not sized (synthetic streams)
     eval_strategy: str = "no"                      # "steps" (every eval_steps optimizer steps) | "epoch" | "no" (train_desta.py:147-148)
@@ -597,6 +597,11 @@ class DeSTA25Trainer:
         if rng["cuda"] is None:
             del rng["cuda"]
         torch.save(rng, os.path.join(output_dir, "rng_state.pth" if self.world <= 1 else f"rng_state_{self.rank}.pth"))
+        # the library's own resume data, PER RANK: the forward counter of the stateless dropout stream advances only on batches
+        # with audio, so ranks that drew different `_empty_batch`es sit at different positions
+        with open(os.path.join(output_dir, "desta_hip_state.json" if self.rank == 0 else f"desta_hip_state_{self.rank}.json"), "w") as f:
+            json.dump({"forward_count": self.model._fwd_count, "dropout_seed": self.model.dropout_seed, "micro": self._micro,
+                       "rank": self.rank, "world": self.world}, f, indent=1)
         if self.rank != 0:
             return
         self.model.save_pretrained(output_dir)
@@ -610,8 +615,6 @@ class DeSTA25Trainer:
         self._flush_logs()
         with open(os.path.join(output_dir, "trainer_state.json"), "w") as f:
             f.write(json.dumps(self._trainer_state(), indent=2, sort_keys=True) + "\n")   # `TrainerState.save_to_json` format
-        with open(os.path.join(output_dir, "desta_hip_state.json"), "w") as f:
-            json.dump({"forward_count": self.model._fwd_count, "dropout_seed": self.model.dropout_seed, "micro": self._micro}, f, indent=1)
 
     def resume_from_checkpoint(self, ckpt_dir: str) -> None:
         """Restore parameters, optimizer moments, schedule position, log history and the dropout stream position.  Reads
@@ -633,10 +636,27 @@ class DeSTA25Trainer:
             self.log_history = list(st.get("log_history") or [])
             legacy = st.get("desta_hip") or {}                                 # round-2 files kept the sidecar data inside trainer_state.json
             self.model._fwd_count = int(legacy.get("forward_count", self.model._fwd_count))
-        side = os.path.join(ckpt_dir, "desta_hip_state.json")
+        side = os.path.join(ckpt_dir, f"desta_hip_state_{self.rank}.json")
+        if self.rank == 0 or not os.path.isfile(side):                        # rank 0's file also serves a run resumed on more ranks than it was saved on
+            side = os.path.join(ckpt_dir, "desta_hip_state.json")
         if os.path.isfile(side):
             with open(side) as f:
-                self.model._fwd_count = int(json.load(f).get("forward_count", self.model._fwd_count))
+                sc = json.load(f)
+            self.model._fwd_count = int(sc.get("forward_count", self.model._fwd_count))
+            if sc.get("dropout_seed") is not None and int(sc.get("world", self.world)) == self.world:
+                self.model.dropout_seed = int(sc["dropout_seed"])
+        # torch's generators (HF `_load_rng_state`): nothing on the hot path draws from them (dropout has its own counter RNG, the
+        # sample order is a pure function of seed + epoch) — restored when the file holds plain tensors, for callers that do
+        rp = os.path.join(ckpt_dir, "rng_state.pth" if self.world <= 1 else f"rng_state_{self.rank}.pth")
+        if os.path.isfile(rp):
+            try:
+                rs = torch.load(rp, map_location="cpu", weights_only=True)
+                if torch.is_tensor(rs.get("cpu")):
+                    torch.random.set_rng_state(rs["cpu"])
+                if torch.is_tensor(rs.get("cuda")) and torch.cuda.is_available():
+                    torch.cuda.set_rng_state(rs["cuda"], self.model.device)
+            except Exception:                                                 # noqa: BLE001 — python / numpy generator states need the unsafe loader: skipped
+                pass
         self._micro = 0                                                       # checkpoints are written at window boundaries only
         self.model.refresh_weights()
         self.model._weights_dirty = False

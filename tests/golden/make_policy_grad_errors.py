@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import desta_oracle as O  # noqa: E402
 
-CASES = {"ref_tiny_llama": lambda: O.tiny_dims(False), "ref_deep_llama": lambda: O.deep_dims(False),
+CASES = {"ref_tiny_llama": lambda: O.tiny_dims(False), "ref_tiny_qwen3": lambda: O.tiny_dims(True), "ref_deep_llama": lambda: O.deep_dims(False),
          "ref_deep_qwen3": lambda: O.deep_dims(True), "ref_tied_qwen3": O.tied_dims}
 
 

@@ -251,3 +251,31 @@ def test_c_abi_allreduce_grads_at_world_size_one():
 
 if __name__ == "__main__" and len(sys.argv) >= 3 and sys.argv[1] == "--worker":
     worker(sys.argv[2])
+
+
+@pytest.mark.gpu
+def test_stream_overlaps_are_bit_identical_to_the_in_line_step():
+    """Round 4: `overlap_encoder` (the frozen Whisper forward of batch t+1 on its own stream beside the connector / LLM of batch t)
+    and `overlap_connector_backward` (the connector's backward of step t on the optimizer's side stream) are the DEFAULTS.  Six
+    optimizer steps with Q-Former dropout on, ragged batches and an `_empty_batch` in the middle: the losses, the parameters and
+    the optimizer state equal, bit for bit, the same steps run with no side stream at all.  (The frozen encoder depends on
+    nothing the optimizer writes, /root/reference/desta/models/modeling_desta25.py:577-598.)"""
+    _setup_paths()
+    import desta_oracle as O
+    from desta.trainer.desta_trainer import DeSTA25Trainer, TrainingArguments
+    assert TrainingArguments().overlap_encoder and TrainingArguments().overlap_connector_backward and TrainingArguments().overlap_comm
+    results = []
+    for on in (True, False):
+        d, model = _model()
+        tr = DeSTA25Trainer(model, args=TrainingArguments(learning_rate=LR, warmup_steps=WARM, max_steps=TOTAL, logging_steps=1,
+                                                          overlap_comm=on, overlap_encoder=on, overlap_connector_backward=on))
+        assert (tr._side is not None) == on and (tr._enc_stream is not None) == on
+        batches = [O.synthetic_batch(d, B=2 + (i % 2), S_ctx=4 + i, S_tgt=9 + 2 * i, seed=300 + i, pad=[i % 3, 0, 1][:2 + (i % 2)]) for i in range(6)]
+        batches[3] = {"_empty_batch": True}
+        losses = tr.train(batches)
+        torch.cuda.synchronize()
+        results.append((losses, model.arena.params.clone(), tr.optimizer.state.clone(), model.arena.grads.clone()))
+    (l1, p1, s1, g1), (l0, p0, s0, g0) = results
+    assert l1 == l0, (l1, l0)
+    assert torch.equal(g1, g0), "gradient arena differs between the overlapped and the in-line step"
+    assert torch.equal(p1, p0) and torch.equal(s1, s0)

@@ -118,3 +118,45 @@ def test_manifest_dataset_through_main(tmp_path, monkeypatch):
     for ep in (0, 1):
         seen.append([x for b in tr._epoch_batches(ep) for x in b])
     assert sorted(seen[0]) == sorted(seen[1]) and len(set(seen[0])) == 5 and seen[0] != seen[1]
+
+
+def test_init_from_pretrained_weights_lightning_style_file(tmp_path):
+    """`init_from_pretrained_weights=<file>` (reference examples/train/train_desta.py:73-83, :139-145): a legacy Lightning
+    checkpoint `{"state_dict": {"model.<name>": tensor}}` — the "model." prefix is stripped, names the model does not train
+    (frozen LLM / Whisper tensors that such files also hold) are ignored (`strict=False`), tensors absent from the file keep
+    their initial value.  The file is hand-made here (tensors only: the product loads it with weights_only=True)."""
+    m = _mod()
+    args = ["--config-name", "desta25_debug", "+dataset=debug", "trainer.max_steps=1", f"exp_dir={tmp_path}/base"]
+    base = m.main(args).model
+    names = base.trainable_parameter_names
+    p0 = {n: base.arena.param(n).detach().cpu().clone() for n in names}
+    del base
+    g = torch.Generator().manual_seed(3)
+    picked = [n for n in names if "layer.0.crossattention.self.query" in n or n.endswith("layer_weights") or ".proj.1.bias" in n]
+    assert len(picked) == 4
+    new = {n: torch.randn(p0[n].shape, generator=g) for n in picked}
+    blob = {"state_dict": {**{"model." + n: v for n, v in new.items()},
+                           "model.llm_model.model.embed_tokens.weight": torch.zeros(4, 4),         # frozen tensor in a Lightning file: ignored
+                           "epoch_marker_not_a_parameter": torch.zeros(1)},
+            "epoch": 3, "global_step": 1234}
+    path = str(tmp_path / "legacy.ckpt")
+    torch.save(blob, path)
+    tr = m.main(["--config-name", "desta25_debug", "+dataset=debug", "trainer.max_steps=1", f"exp_dir={tmp_path}/init",
+                 f"init_from_pretrained_weights={path}"])
+    init = load_file(tmp_path / "init" / "checkpoint-initial" / "model.safetensors")              # written right after the load, before any step
+    for n in picked:
+        assert torch.equal(init[n], new[n]), n
+    # untouched tensors equal a model built without the file (same seeded init), touched ones equal the file
+    fresh = m.main(["--config-name", "desta25_debug", "+dataset=debug", "trainer.max_steps=1", f"exp_dir={tmp_path}/fresh"])
+    f0 = load_file(tmp_path / "fresh" / "checkpoint-initial" / "model.safetensors")
+    for n in names:
+        if n in new:
+            assert not torch.equal(init[n], f0[n]), n
+        else:
+            assert torch.equal(init[n], f0[n]), n
+    assert tr.global_step == 1                                               # and the run trains on from the loaded weights
+    # a plain state dict without the "state_dict" wrapper loads too
+    torch.save({"model." + n: v for n, v in new.items()}, str(tmp_path / "flat.ckpt"))
+    m.load_pretrained_weights(fresh.model, str(tmp_path / "flat.ckpt"))
+    for n in picked:
+        assert torch.equal(fresh.model.arena.param(n).detach().cpu(), new[n]), n

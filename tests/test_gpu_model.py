@@ -30,12 +30,14 @@ def test_forward_backward_vs_reference_golden(golden_dir, name):
     model, w = _model(d)
     out = model(**batch, keep_logits=True)
     loss = float(out.loss)
-    assert abs(loss - float(g["loss"])) < 2e-2, (loss, float(g["loss"]))          # bf16 path vs fp32 reference
+    # bf16 path vs the reference's fp32 golden; bounds = 3x what the path measures (round 3: dloss 6e-4, features 3e-3, logits 6e-3;
+    # rounds 1-3 asserted 2e-2 / 2e-2 / 3e-2, which a tenfold regression would have passed)
+    assert abs(loss - float(g["loss"])) < 2e-3, (loss, float(g["loss"]))
     m = g["attention_mask"].bool()
     e_logits = rel_err(out.logits.float().cpu()[m], g["logits"][m])
     e_af = rel_err(model.connector.af.float().view(g["audio_features"].shape), g["audio_features"])
-    assert e_af < 2e-2, e_af
-    assert e_logits < 3e-2, e_logits
+    assert e_af < 1e-2, e_af
+    assert e_logits < 2e-2, e_logits
     model.backward()
     errs = {}
     # relative L2 error per tensor; tensors whose true gradient is (numerically) zero — the key biases:
@@ -49,8 +51,16 @@ def test_forward_backward_vs_reference_golden(golden_dir, name):
     for n in sorted(errs, key=errs.get)[-6:]:
         print(f"   grad err {errs[n]:.4f}  {n}")
     worst = max(errs, key=errs.get)
-    print("loss", loss, float(g["loss"]), "logits", e_logits, "af", e_af, "worst grad", worst, errs[worst])
-    assert errs[worst] < 8e-2, (worst, errs[worst])
+    # per-TENSOR yardstick, as in the deep test below: the error the reference's own autocast(bf16) policy carries on that tensor
+    # against the same fp32 golden (tests/golden/autocast_policy_grad_errors.json); no tensor more than 2.5x that (floor 5e-3)
+    import json
+    pol = json.load(open(os.path.join(golden_dir, "autocast_policy_grad_errors.json")))["ref_tiny_" + name]
+    ratio = {n: errs[n] / max(pol[n], 5e-3) for n in errs}
+    wr = max(ratio, key=ratio.get)
+    print("loss", loss, float(g["loss"]), "logits", e_logits, "af", e_af, "worst grad", worst, errs[worst],
+          "worst vs policy", wr, errs[wr], pol[wr])
+    assert ratio[wr] < 2.5, (wr, errs[wr], pol[wr])
+    assert errs[worst] < 4e-2, (worst, errs[worst])
     # global gradient direction: cosine over the whole arena
     a = torch.cat([model.arena.grad(n).reshape(-1).double().cpu() for n in model.trainable_parameter_names])
     b = torch.cat([g["grad::" + n].reshape(-1).double() for n in model.trainable_parameter_names])
@@ -405,15 +415,31 @@ def test_loss_curve_tracks_oracle_over_many_steps():
     st = O.adafactor_init([w[n] for n in names])
     pool = [O.synthetic_batch(d, B=2, S_ctx=5, S_tgt=24, seed=500 + i, pad=[0, i % 3]) for i in range(8)]
     hip = tr.train([pool[i % 8] for i in range(n_steps)])
-    ref = []
+    # THREE curves on the same batches: fp32 oracle, the oracle under the reference's own autocast(bf16) policy (what the reference
+    # itself trains under, hazard H11), HIP
+    wp = {k: v.clone() for k, v in w.items()}
+    stp = O.adafactor_init([wp[n] for n in names])
+    ref, polc = [], []
     for i in range(n_steps):
-        lo, _, _, _ = O.train_step(w, d, pool[i % 8], st, O.linear_warmup_lr(i, lr, warm, n_steps))
+        lr_i = O.linear_warmup_lr(i, lr, warm, n_steps)
+        lo, _, _, _ = O.train_step(w, d, pool[i % 8], st, lr_i)
+        lp, _, _, _ = O.train_step(wp, d, pool[i % 8], stp, lr_i, autocast=True)
         ref.append(float(lo))
+        polc.append(float(lp))
+    mean = lambda v: sum(v) / len(v)
     diff = [abs(a - b) for a, b in zip(hip, ref)]
-    print("loss", ref[0], "->", ref[-1], "| mean diff", sum(diff) / len(diff), "max", max(diff))
+    dpol = [abs(a - b) for a, b in zip(hip, polc)]
+    dpr = [abs(a - b) for a, b in zip(polc, ref)]
+    print("loss", ref[0], "->", ref[-1], "| HIP - fp32: mean", mean(diff), "max", max(diff), "| HIP - autocast policy: mean", mean(dpol), "max", max(dpol),
+          "| policy - fp32: mean", mean(dpr), "max", max(dpr))
     assert ref[-1] < ref[0] - 0.3                                # the pool is being fitted
-    assert sum(diff) / len(diff) < 2.5e-3 and max(diff) < 3e-2
-    assert abs(sum(hip[-10:]) - sum(ref[-10:])) / 10 < 2e-3
+    # round 3 measured mean 3.7e-4 / max 1.6e-3 against fp32 (with the fp32 attention output feeding delta); 3x that
+    assert mean(diff) < 1.2e-3 and max(diff) < 5e-3, (mean(diff), max(diff))
+    # against the policy oracle — two bf16 runs with different rounding points — and relative to the policy's own distance from fp32:
+    # the HIP path is no farther from fp32 than 1.5x the reference's own precision policy is
+    assert mean(dpol) < 2.5e-3 and max(dpol) < 2e-2, (mean(dpol), max(dpol))
+    assert mean(diff) < 1.5 * mean(dpr) + 2e-4, (mean(diff), mean(dpr))
+    assert abs(sum(hip[-10:]) - sum(ref[-10:])) / 10 < 1e-3
 
 
 def test_training_entry_point_debug_config(tmp_path):
