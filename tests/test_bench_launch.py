@@ -47,7 +47,7 @@ def test_world_size_mismatch_exits_nonzero():
 @pytest.mark.gpu
 def test_two_rank_bench_on_one_card_reports_the_exchange():
     """The real bench through its own launcher at N = 2 (two ranks share cuda:0 over gloo: the box has one GPU): n_gpus == 2,
-    the all-reduce / wait_update fields are present, value = 2 x steps / time."""
+    the all-reduce / wait_update fields are present, value = steps / time (optimizer steps of the node), gpu_batch_steps_per_s = 2 x that."""
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device",
                         "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-pass", "--no-calibration"],
                        env=dict(ENV, HSA_ENABLE_IPC_MODE_LEGACY="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
@@ -56,4 +56,7 @@ def test_two_rank_bench_on_one_card_reports_the_exchange():
     assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 16
     assert line["bytes_allreduced"] > 5e8 and line["allreduce_ms"] > 0 and line["wait_update_stall_ms"] >= 0
     assert line["comm_backend"] == "gloo"
-    assert abs(line["value"] - 2 * line["steps"] / (line["ms_per_step"] * 1e-3 * line["steps"])) < 1e-6
+    # value = OPTIMIZER steps per second of the node (global batch 8 x N per step); the per-GPU aggregates sit beside it
+    per_s = 1.0 / (line["ms_per_step"] * 1e-3)
+    assert abs(line["value"] - per_s) < 1e-6 and abs(line["gpu_batch_steps_per_s"] - 2 * per_s) < 1e-6
+    assert abs(line["samples_per_s"] - 16 * per_s) < 1e-5
