@@ -282,6 +282,7 @@ def main():
     ap.add_argument("--no-dead-row-skip", action="store_true", help="A/B: the last decoder layer's o_proj / MLP (forward and backward) on every row instead of the target tail, layer 0's input gradient on every row instead of the audio rows")
     ap.add_argument("--attn-q64-two-kernels", action="store_true", help="A/B: the Q-Former's cross-attention backward on the separate dQ and dK/dV kernels instead of the one-pass kernel")
     ap.add_argument("--no-kv-side", action="store_true", help="A/B: the Q-Former's K | V projections inside the layer loop on the main stream instead of up front on a second stream")
+    ap.add_argument("--no-swiglu-fusion", action="store_true", help="A/B: silu(gate) * up and its backward as their own HBM passes instead of inside the gate|up / d(act) GEMM epilogues")
     ap.add_argument("--full-lm-head", action="store_true", help="A/B: lm_head / CE over the whole token grid, not only the target rows")
     a = ap.parse_args()
 
@@ -358,6 +359,8 @@ def main():
         H.attention_set_option(3, 1)
     if a.attn_r2_forward:
         H.attention_set_option(0, 0)
+    if a.no_swiglu_fusion:
+        model.llm.fuse_swiglu = False
     if a.no_kv_side:
         model.connector.kv_side = False
     if a.attn_q64_two_kernels:

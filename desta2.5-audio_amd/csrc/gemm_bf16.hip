@@ -94,29 +94,6 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& p, int z, int m, int n
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = gelu_erf_fast(v[e]);
         }
-    } else if (p.act == 2) {
-        // fused SwiGLU forward on an interleaved gate/up projection: columns (2i, 2i+1) = (gate_i, up_i).
-        // C keeps the bf16 pre-activations (saved for backward); aux[m][n0/2 ..] = bf16(silu(g)) * u,
-        // computed from the ROUNDED values exactly like the unfused HF path (LlamaMLP).
-        float g0 = bf2f(f2bf(v[0])), u0 = bf2f(f2bf(v[1])), g1 = bf2f(f2bf(v[2])), u1 = bf2f(f2bf(v[3]));
-        const float a0 = bf2f(f2bf(g0 / (1.0f + __expf(-g0)))) * u0;
-        const float a1 = bf2f(f2bf(g1 / (1.0f + __expf(-g1)))) * u1;
-        const unsigned pk = (unsigned)f2bf(a0) | ((unsigned)f2bf(a1) << 16);
-        *(unsigned*)(p.aux + (long)m * p.lda_x + (n0 >> 1)) = pk;
-    } else if (p.act == 3) {
-        // fused SwiGLU backward: v = d(act)[m][n0..n0+3]; aux = saved interleaved gate|up [M,2N];
-        // C[m][2n0..2n0+7] = (dgate, dup) interleaved (bf16), ldc counts the 2N-wide rows
-        const u16x8 gu = *(const u16x8*)(p.aux + (long)m * p.lda_x + 2 * n0);
-        u16x8 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float d = bf2f(f2bf(v[e])), g = bf2f(gu[2 * e]), u = bf2f(gu[2 * e + 1]);
-            const float sig = 1.0f / (1.0f + __expf(-g));
-            o[2 * e] = f2bf(d * u * (sig * (1.0f + g * (1.0f - sig))));
-            o[2 * e + 1] = f2bf(d * (g * sig));
-        }
-        *(u16x8*)((bf16_t*)p.C + (long)z * p.sC + (long)m * p.ldc + 2 * n0) = o;
-        return;
     }
     if (p.drop_thresh) {
         const unsigned long base = ((unsigned long)z * p.M + m) * p.N + n0;
@@ -219,6 +196,88 @@ __device__ __forceinline__ void epilogue_pair_bf16(const GemmArgs& p, int z, int
     const auto hi = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
     const int col = ncol0 + (fq & 1) * 16 + (fq >> 1) * 8;
     if (row_ok) *(uint4*)((bf16_t*)p.C + (long)z * p.sC + (long)m * p.ldc + col) = make_uint4(lo[0], hi[0], lo[1], hi[1]);
+}
+
+// ---- fused SwiGLU epilogues over the BLOCKED gate|up layout (act 2 / act 3; round 4) ------------------------------------------
+// Column n of the gate|up projection: 64-column block b = n / 64 holds gate_{32b .. 32b+31} in its first 32 columns and
+// up_{32b .. 32b+31} in its last 32 (the frozen weight rows are permuted once at load).  A wave of every tile kernel here owns
+// whole 64-column blocks — the four adjacent 16x16 accumulators a0..a3 of one row group are (gate, gate, up, up) of the SAME 32
+// activations — so silu(gate) * up is formed in registers, lane-locally, and every store stays a 16-byte piece after the
+// permlane16 exchange (the first version interleaved (gate_i, up_i) column pairs: 4-byte activation stores and no wide-store
+// path for the projection itself, and measured no faster than the separate kernels).
+// Exchange: odd 16-lane rows of X swap with the even rows of Y; afterwards the lane owns 8 CONTIGUOUS columns of the 32-column
+// pair (X = columns [0,16), Y = [16,32)), starting at col8 = (fq & 1) * 16 + (fq >> 1) * 8.
+__device__ __forceinline__ uint4 pair_swap_pk(unsigned x0, unsigned x1, unsigned y0, unsigned y1) {
+    const auto lo = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+    return make_uint4(lo[0], hi[0], lo[1], hi[1]);
+}
+__device__ __forceinline__ unsigned pk2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+
+// act 2 — forward.  C[M, N] (bf16) keeps the projection (saved for the backward), aux[M, N/2] = bf16(bf16(silu(g)) * u) with the
+// rounding points of the unfused path (projection rounded to bf16, then swiglu_fwd_k).  ncol0 = first column of the 64-block.
+__device__ __forceinline__ void epilogue_swiglu_fwd(const GemmArgs& p, int z, int m, bool row_ok, int ncol0, int fq,
+                                                    const f32x4& a0, const f32x4& a1, const f32x4& a2, const f32x4& a3) {
+    float g[2][4], u[2][4], o[2][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        g[0][e] = bf2f(f2bf(a0[e] * p.alpha)); g[1][e] = bf2f(f2bf(a1[e] * p.alpha));
+        u[0][e] = bf2f(f2bf(a2[e] * p.alpha)); u[1][e] = bf2f(f2bf(a3[e] * p.alpha));
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float sg = g[t][e] / (1.0f + __expf(-g[t][e]));
+            o[t][e] = bf2f(f2bf(sg)) * u[t][e];                  // HF rounds silu(gate) to bf16 before the product
+        }
+    const int col8 = (fq & 1) * 16 + (fq >> 1) * 8;
+    const uint4 vg = pair_swap_pk(pk2(g[0][0], g[0][1]), pk2(g[0][2], g[0][3]), pk2(g[1][0], g[1][1]), pk2(g[1][2], g[1][3]));
+    const uint4 vu = pair_swap_pk(pk2(u[0][0], u[0][1]), pk2(u[0][2], u[0][3]), pk2(u[1][0], u[1][1]), pk2(u[1][2], u[1][3]));
+    const uint4 vo = pair_swap_pk(pk2(o[0][0], o[0][1]), pk2(o[0][2], o[0][3]), pk2(o[1][0], o[1][1]), pk2(o[1][2], o[1][3]));
+    if (row_ok) {
+        bf16_t* c = (bf16_t*)p.C + (long)z * p.sC + (long)m * p.ldc + ncol0 + col8;
+        *(uint4*)c = vg;
+        *(uint4*)(c + 32) = vu;
+        *(uint4*)(p.aux + (long)m * p.lda_x + (ncol0 >> 1) + col8) = vo;
+    }
+}
+// act 3 — backward.  The GEMM computes d(act)[M, N]; ncol0 = first of 64 activation columns = TWO 32-blocks: (a0, a1) belong to
+// gate|up block ncol0 / 32, (a2, a3) to the next.  aux[M, 2N] (in) = the saved blocked gate|up, C[M, 2N] (out, ldc = its row
+// length) = d(gate|up) in the same blocked layout; d(act) is rounded to bf16 first (the unfused path stores it), then the
+// arithmetic of swiglu_bwd_k.
+__device__ __forceinline__ void epilogue_swiglu_bwd(const GemmArgs& p, int z, int m, bool row_ok, int ncol0, int fq,
+                                                    const f32x4& a0, const f32x4& a1, const f32x4& a2, const f32x4& a3) {
+    const int col8 = (fq & 1) * 16 + (fq >> 1) * 8;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x4& x = h ? a2 : a0;
+        const f32x4& y = h ? a3 : a1;
+        float d[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(bf2f(f2bf(x[e] * p.alpha))), __float_as_uint(bf2f(f2bf(y[e] * p.alpha))), false, false);
+            d[e] = __uint_as_float(sw[0]);
+            d[4 + e] = __uint_as_float(sw[1]);
+        }
+        const long off = (long)m * p.lda_x + 2 * (ncol0 + 32 * h) + col8;          // gate piece; the up piece sits 32 columns on
+        const u16x8 gv = *(const u16x8*)(p.aux + off);
+        const u16x8 uv = *(const u16x8*)(p.aux + off + 32);
+        u16x8 og, ou;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float gg = bf2f(gv[e]), uu = bf2f(uv[e]);
+            const float sig = 1.0f / (1.0f + __expf(-gg));
+            const float sg = gg * sig;
+            ou[e] = f2bf(d[e] * sg);
+            og[e] = f2bf(d[e] * uu * (sig * (1.0f + gg * (1.0f - sig))));
+        }
+        if (row_ok) {
+            bf16_t* c = (bf16_t*)p.C + (long)z * p.sC + (long)m * p.ldc + 2 * (ncol0 + 32 * h) + col8;
+            *(u16x8*)c = og;
+            *(u16x8*)(c + 32) = ou;
+        }
+    }
 }
 
 // TA / TB: the operand is stored TRANSPOSED, i.e. as [K, M] (resp. [K, N]) row-major with the reduction index as
@@ -343,6 +402,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs p) {
     }
 
     // epilogue: lane holds C[m][n0..n0+3], m = ..+fr, n0 = ..+fq*4
+    if constexpr (!TA && !TB) {
+        if (p.act == 2 || p.act == 3) {                                  // fused SwiGLU over the blocked gate|up layout (block-uniform)
+            const int ncol0 = bcol + wc * 64;
+            if (ncol0 < p.N) {                                           // wave-uniform (N is a multiple of 64: host check)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = brow + wr * 64 + i * 16 + fr;          // all lanes take part in the exchange; rows >= M only skip the stores
+                    if (p.act == 2) epilogue_swiglu_fwd(p, z, min(m, p.M - 1), m < p.M, ncol0, fq, acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+                    else epilogue_swiglu_bwd(p, z, min(m, p.M - 1), m < p.M, ncol0, fq, acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = brow + wr * 64 + i * 16 + fr;
@@ -546,6 +619,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_ring_kernel(GemmArgs p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // no LDS-DMA may outlive the block
 
+    if constexpr (!TA && !TB) {
+        if (p.act == 2 || p.act == 3) {                                  // fused SwiGLU over the blocked gate|up layout (block-uniform)
+            const int ncol0 = bcol + wc * 64;
+            if (ncol0 < p.N) {                                           // wave-uniform (N is a multiple of 64: host check)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = brow + wr * 64 + i * 16 + fr;          // all lanes take part in the exchange; rows >= M only skip the stores
+                    if (p.act == 2) epilogue_swiglu_fwd(p, z, min(m, p.M - 1), m < p.M, ncol0, fq, acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+                    else epilogue_swiglu_bwd(p, z, min(m, p.M - 1), m < p.M, ncol0, fq, acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = brow + wr * 64 + i * 16 + fr;
@@ -578,7 +665,9 @@ constexpr int HT = 128 * BK * 2;                         // half-tile bytes (128
 // workgroup barriers per K-tile (rocprofv3 PMC: the waves of the 4-phase kernel are parked at s_waitcnt / s_barrier 37 %
 // of their cycles).  P1 stages A1(t+1) into the slot P2(t-1) vacated, P2 stages A0,B0,B1(t+2) into the slots P1
 // vacated; every barrier is preceded by vmcnt(8): all but the 4 youngest half-tiles have landed.
-template <bool STAGGER, int PHASES>
+// EPI = 1: the fused SwiGLU epilogues (act 2 / act 3) as their OWN instantiation, so that the default kernel's code and register
+// allocation stay exactly what they were (an extra body in its unrolled epilogue once cost a 528-byte scratch frame, see epilogue4).
+template <bool STAGGER, int PHASES, int EPI = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) char lds[2 * 4 * HT];            // [buf][A0,A1,B0,B1]
 
@@ -832,6 +921,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
             if (dpt == p.split - 1) {
                 __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(tk + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        return;
+    }
+    if constexpr (EPI == 1) {                                  // act 2 / act 3 (never split: host)
+        const int ncol0 = bcol + wn * 64;
+        if (ncol0 < p.N) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = brow + wm * 128 + i * 16 + fr;
+                if (p.act == 2) epilogue_swiglu_fwd(p, z, min(m, p.M - 1), m < p.M, ncol0, fq, acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+                else epilogue_swiglu_bwd(p, z, min(m, p.M - 1), m < p.M, ncol0, fq, acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
             }
         }
         return;
@@ -1373,6 +1474,8 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
     DESTA_CHECK_ARG(d->act < 2 || d->act == 4 || (d->aux && !d->out_f32 && !d->bias && !d->residual && !d->preact && d->ld_aux % 8 == 0),
                     "gemm: SwiGLU epilogues need aux, bf16 output and no bias/residual/preact");
     DESTA_CHECK_ARG(d->act != 3 || d->ldc % 8 == 0, "gemm: act 3 needs ldc (2N-wide rows) to be a multiple of 8");
+    DESTA_CHECK_ARG((d->act != 2 && d->act != 3) || (d->N % 64 == 0 && d->ldc % 8 == 0 && d->batch == 1 && !d->trans_a && !d->trans_b && d->dropout_p == 0.f),
+                    "gemm: the SwiGLU epilogues work on whole 64-column blocks (N %% 64 == 0), row-major operands, batch 1");
     // Tile choice.  The 256x256 8-phase kernel runs ONE block per CU, so the tile grid executes in rounds
     // of 256; a partial last round leaves CUs idle (M=5120 x N=4096: 320 tiles = 1.25 rounds).  Those tail
     // tiles are cut into `split` K-slices (<= 256 items, each 1/split long: "1 + 1/split" rounds instead
@@ -1382,7 +1485,7 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
     const int tM = (d->M + 255) / 256, tN = (d->N + 255) / 256, nk = d->K / BK;
     const long T = (long)tM * tN;
     int split = 1, full = (int)T;
-    if (d->batch == 1 && d->workspace && nk >= 8) {
+    if (d->batch == 1 && d->workspace && nk >= 8 && d->act != 2 && d->act != 3) {      // (the SwiGLU epilogues need the whole accumulator tile in registers: no K-slices)
         const int rem = (int)(T % NCU);
         if (rem > 0 && rem <= NCU / 2) {
             int sp = NCU / rem;
@@ -1402,7 +1505,7 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
         DESTA_CHECK_ARG(d->M <= 16 && (size_t)d->M * 2 * (size_t)d->K <= (size_t)SKINNY_XS_BYTES && d->K % 512 == 0 &&
                         (d->act == 0 || d->act == 4) && g_force_variant == 0,
                         "gemm: a_rms_weight (fused RMSNorm of A) needs M <= 16, M*2K <= %d bytes of LDS, K %% 512 == 0, act 0 or 4", SKINNY_XS_BYTES);
-    if (d->act == 4 || (d->M <= 16 && g_force_variant == 0 && !d->trans_a && !d->trans_b)) {          // decode-time projections: weight streaming
+    if (d->act == 4 || (d->M <= 16 && g_force_variant == 0 && !d->trans_a && !d->trans_b && d->act != 2 && d->act != 3)) {          // decode-time projections: weight streaming
         DESTA_CHECK_ARG(d->act != 4 || (d->M <= 16 && !d->out_f32 && !d->bias && !d->residual && !d->preact && d->dropout_p == 0.f),
                         "gemm: act 4 (SwiGLU over concatenated gate|up rows) is the decode path: M <= 16, bf16 out, no other epilogue");
         // 16 columns x 8 K-slices per tile measured fastest on every decode shape (tools/skinny_bench.py; wider
@@ -1450,7 +1553,8 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
         // variants: 2 = lockstep, 3 = staggered (+4-7 %), 4 = staggered + persistent cross-tile streaming
         //           (default when a block gets more than one item; +3-7 % on the LLM shapes)
         const bool persistent = g_force_variant == 4 || (g_force_variant == 0 && g_persistent && items > NCU);
-        if (g_force_variant == 2 || (g_force_variant == 0 && !g_stagger)) hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<false, 4>), dim3(items, d->batch), dim3(512), 0, (hipStream_t)stream, a);
+        if (d->act == 2 || d->act == 3) hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<true, 2, 1>), dim3(items, d->batch), dim3(512), 0, (hipStream_t)stream, a);
+        else if (g_force_variant == 2 || (g_force_variant == 0 && !g_stagger)) hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<false, 4>), dim3(items, d->batch), dim3(512), 0, (hipStream_t)stream, a);
         else if (g_force_variant == 8) hipLaunchKernelGGL((gemm_bf16_nt_256p_kernel<true, 2>), dim3(items < NCU ? items : NCU, d->batch), dim3(512), 0, (hipStream_t)stream, a, items);
         else if (persistent) hipLaunchKernelGGL((gemm_bf16_nt_256p_kernel<true, 4>), dim3(items < NCU ? items : NCU, d->batch), dim3(512), 0, (hipStream_t)stream, a, items);
         else if (g_force_variant == 6 || (g_force_variant == 0 && g_phases2)) hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<true, 2>), dim3(items, d->batch), dim3(512), 0, (hipStream_t)stream, a);

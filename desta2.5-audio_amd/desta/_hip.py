@@ -40,7 +40,7 @@ class GemmDesc(C.Structure):
 
 lib.desta_abi_version.restype = i32
 lib.desta_last_error.restype = C.c_char_p
-ABI_VERSION = 5
+ABI_VERSION = 6
 if lib.desta_abi_version() != ABI_VERSION:
     raise ImportError(f"libdesta_hip.so has ABI version {lib.desta_abi_version()}, this binding needs {ABI_VERSION}: "
                       "rebuild with `python desta2.5-audio_amd/build.py`")

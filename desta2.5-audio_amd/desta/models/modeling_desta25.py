@@ -713,6 +713,7 @@ class CausalLMHIP:
             t = torch.empty(i, _r64(o), dtype=BF16, device=dev)
             H.transpose_to_bf16(x, o, i, t, _r64(o))
             return t
+        self._T = T
         self.embed = g("model.embed_tokens.weight").to(BF16).contiguous()
         self.layers = []
         for i in range(self.L):
@@ -722,7 +723,20 @@ class CausalLMHIP:
             wgu = torch.cat([g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight")], 0).to(BF16).contiguous()
             wd = g(p + "mlp.down_proj.weight").to(BF16).contiguous()
             ly = dict(n1=g(p + "input_layernorm.weight").float().contiguous(), n2=g(p + "post_attention_layernorm.weight").float().contiguous(),
-                      wqkv=wqkv, wqkvT=T(wqkv), wo=wo, woT=T(wo), wgu=wgu, wguT=T(wgu), wd=wd, wdT=T(wd))
+                      wqkv=wqkv, wqkvT=T(wqkv), wo=wo, woT=T(wo), wgu=wgu, wd=wd, wdT=T(wd))
+            if self.I % 32 == 0:
+                # SwiGLU inside the GEMM epilogues (desta_gemm_desc.act 2 / 3): the frozen gate|up rows re-ordered at load into
+                # 64-row blocks (32 gate rows, then the 32 matching up rows), so that one wave of the tile kernels owns gate AND up
+                # of the same activations.  The plain copy stays for the decode kernels (act 4 walks the concatenated layout);
+                # its transpose (the UNFUSED backward, A/B switch) is made on first use.
+                if not hasattr(self, "_gu_perm"):
+                    b = torch.arange(self.I // 32, device=dev).view(-1, 1) * 32
+                    r = torch.arange(32, device=dev).view(1, -1)
+                    self._gu_perm = torch.cat([b + r, self.I + b + r], dim=1).reshape(-1)
+                ly["wgu_b"] = wgu[self._gu_perm].contiguous()
+                ly["wguT_b"] = T(ly["wgu_b"])
+            else:
+                ly["wguT"] = T(wgu)
             if not c.qk_norm and not cfg.use_lora:            # (with adapters the fused-rope path is never taken: no second copy)
                 # rotary embedding fused into the q|k|v projection (frozen weights, so a re-layout at load is free): the rows of
                 # every q / k head in the order 0, hd/2, 1, hd/2+1, ... put HF's rotate_half pair (i, i + hd/2) on ADJACENT output
@@ -744,6 +758,7 @@ class CausalLMHIP:
         self.B = self.S = 0
         self.lora = None
         self.skip_dead_rows = True                  # A/B switch (bench.py --no-dead-row-skip): last layer on the target tail, layer-0 dX on the audio rows
+        self.fuse_swiglu = True                     # A/B switch (bench.py --no-swiglu-fusion): silu(gate) * up and its backward inside the gate|up / d(act) GEMM epilogues
 
     # -- LoRA adapters on q/k/v (reference: peft, modeling_desta25.py:720-729; published layer: y = W x + (alpha / r) B A drop(x)) --------
     LORA_KP = 64                                    # the three rank-r adapters side by side, padded to one 64-wide GEMM K block
@@ -950,10 +965,13 @@ class CausalLMHIP:
             if Mt > 0:
                 H.gemm(s["att"][t0:], ly["wo"], s["xm"][t0:], Mt, h, self.hq * self.hd, residual=x[t0:])
                 H.rmsnorm_fwd(s["xm"][t0:], ly["n2"], c.rms_norm_eps, self.hb[t0:], s["r2"][t0:])
-                # (the GEMM also has fused SwiGLU epilogues, act=2/3; measured SLOWER here: with one 256x256 block
-                #  per CU the extra epilogue traffic is not overlapped, the streaming kernels run at HBM rate)
-                H.gemm(self.hb[t0:], ly["wgu"], s["gu"][t0:], Mt, 2 * self.I, h)
-                H.swiglu_fwd(s["gu"][t0:], self.act[t0:], Mt, self.I)
+                s["gu_blocked"] = self.fuse_swiglu and "wgu_b" in ly
+                if s["gu_blocked"]:
+                    # one launch: the projection (kept for the backward, 64-column gate|up blocks) and silu(gate) * up
+                    H.gemm(self.hb[t0:], ly["wgu_b"], s["gu"][t0:], Mt, 2 * self.I, h, act=2, aux=self.act[t0:], ld_aux=self.I)
+                else:
+                    H.gemm(self.hb[t0:], ly["wgu"], s["gu"][t0:], Mt, 2 * self.I, h)
+                    H.swiglu_fwd(s["gu"][t0:], self.act[t0:], Mt, self.I)
                 H.gemm(self.act[t0:], ly["wd"], self.xs[i + 1][t0:], Mt, h, self.I, residual=s["xm"][t0:])
         t0 = self.tail0
         if M - t0 > 0:
@@ -1129,9 +1147,16 @@ class CausalLMHIP:
             a0 = tl if i == self.L - 1 else r0                                                # first row with a non-zero d(layer output)
             Ma = M - a0
             if Ma > 0:
-                H.gemm(dx[a0:], ly["wdT"], self.act[a0:], Ma, self.I, h)                      # d act
-                H.swiglu_bwd(s["gu"][a0:], self.act[a0:], self.dgu[a0:], Ma, self.I)
-                H.gemm(self.dgu[a0:], ly["wguT"], dhb[a0:], Ma, h, 2 * self.I)
+                if s.get("gu_blocked"):
+                    # d(act) never reaches HBM: the epilogue of its GEMM forms d(gate|up) from the saved projection
+                    H.gemm(dx[a0:], ly["wdT"], self.dgu[a0:], Ma, self.I, h, act=3, aux=s["gu"][a0:], ld_aux=2 * self.I, ldc=2 * self.I)
+                    H.gemm(self.dgu[a0:], ly["wguT_b"], dhb[a0:], Ma, h, 2 * self.I)
+                else:
+                    if "wguT" not in ly:
+                        ly["wguT"] = self._T(ly["wgu"])
+                    H.gemm(dx[a0:], ly["wdT"], self.act[a0:], Ma, self.I, h)                  # d act
+                    H.swiglu_bwd(s["gu"][a0:], self.act[a0:], self.dgu[a0:], Ma, self.I)
+                    H.gemm(self.dgu[a0:], ly["wguT"], dhb[a0:], Ma, h, 2 * self.I)
                 H.rmsnorm_bwd(dhb[a0:], s["xm"][a0:], ly["n2"], s["r2"][a0:], other[a0:], dres=dx[a0:])   # other := d x_mid
                 H.gemm(other[a0:], ly["woT"], self.datt[a0:], Ma, aw, h)
             # attention backward runs on the whole grid (rows < r0 of datt stay zero; their dQ / the dK,dV of those keys are unused)

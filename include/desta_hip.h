@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DESTA_ABI_VERSION 5
+#define DESTA_ABI_VERSION 6
 
 int desta_abi_version(void);
 /* sizeof of the descriptor structs as this library was compiled (0 = desta_gemm_desc, 1 = desta_attn_desc,
@@ -79,10 +79,14 @@ typedef struct desta_gemm_desc {
     void* preact;                      /* optional bf16 [M,N] */
     int64_t ldp, stride_p;
     float alpha;
-    void* aux;                         /* act 2: columns are interleaved (gate_i, up_i): C keeps the bf16    */
-    int64_t ld_aux;                    /*   pre-activations, aux[M,N/2] (bf16, out) = silu(gate)*up.          */
-                                       /* act 3: C[M,2N] (bf16, ldc = row length) = d(gate|up) interleaved    */
-                                       /*   from v = d(act) and aux[M,2N] (bf16, in) = saved gate|up          */
+    void* aux;                         /* act 2 / act 3: fused SwiGLU over the BLOCKED gate|up layout (ABI 6): 64-column  */
+    int64_t ld_aux;                    /*   block b of the projection = gate_{32b..32b+31} | up_{32b..32b+31} (weight rows    */
+                                       /*   permuted once at load; N % 64 == 0).  act 2 (forward): C[M,N] keeps the bf16      */
+                                       /*   projection, aux[M,N/2] (bf16, out) = silu(gate) * up in plain column order.       */
+                                       /* act 3 (backward): v = d(act)[M,N] in plain column order, aux[M,2N] (bf16, in) = the */
+                                       /*   saved blocked gate|up, C[M,2N] (bf16, ldc = row length) = d(gate|up), blocked.    */
+                                       /*   Replaces TF:models/llama/modeling_llama.py:163-176 (LlamaMLP act_fn(gate) * up)   */
+                                       /*   and its autograd; same rounding points as desta_swiglu_fwd / _bwd.                */
     float dropout_p;                   /* > 0: inverted dropout of act(acc+bias) BEFORE the residual add, mask */
     uint64_t dropout_seed;             /*   = desta_dropout_mask(seed, m*N + n) (BertSelfOutput/BertOutput, p=0.1) */
     void* workspace;                   /* optional fp32 scratch for the split-K tail (NULL = never split);   */

@@ -640,3 +640,32 @@ def test_dead_row_skip_equals_every_row(name):
     assert float((ga - gb).norm() / gb.norm()) < 1e-3, float((ga - gb).norm() / gb.norm())
     loss_o, _ = O.model_forward(w, d, batch)
     assert abs(res[True][0] - float(loss_o)) < 2e-2
+
+
+@pytest.mark.parametrize("name", ["llama", "qwen3"])
+def test_swiglu_fusion_equals_separate_kernels(golden_dir, name):
+    """Round 4: silu(gate) * up inside the gate|up GEMM epilogue (64-column gate|up blocks, `desta_gemm_desc.act` 2) and its
+    backward inside the d(act) GEMM epilogue (act 3) against the unfused path (plain layout + swiglu_fwd / swiglu_bwd kernels):
+    same rounding points, so the loss agrees to bf16 noise of a handful of elements and every gradient to 2e-3; both stay on the
+    reference's golden.  (A/B switch: `model.llm.fuse_swiglu`, bench.py --no-swiglu-fusion.)"""
+    d = O.tiny_dims(name == "qwen3")
+    g, batch = golden_batch(golden_dir, name)
+    model, w = _model(d)
+    assert all("wgu_b" in ly for ly in model.llm.layers)
+    res = {}
+    for fuse in (True, False):
+        model.llm.fuse_swiglu = fuse
+        out = model(**batch)
+        assert all(s["gu_blocked"] == fuse for s in model.llm.sv)
+        model.backward()
+        res[fuse] = (float(out.loss), model.arena.grads.clone())
+    assert abs(res[True][0] - res[False][0]) < 2e-4, (res[True][0], res[False][0])
+    a, b = res[True][1].double(), res[False][1].double()
+    assert float((a - b).norm() / b.norm()) < 2e-3, float((a - b).norm() / b.norm())
+    assert abs(res[True][0] - float(g["loss"])) < 2e-3
+    # eval forward (batch-major grid, logits kept) takes the fused projection too and matches the golden logits
+    model.eval()
+    model.llm.fuse_swiglu = True
+    out = model(**batch, keep_logits=True)
+    m = g["attention_mask"].bool()
+    assert rel_err(out.logits.float().cpu()[m], g["logits"][m]) < 2e-2
