@@ -282,6 +282,7 @@ def main():
     ap.add_argument("--no-dead-row-skip", action="store_true", help="A/B: the last decoder layer's o_proj / MLP (forward and backward) on every row instead of the target tail, layer 0's input gradient on every row instead of the audio rows")
     ap.add_argument("--attn-q64-two-kernels", action="store_true", help="A/B: the Q-Former's cross-attention backward on the separate dQ and dK/dV kernels instead of the one-pass kernel")
     ap.add_argument("--no-kv-side", action="store_true", help="A/B: the Q-Former's K | V projections inside the layer loop on the main stream instead of up front on a second stream")
+    ap.add_argument("--gelu-rcp-exp", action="store_true", help="A/B: bf16-output GELU epilogues on the A&S 7.1.26 form (v_rcp + v_exp per value) instead of the packed polynomial")
     ap.add_argument("--no-swiglu-fusion", action="store_true", help="A/B: silu(gate) * up and its backward as their own HBM passes instead of inside the gate|up / d(act) GEMM epilogues")
     ap.add_argument("--full-lm-head", action="store_true", help="A/B: lm_head / CE over the whole token grid, not only the target rows")
     a = ap.parse_args()
@@ -340,6 +341,8 @@ def main():
         H.gemm_set_option(6, a.small_gemm_ring)
     if a.splitk_inkernel:
         H.gemm_set_option(5, 1)
+    if a.gelu_rcp_exp:
+        H.gemm_set_option(9, 0)
     cfg = DeSTA25Config(**FULL_CONFIGS[a.config], use_lora=a.lora)
     t0 = time.time()
     model = DeSTA25AudioModel(cfg, weights=RandomWeights(cfg, dev, seed=0), device=dev)

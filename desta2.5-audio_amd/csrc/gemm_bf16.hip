@@ -47,6 +47,7 @@ struct GemmArgs {
     const float* rms_w; float rms_eps;                  // skinny kernel: RMSNorm(A rows; weight rms_w) applied on the fly
     const float* rope_cs; const int* rope_pos; int rope_cols, rope_hd;   // rotary embedding of output columns [0, rope_cols) in adjacent pairs
     int desync;                                         // 256-kernel: first-round blocks start up to desync x 0.5 us apart (see gemm_bf16_nt_256_kernel)
+    int gelu_poly;                                      // bf16-output GELU epilogues: 1 = packed polynomial form, 0 = A&S 7.1.26 with v_rcp / v_exp (option 9)
 };
 
 // rotary embedding of 4 consecutive outputs (two adjacent pairs) of row m, columns n0 .. n0 + 3 (see desta_gemm_desc.rope_*)
@@ -57,6 +58,17 @@ __device__ __forceinline__ void rope4(const GemmArgs& p, int m, int n0, float (&
         const float a0 = v[0], b0 = v[1], a1 = v[2], b1 = v[3];
         v[0] = a0 * cs.x - b0 * cs.y; v[1] = b0 * cs.x + a0 * cs.y;
         v[2] = a1 * cs.z - b1 * cs.w; v[3] = b1 * cs.z + a1 * cs.w;
+    }
+}
+
+// bias + GELU of 4 adjacent outputs destined for a bf16 store: packed polynomial form (common.h), or the A&S form (option 9 = 0)
+__device__ __forceinline__ void gelu4_bf16(float (&v)[4], int poly) {
+    if (poly) {
+        const desta_f32x2 a = gelu_erf_poly2(desta_f32x2{v[0], v[1]}), b = gelu_erf_poly2(desta_f32x2{v[2], v[3]});
+        v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf_fast(v[e]);
     }
 }
 
@@ -90,9 +102,8 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& p, int z, int m, int n
         if (p.out_f32) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-        } else {                                           // bf16 store: the 1.5e-7 erf approximation is exact after rounding
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_erf_fast(v[e]);
+        } else {                                           // bf16 store: the approximation error sits far below the rounding step
+            gelu4_bf16(v, p.gelu_poly);
         }
     }
     if (p.drop_thresh) {
@@ -140,10 +151,7 @@ __device__ __forceinline__ void epilogue_pair_bf16(const GemmArgs& p, int z, int
                 const float4 b = *(const float4*)(p.bias + n0);
                 v[t][0] += b.x; v[t][1] += b.y; v[t][2] += b.z; v[t][3] += b.w;
             }
-            if (p.act == 1) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[t][e] = gelu_erf_fast(v[t][e]);
-            }
+            if (p.act == 1) gelu4_bf16(v[t], p.gelu_poly);
         }
         const int col = ncol0 + (fq & 1) * 16 + (fq >> 1) * 8;
         const u16x8 r = *(const u16x8*)((const bf16_t*)p.res + (long)z * p.sR + (long)m * p.ldr + col);
@@ -174,10 +182,7 @@ __device__ __forceinline__ void epilogue_pair_bf16(const GemmArgs& p, int z, int
             v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
         }
         rope4(p, min(m, p.M - 1), n0, v);
-        if (p.act == 1) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_erf_fast(v[e]);
-        }
+        if (p.act == 1) gelu4_bf16(v, p.gelu_poly);
         if (p.res) {
             if (p.res_f32) {
                 const float4 r = *(const float4*)((const float*)p.res + (long)z * p.sR + (long)m * p.ldr + n0);
@@ -1418,6 +1423,7 @@ static int g_skinny = 0;          // 0 auto, else COLS*10 + U of the skinny (M <
 static int g_desync = 0;          // option 7: spread of the first round's block starts in 0.5-us units, grids of >= g_desync_min_items
 static int g_desync_min = 640;    // option 8: items from which the spread is applied (2.5 rounds)
 static int g_skinny_blocks = 512;  // persistent grid of the skinny kernel (2 blocks per CU)
+static int g_gelu_poly = 1;        // option 9: bf16-output GELU epilogues on the packed polynomial (1, default) or on A&S 7.1.26 (0; A/B runs)
 extern "C" int desta_gemm_set_option(int option, int value) {
     if (option == 0) g_persistent = value;
     else if (option == 1) g_stagger = value;
@@ -1433,6 +1439,7 @@ extern "C" int desta_gemm_set_option(int option, int value) {
     else if (option == 6) g_small_ring = value;
     else if (option == 7) g_desync = value;
     else if (option == 8) g_desync_min = value;
+    else if (option == 9) g_gelu_poly = value;
     else if (option == 3) {
         if (value < 1 || value > 65535) { desta_set_error("gemm_set_option: skinny grid %d out of range", value); return DESTA_EINVAL; }
         g_skinny_blocks = value;
@@ -1462,7 +1469,7 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
     a.sA = d->stride_a; a.sB = d->stride_b; a.sC = d->stride_c;
     a.bias = d->bias;
     a.res = d->residual; a.ldr = d->ldr; a.sR = d->stride_r; a.res_f32 = d->residual_f32;
-    a.act = d->act; a.out_f32 = d->out_f32;
+    a.act = d->act; a.out_f32 = d->out_f32; a.gelu_poly = g_gelu_poly;
     a.preact = (bf16_t*)d->preact; a.ldp = d->ldp; a.sP = d->stride_p;
     a.alpha = d->alpha;
     a.aux = (bf16_t*)d->aux; a.lda_x = d->ld_aux;

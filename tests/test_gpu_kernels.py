@@ -277,6 +277,39 @@ def test_gemm_epilogues_and_batch(hip):
     torch.testing.assert_close(outb.float(), pre_ref + resb.float(), rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+def test_gemm_gelu_epilogue_polynomial_form(hip, variant):
+    """bf16-output GELU(erf) epilogue (Whisper fc1 / conv stem, Q-Former FFN; TF:activations.py GELUActivation = erf form):
+    the packed degree-12 polynomial form (csrc/common.h gelu_erf_poly2, default since round 4) and the A&S 7.1.26 form
+    (option 9 = 0) both land within ONE bf16 ulp of gelu(pre-activation) evaluated in float64 and then rounded, and on the exactly
+    rounded value for > 97 % of the elements; pre-activations cover |x| up to ~9 (beyond the polynomial's clamp at 5)."""
+    g = torch.Generator().manual_seed(77)
+    M, N, K = 512, 768, 256
+    A = _bf(torch.randn(M, K, generator=g) * 0.5).cuda()
+    B = _bf(torch.randn(N, K, generator=g) / 4).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    pre = (A.float() @ B.float().T + bias).double()
+    ref = (0.5 * pre * (1 + torch.erf(pre / math.sqrt(2)))).float().to(torch.bfloat16)
+    assert float(pre.abs().max()) > 6.0
+    try:
+        hip.gemm_force_variant(variant)
+        outs = {}
+        for poly in (1, 0):
+            hip.gemm_set_option(9, poly)
+            out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+            hip.gemm(A, B, out, M, N, K, bias=bias, act=1)
+            outs[poly] = out
+            ulp = (out.view(torch.int16).int() - ref.view(torch.int16).int()).abs()
+            big = ref.float().abs() > 1e-4                                      # (tiny negative-tail values: compare absolutely)
+            assert int(ulp[big].max()) <= 1, (poly, int(ulp[big].max()))
+            assert float((out.float() - ref.float()).abs()[~big].max()) < 2e-5
+            assert float((ulp[big] != 0).float().mean()) < 0.03, (poly, float((ulp[big] != 0).float().mean()))
+        assert float((outs[0] != outs[1]).float().mean()) < 0.03
+    finally:
+        hip.gemm_set_option(9, 1)
+        hip.gemm_force_variant(0)
+
+
 def _gu_block_perm(I):
     b = torch.arange(I // 32).view(-1, 1) * 32
     r = torch.arange(32).view(1, -1)
