@@ -493,7 +493,7 @@ def _lora_lin(w, d: Dims, name: str, h: Tensor, masks: Optional[dict]) -> Tensor
 
 
 def llm_forward(w, d: Dims, inputs_embeds: Tensor, attention_mask: Tensor, keep: Optional[dict] = None,
-                position_ids: Optional[Tensor] = None, lora_masks: Optional[dict] = None) -> Tensor:
+                position_ids: Optional[Tensor] = None, lora_masks: Optional[dict] = None, layer_hook=None) -> Tensor:
     """Returns logits [B,S,V].  position_ids = arange(S) for every row (H7) unless given ([B,S], the
     generate() path); additive causal mask AND left-pad key mask, as ``create_causal_mask`` builds it."""
     B, S, _ = inputs_embeds.shape
@@ -536,6 +536,8 @@ def llm_forward(w, d: Dims, inputs_embeds: Tensor, attention_mask: Tensor, keep:
         g = _lin(h, w[p + "mlp.gate_proj.weight"])
         u = _lin(h, w[p + "mlp.up_proj.weight"])
         x = x + _lin(F.silu(g) * u, w[p + "mlp.down_proj.weight"])
+        if layer_hook is not None:            # ORCA deep injection wraps every decoder layer's forward (modeling_desta25.py:1101-1141)
+            x = layer_hook(i, x)
         if keep is not None:
             keep.setdefault("llm_hidden", []).append(x)
     x = _rmsnorm(x, w[LLM + "model.norm.weight"], d.rms_eps)

@@ -40,7 +40,7 @@ def _stub_missing():
     sys.modules["librosa"].__path__ = []
 
 
-def build_reference_model(d, w, encoder_model_id="openai/whisper-tiny"):
+def build_reference_model(d, w, encoder_model_id="openai/whisper-tiny", allow_missing_connector=False):
     """Assemble the reference classes around local-config HF modules and load weights ``w``."""
     # transformers probes optional packages with find_spec at import: import it BEFORE stubbing
     from transformers import WhisperConfig, WhisperForConditionalGeneration, LlamaConfig, Qwen3Config
@@ -123,7 +123,8 @@ def build_reference_model(d, w, encoder_model_id="openai/whisper-tiny"):
         assert llm.lm_head.weight is llm.model.embed_tokens.weight
         sd["llm_model.lm_head.weight"] = sd["llm_model.model.embed_tokens.weight"]
     missing, unexpected = torch.nn.Module.load_state_dict(model, sd, strict=False)
-    missing = [m for m in missing if "decoder" not in m and "proj_out" not in m and "encoder.layer_norm" not in m]
+    missing = [m for m in missing if "decoder" not in m and "proj_out" not in m and "encoder.layer_norm" not in m
+               and not (allow_missing_connector and m.startswith("perception.connector."))]
     assert not missing, missing
     assert not unexpected, unexpected
     model.eval()
@@ -205,9 +206,99 @@ def make_case(name, d, encoder_model_id="openai/whisper-tiny", with_generate=Tru
         print(name, "loss", float(out.loss), "->", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def make_orca_case():
+    """ORCA hybrid, first slice: the reference's own `ORCAHybridConnector`, `ORCAGatedCrossAttention` (deep injection
+    wrappers installed by `_enable_orca_deep_injection`), `_prepare_inputs_for_llm`, the ORCA branch of `forward` and
+    `compute_orca_losses` on a tiny local-config model in TRAINING mode (alignment loss on), fp32, dropout 0, with a 3-token
+    transcription behind every audio (so the transcription-span pooling of the alignment loss is exercised) ->
+    tests/golden/ref_orca_tiny.safetensors: weights of the ORCA tensors, batch, global / local tokens, logits, hidden states,
+    LM loss, every ORCA loss and every trainable gradient of (LM loss + sum of ORCA losses)."""
+    import desta_oracle as O
+    import orca_oracle as R
+    from safetensors.torch import save_file
+    from transformers import BertConfig
+    torch.manual_seed(0)
+    d = O.tiny_dims(False)
+    NTR = 3
+    o = R.OrcaDims(global_num_tokens=8, local_downsample=4, local_kernel_size=5, gate_init=0.1, audio_position_scale=2.5,
+                   global_cross_attn=False, ortho_diversity_weight=0.05, ortho_weight_qformer_local=0.05, align_weight_local=0.05)
+    w = R.init_weights(d, o, seed=7)
+    d.prompt_size = o.global_num_tokens + NTR                    # placeholders per audio in the token stream: global tokens + transcription
+    base = {k: v for k, v in O.init_weights(d, seed=7).items()}
+    base.update(w)
+    model, M = build_reference_model(d, {k: v for k, v in base.items() if not k.startswith("perception.connector.global") and not k.startswith("perception.connector.local")
+                                          and not k.startswith("orca_cross_attns.")}, allow_missing_connector=True)
+    cfg = model.config
+    for k, v in dict(connector_mode="orca_hybrid", orca_enabled=True, orca_use_all_layers=False, orca_local_enabled=True,
+                     orca_global_cross_attn=o.global_cross_attn, orca_deep_injection_enabled=True,
+                     orca_audio_position_scale=o.audio_position_scale, orca_global_num_tokens=o.global_num_tokens,
+                     orca_local_downsample=o.local_downsample, orca_local_kernel_size=o.local_kernel_size, orca_gate_init=o.gate_init,
+                     orca_ortho_weight_global=0.05, orca_ortho_diversity_weight=o.ortho_diversity_weight,
+                     orca_ortho_weight_qformer_local=o.ortho_weight_qformer_local, orca_align_weight_local=o.align_weight_local).items():
+        setattr(cfg, k, v)
+    _orig_init = BertConfig.__init__
+
+    def _patched(self, *a, **k):
+        k.setdefault("intermediate_size", d.qf_inter)
+        k.setdefault("hidden_dropout_prob", 0.0)
+        k.setdefault("attention_probs_dropout_prob", 0.0)
+        _orig_init(self, *a, **k)
+    BertConfig.__init__ = _patched
+    try:
+        model.perception.connector = M.ORCAHybridConnector(cfg)
+    finally:
+        BertConfig.__init__ = _orig_init
+    assert list(model.perception.connector.target_layer_ids) == list(d.taps)
+    model._enable_orca_deep_injection()
+    model._orca_audio_local = None
+    model._orca_audio_local_mask = None
+    rope_theta_used = float(getattr(cfg.llm_config, "rope_theta", 10000.0))        # what `_enable_orca_deep_injection` read (:1087)
+    model.configure_trainable_parameters()
+    names = R.trainable_names(d, o)
+    assert sorted(model.trainable_parameter_names) == sorted(names), set(model.trainable_parameter_names) ^ set(names)
+    assert sorted(M.DeSTA25AudioModel.state_dict(model).keys()) == sorted(names)
+    missing, unexpected = torch.nn.Module.load_state_dict(model, {n: w[n] for n in names}, strict=False)
+    assert not unexpected, unexpected
+    model.train()
+    batch = O.synthetic_batch(d, B=2, S_ctx=5, S_tgt=12, seed=11, pad=[3, 0])
+    g = torch.Generator().manual_seed(5)
+    batch["batch_transcription_ids"] = [torch.randint(3, d.vocab, (1, NTR), generator=g) for _ in range(2)]
+    starts = [(b, torch.tensor(s)) for b, s in batch["batch_start_positions"]]
+    out = M.DeSTA25AudioModel.forward(
+        model, input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], batch_features=batch["batch_features"],
+        batch_transcription_ids=batch["batch_transcription_ids"], batch_start_positions=starts, labels=batch["labels"])
+    total = out.loss
+    for v in out.orca_losses.values():
+        total = total + v
+    total.backward()
+    grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.requires_grad and p.grad is not None}
+    model.eval()
+    with torch.no_grad():
+        out_eval = M.DeSTA25AudioModel.forward(
+            model, input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], batch_features=batch["batch_features"],
+            batch_transcription_ids=batch["batch_transcription_ids"], batch_start_positions=starts, labels=batch["labels"])
+    assert "L_align_layerwise" not in out_eval.orca_losses                         # eval mode: no alignment loss (:487-488)
+    blob = {"loss": out.loss.detach().reshape(1), "logits": out.logits.detach().contiguous(),
+            "global_tokens": out.audio_global.detach().contiguous(), "local_tokens": out.audio_local.detach().contiguous(),
+            "hidden_last": out.hidden_states[-1].detach().contiguous(), "hidden_1": out.hidden_states[1].detach().contiguous(),
+            "input_ids": batch["input_ids"], "attention_mask": batch["attention_mask"], "labels": batch["labels"],
+            "batch_features": batch["batch_features"], "starts": torch.tensor([[b, int(s)] for b, s in batch["batch_start_positions"]]),
+            "transcription_ids": torch.cat(batch["batch_transcription_ids"], 0), "rope_theta_used": torch.tensor([rope_theta_used]),
+            "orca_dims": torch.tensor([o.global_num_tokens, o.local_downsample, o.local_kernel_size, NTR], dtype=torch.long),
+            "logits_eval": out_eval.logits.detach().contiguous()}
+    for k, v in out.orca_losses.items():
+        blob["orca_loss::" + k] = v.detach().reshape(1)
+    for n in names:                            # (weights are not stored: orca_oracle.init_weights(d, o, seed=7) regenerates them)
+        blob["grad::" + n] = grads[n].contiguous() if n in grads else torch.zeros_like(w[n])
+    path = os.path.join(HERE, "ref_orca_tiny.safetensors")
+    save_file({k: v.contiguous() for k, v in blob.items()}, path)
+    print("orca: lm loss", float(out.loss.detach()), {k: float(v.detach()) for k, v in out.orca_losses.items()}, "rope_theta read by the reference:", rope_theta_used,
+          "->", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def main():
     import desta_oracle as O
-    which = sys.argv[1:] or ["tiny", "deep", "tied"]
+    which = sys.argv[1:] or ["tiny", "deep", "tied", "orca"]
     if "tiny" in which:
         for name, d in (("llama", O.tiny_dims(False)), ("qwen3", O.tiny_dims(True))):
             make_case(name, d)
@@ -219,6 +310,8 @@ def main():
         # Qwen3-4B-like: tied lm_head, Hq*hd != hidden, whisper-large-v3-turbo id (taps by name) on a 4-layer stand-in is
         # not possible (taps 7..31 need 32 layers) -> tiny encoder id
         make_case("qwen3", O.tied_dims(), with_generate=True, prefix="ref_tied_")
+    if "orca" in which:
+        make_orca_case()
 
 
 if __name__ == "__main__":

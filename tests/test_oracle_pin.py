@@ -243,3 +243,70 @@ def test_lora_restatement_is_self_consistent():
         masks = {f"llm_model.model.layers.0.self_attn.q_proj": torch.zeros(2, S, d.llm_h)}        # drop everything: q of layer 0 loses its adapter
         wq = {k: (torch.zeros_like(v) if k == "llm_model.model.layers.0.self_attn.q_proj.lora_B.default.weight" else v) for k, v in w.items()}
         assert torch.allclose(O.model_forward(w, d, batch, lora_masks=masks)[1], O.model_forward(wq, d, batch)[1], atol=1e-6)   # (d)
+
+
+# ------------------------------------------------------------------------------------------------ ORCA hybrid
+def _orca_case(golden_dir):
+    import copy
+    import orca_oracle as R
+    g = load_file(os.path.join(golden_dir, "ref_orca_tiny.safetensors"))
+    kg, ds, ks, ntr = (int(x) for x in g["orca_dims"])
+    d = O.tiny_dims(False)
+    o = R.OrcaDims(global_num_tokens=kg, local_downsample=ds, local_kernel_size=ks, ortho_diversity_weight=0.05,
+                   ortho_weight_qformer_local=0.05, align_weight_local=0.05)
+    w = R.init_weights(d, o, seed=7)
+    d = copy.copy(d)
+    d.prompt_size = kg + ntr
+    # the reference read `llm_config.rope_theta` for the audio rotation and, under transformers 5.x (rope_parameters), fell back to
+    # its getattr default 10000.0 (modeling_desta25.py:1087); the oracle takes the value the golden records
+    d_x = copy.copy(d)
+    d_x.rope_theta = float(g["rope_theta_used"])
+    n = g["starts"].shape[0]
+    batch = {"input_ids": g["input_ids"], "attention_mask": g["attention_mask"], "labels": g["labels"], "batch_features": g["batch_features"],
+             "batch_start_positions": [(int(b), int(s)) for b, s in g["starts"].tolist()],
+             "batch_transcription_ids": [g["transcription_ids"][i:i + 1] for i in range(n)]}
+    return R, g, d, d_x, o, w, batch
+
+
+def test_orca_oracle_matches_reference_golden(golden_dir):
+    """`oracle/orca_oracle.py` against the reference's own ORCAHybridConnector / ORCAGatedCrossAttention / compute_orca_losses /
+    forward (tests/golden/ref_orca_tiny.safetensors, made by make_golden_from_reference.py): tokens, hidden states, logits, LM
+    loss, the three auxiliary losses and every gradient of the trainer's total loss (fp32 vs fp32)."""
+    R, g, d, d_x, o, w, batch = _orca_case(golden_dir)
+    names = R.trainable_names(d, o)
+    assert sorted("grad::" + n for n in names) == sorted(k for k in g if k.startswith("grad::"))
+    for n in names:
+        w[n].requires_grad_(True)
+    keep = {}
+
+    # the decoder's own rotary embedding keeps the model's theta; only the audio rotation uses the value the reference read
+    import orca_oracle
+    orig = orca_oracle.rope_whole_vector
+    orca_oracle.rope_whole_vector = lambda x, theta, scale: orig(x, d_x.rope_theta, scale)
+    try:
+        loss, logits, losses = R.model_forward(w, d, o, batch, training=True, keep=keep)
+        R.total_loss(loss, losses).backward()
+        with torch.no_grad():
+            _, logits_eval, losses_eval = R.model_forward(w, d, o, batch, training=False)
+    finally:
+        orca_oracle.rope_whole_vector = orig
+    assert rel_err(keep["global_tokens"], g["global_tokens"]) < 1e-5
+    assert rel_err(keep["local_tokens"], g["local_tokens"]) < 1e-5
+    assert rel_err(keep["llm_hidden"][0], g["hidden_1"]) < 1e-5                   # output of decoder layer 0 INCLUDING its injection
+    assert rel_err(logits, g["logits"]) < 2e-4 and rel_err(logits_eval, g["logits_eval"]) < 2e-4
+    assert abs(float(loss) - float(g["loss"])) < 2e-5
+    assert sorted(losses) == sorted(k[len("orca_loss::"):] for k in g if k.startswith("orca_loss::"))
+    for k, v in losses.items():
+        assert abs(float(v) - float(g["orca_loss::" + k])) < 1e-6 + 1e-4 * abs(float(g["orca_loss::" + k])), (k, float(v))
+    assert "L_align_layerwise" not in losses_eval
+    # relative L2 per tensor; the key biases' true gradient is zero (softmax is invariant to a per-query constant): measured against
+    # the typical gradient norm, as in tests/test_gpu_model.py
+    gn = sorted(float(g["grad::" + n].double().norm()) for n in names)
+    floor = gn[len(gn) // 2] * 1e-2
+    worst = max(float((w[n].grad.double() - g["grad::" + n].double()).norm() / max(float(g["grad::" + n].double().norm()), floor)) for n in names)
+    assert worst < 2e-3, worst
+
+
+def rel_err(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
