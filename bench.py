@@ -267,8 +267,8 @@ def main():
     ap.add_argument("--repeat", type=int, default=1, help="repeat the timed region (reports the best), for A/B runs")
     ap.add_argument("--no-dw-overlap", action="store_true", help="A/B: Q-Former weight gradients on the main stream")
     ap.add_argument("--gemm-4phase", action="store_true", help="A/B: the 4-phase (16 MFMAs per phase) GEMM schedule")
-    ap.add_argument("--connector-overlap", action=argparse.BooleanOptionalAction, default=True,
-                    help="the connector's backward joins all-reduce + Adafactor on the side stream beside the next batch's frozen Whisper forward (default on)")
+    ap.add_argument("--connector-overlap", action=argparse.BooleanOptionalAction, default=False,
+                    help="the connector's backward joins all-reduce + Adafactor on the side stream (default off: with the encoder on its own stream it measured +0.5 ms)")
     ap.add_argument("--timed-gemm-events", action="store_true", help="A/B: HIP events around every GEMM launch INSIDE the timed region too (rounds 1-3 did; ~800 event records per step)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group and run the gradient all-reduce even at WORLD_SIZE 1 (one-GPU rehearsal of the N > 1 path over RCCL)")
     ap.add_argument("--small-gemm-ring", type=int, default=None, help="A/B: option 6 of desta_gemm_set_option (0 = the 128x128 GEMM never takes its four-slot ring form, 1 = default, 2 = always)")
@@ -282,7 +282,7 @@ def main():
     ap.add_argument("--no-dead-row-skip", action="store_true", help="A/B: the last decoder layer's o_proj / MLP (forward and backward) on every row instead of the target tail, layer 0's input gradient on every row instead of the audio rows")
     ap.add_argument("--attn-q64-two-kernels", action="store_true", help="A/B: the Q-Former's cross-attention backward on the separate dQ and dK/dV kernels instead of the one-pass kernel")
     ap.add_argument("--no-kv-side", action="store_true", help="A/B: the Q-Former's K | V projections inside the layer loop on the main stream instead of up front on a second stream")
-    ap.add_argument("--gelu-rcp-exp", action="store_true", help="A/B: bf16-output GELU epilogues on the A&S 7.1.26 form (v_rcp + v_exp per value) instead of the packed polynomial")
+    ap.add_argument("--gelu-poly", action="store_true", help="A/B: bf16-output GELU epilogues on the packed degree-12 polynomial instead of the A&S 7.1.26 form (measured equal)")
     ap.add_argument("--no-swiglu-fusion", action="store_true", help="A/B: silu(gate) * up and its backward as their own HBM passes instead of inside the gate|up / d(act) GEMM epilogues")
     ap.add_argument("--full-lm-head", action="store_true", help="A/B: lm_head / CE over the whole token grid, not only the target rows")
     a = ap.parse_args()
@@ -341,8 +341,8 @@ def main():
         H.gemm_set_option(6, a.small_gemm_ring)
     if a.splitk_inkernel:
         H.gemm_set_option(5, 1)
-    if a.gelu_rcp_exp:
-        H.gemm_set_option(9, 0)
+    if a.gelu_poly:
+        H.gemm_set_option(9, 1)
     cfg = DeSTA25Config(**FULL_CONFIGS[a.config], use_lora=a.lora)
     t0 = time.time()
     model = DeSTA25AudioModel(cfg, weights=RandomWeights(cfg, dev, seed=0), device=dev)

@@ -92,9 +92,11 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
     const float e = 1.0f - poly * t * __expf(-z * z);          // erf(|x|/sqrt2)
     return 0.5f * x * (1.0f + copysignf(e, x));
 }
-// GELU(erf) for bf16-rounded outputs, TWO values per instruction (round 4): with one 256x256 tile per CU the bias + GELU epilogue
-// of the Whisper fc1 GEMM is VALU-bound — 128 outputs per lane at ~20 issue slots each (v_rcp and v_exp are quarter rate and do
-// not pack) = 12 us per tile beside a 29-us main loop.  Here: gelu(x) = x * (0.5 + xc * R(xc^2)), xc = clamp(x, +-5), R = the
+// GELU(erf) for bf16-rounded outputs, TWO values per instruction (round 4; OPT-IN, desta_gemm_set_option(9, 1)).  Hypothesis: with
+// one 256x256 tile per CU the bias + GELU epilogue of the Whisper fc1 GEMM is VALU-bound (128 outputs per lane at ~20 issue slots
+// each: v_rcp and v_exp are quarter rate and do not pack).  Measured: NO step-time difference against the A&S form in a same-box
+// alternating A/B (bench.py --gelu-rcp-exp, profiles/r04_ab_step.log) — the epilogue is not issue-bound — so the A&S form, which is
+// four times more accurate, stays the default.  The form: gelu(x) = x * (0.5 + xc * R(xc^2)), xc = clamp(x, +-5), R = the
 // degree-12 Chebyshev interpolant of (Phi(x) - 0.5) / x over x^2 in [0, 25], evaluated by Horner in u = 2 x^2 / 25 - 1 on
 // register PAIRS (v_pk_mul_f32 / v_pk_fma_f32: 17 packed instructions per two values, no transcendental) — ~9 issue slots per
 // value.  Host check (numpy, fp32 Horner, 2 M points in [-9, 9]): |error| < 1.9e-6 absolute (A&S 7.1.26 above: 4.7e-7), relative

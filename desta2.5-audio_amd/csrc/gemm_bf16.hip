@@ -47,7 +47,7 @@ struct GemmArgs {
     const float* rms_w; float rms_eps;                  // skinny kernel: RMSNorm(A rows; weight rms_w) applied on the fly
     const float* rope_cs; const int* rope_pos; int rope_cols, rope_hd;   // rotary embedding of output columns [0, rope_cols) in adjacent pairs
     int desync;                                         // 256-kernel: first-round blocks start up to desync x 0.5 us apart (see gemm_bf16_nt_256_kernel)
-    int gelu_poly;                                      // bf16-output GELU epilogues: 1 = packed polynomial form, 0 = A&S 7.1.26 with v_rcp / v_exp (option 9)
+    int gelu_poly;                                      // bf16-output GELU epilogues: 0 = A&S 7.1.26 with v_rcp / v_exp (default), 1 = packed polynomial form (option 9)
 };
 
 // rotary embedding of 4 consecutive outputs (two adjacent pairs) of row m, columns n0 .. n0 + 3 (see desta_gemm_desc.rope_*)
@@ -1423,7 +1423,7 @@ static int g_skinny = 0;          // 0 auto, else COLS*10 + U of the skinny (M <
 static int g_desync = 0;          // option 7: spread of the first round's block starts in 0.5-us units, grids of >= g_desync_min_items
 static int g_desync_min = 640;    // option 8: items from which the spread is applied (2.5 rounds)
 static int g_skinny_blocks = 512;  // persistent grid of the skinny kernel (2 blocks per CU)
-static int g_gelu_poly = 1;        // option 9: bf16-output GELU epilogues on the packed polynomial (1, default) or on A&S 7.1.26 (0; A/B runs)
+static int g_gelu_poly = 0;        // option 9: bf16-output GELU epilogues on A&S 7.1.26 (0, default) or on the packed polynomial (1): same step time in the same-box A/B (163.0 / 163.3 vs 163.1 / 163.2 ms), so the more accurate form stays
 extern "C" int desta_gemm_set_option(int option, int value) {
     if (option == 0) g_persistent = value;
     else if (option == 1) g_stagger = value;

@@ -43,7 +43,7 @@ class TrainingArguments:
     optim: str = "adafactor"
     bf16: bool = True
     overlap_comm: bool = True
-    overlap_connector_backward: bool = True        # with overlap_comm: the connector's backward ALSO runs on the side stream beside the next batch's frozen Whisper forward (bit-identical results; default since round 4)
+    overlap_connector_backward: bool = False       # with overlap_comm: the connector's backward ALSO runs on the side stream (bit-identical results; round 3: -0.4 ms WITHOUT the encoder stream; round 4, beside `overlap_encoder`: +0.5 ms and 4x the step-time spread, same-box A/B -> off)
     overlap_encoder: bool = True                   # next batch's frozen Whisper forward on its own HIP stream beside the connector / LLM of the current batch (bit-identical results; default since round 4)
     save_strategy: str = "no"                      # "epoch" (train_desta.py:146, enable_checkpointing) | "no"
     steps_per_epoch: Optional[int] = None          # len(train dataloader) = MICRO-batches per epoch when the dataset is not sized (synthetic streams)

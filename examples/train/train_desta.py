@@ -132,7 +132,7 @@ def create_training_args(cfg: Cfg):
         per_device_eval_batch_size=cfg.dataset.validation_ds.batch_size,
         overlap_comm=bool(cfg.trainer.get("overlap_comm", True)),
         overlap_encoder=bool(cfg.trainer.get("overlap_encoder", True)),
-        overlap_connector_backward=bool(cfg.trainer.get("overlap_connector_backward", True)),
+        overlap_connector_backward=bool(cfg.trainer.get("overlap_connector_backward", False)),
         # synthetic streams have no len(): every rank draws num_samples // batch_size batches per epoch
         steps_per_epoch=(cfg.dataset.train_ds.num_samples // cfg.dataset.train_ds.batch_size
                          if cfg.dataset.train_ds.get("synthetic", False) else None))

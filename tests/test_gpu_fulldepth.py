@@ -57,6 +57,7 @@ def test_full_width_full_depth_vs_oracle(golden_dir):
     # ... and the TRAINING FAST PATH (position-major grid, lm_head on target rows, fused rotary epilogue, dead-row skips)
     out2 = model(**batch)
     assert out2.logits is None
+    model.arena.grads.zero_()                                                  # (the comparison below must not see the first backward's values)
     model.backward()
     g_fast = {n: model.arena.grad(n).detach().double().cpu() for n in names}
 
@@ -98,8 +99,22 @@ def test_full_width_full_depth_vs_oracle(golden_dir):
     assert all(t < 1e-2 for t in rec["taps"]), rec                             # flat in depth: fp32 Whisper residual stream
     assert all(t < 3e-2 for t in rec["hidden_1_16_32"]), rec
     assert rec["grad"] < 5e-2 and rec["cos"] > 0.999, rec
-    # two bf16 paths with different rounding points (fused rotary epilogue, position-major grid, split-K tails) over 32 decoder
-    # layers: measured 7.7e-3 apart — half of either path's own distance from the fp32 oracle (1.5e-2); at 2 layers it is 2.4e-3
-    assert rec["fast_vs_full_grad"] < 1.5e-2, rec
+    # the fast path changes WHICH rows are computed, not how (no split-K tail at M = 207): the two gradients agree to 8e-3 or better
+    # (half of either path's own distance from the fp32 oracle)
+    assert rec["fast_vs_full_grad"] < 8e-3, rec
     assert ratio[wr] < 2.5, rec                                                # no tensor more than 2.5x the policy's own error
     assert errs[worst] < 0.06, rec
+    # the same pair of passes with the SwiGLU epilogue fusion OFF (separate swiglu kernels, plain gate|up layout): same loss to bf16
+    # noise, gradients within 5e-3 of the fused run, and again fast path == full grid
+    model.llm.fuse_swiglu = False
+    res = {}
+    for fast in (False, True):
+        o3 = model(**batch, keep_logits=True) if not fast else model(**batch)
+        model.arena.grads.zero_()
+        model.backward()
+        res[fast] = (float(o3.loss), model.arena.grads.clone())
+    model.llm.fuse_swiglu = True
+    unf = dict(dloss_vs_fused=abs(res[False][0] - float(loss_full)), grad_vs_fused=float((res[False][1] - g_full).double().norm() / g_full.double().norm()),
+               fast_vs_full=float((res[True][1] - res[False][1]).double().norm() / res[False][1].double().norm()))
+    print("   SwiGLU fusion off:", unf)
+    assert unf["dloss_vs_fused"] < 2e-3 and unf["grad_vs_fused"] < 1e-2 and unf["fast_vs_full"] < 8e-3, unf
