@@ -659,3 +659,32 @@ def target_rows(labels, batch, seq, idx, compact_labels, count, s_major=False):
     """Rows with a real shifted target -> idx / compact label layout / device count int32[2] = (n, first position with a target)
     (see include/desta_hip.h)."""
     check(_target_rows(p(labels), batch, seq, p(idx), p(compact_labels), p(count), int(s_major), stream()), "desta_target_rows")
+
+
+# ----------------------------------------------------------------------------- ORCA hybrid (forward only, ABI 6)
+_orca_local_mix = _sig("desta_orca_local_mix", vp, vp, i32, i64, i32, vp, vp)
+_orca_rope = _sig("desta_orca_rope", vp, vp, i32, i32, i32, C.c_float, C.c_float, i32, vp)
+_orca_gate_residual = _sig("desta_orca_gate_residual", vp, i64, vp, vp, vp, vp, i64, i32, i32, vp, vp)
+_orca_sim_loss = _sig("desta_orca_sim_loss", vp, vp, vp, i32, i32, i32, i64, i32, i32, vp, vp)
+_orca_align = _sig("desta_orca_align", vp, i32, vp, i64, i64, i32, vp, i32, vp, vp)
+
+
+def orca_local_mix(x, layer_weights, taps, rows, d, out):
+    check(_orca_local_mix(p(x), p(layer_weights), taps, rows, d, p(out), stream()), "desta_orca_local_mix")
+
+
+def orca_rope(x, y, batch, tokens, hidden, theta, position_scale, round_cos_sin=True):
+    check(_orca_rope(p(x), p(y), batch, tokens, hidden, float(theta), float(position_scale), int(round_cos_sin), stream()), "desta_orca_rope")
+
+
+def orca_gate_residual(hidden, ld_hidden, cross, gate_hidden, gate_w2, gate_b2, rows, hidden_size, gate_width, gate_out=None):
+    check(_orca_gate_residual(p(hidden), ld_hidden, p(cross), p(gate_hidden), p(gate_w2), p(gate_b2), rows, hidden_size, gate_width,
+                              p(gate_out), stream()), "desta_orca_gate_residual")
+
+
+def orca_sim_loss(x, y, y_index, batch, nx, ny, y_rows, hidden, subtract_identity, partials):
+    check(_orca_sim_loss(p(x), p(y), p(y_index), batch, nx, ny, y_rows, hidden, int(subtract_identity), p(partials), stream()), "desta_orca_sim_loss")
+
+
+def orca_align(audio, tokens, hidden, row_stride, batch_stride, hidden_size, spans, n_spans, out):
+    check(_orca_align(p(audio), tokens, p(hidden), row_stride, batch_stride, hidden_size, p(spans), n_spans, p(out), stream()), "desta_orca_align")

@@ -116,11 +116,28 @@ class DeSTA25Config:
                  audio_locator="<|AUDIO|>", placeholder_token="<|reserved_special_token_87|>",
                  llm_config: Optional[dict] = None, encoder_config: Optional[dict] = None,
                  qformer_intermediate_size: int = 3072, target_layer_ids: Optional[List[int]] = None,
-                 qformer_dropout: float = 0.1, orca_enabled=False, **kwargs):
-        if connector_mode != "qformer_1" or orca_enabled:
-            raise NotImplementedError(
-                f"connector_mode '{connector_mode}' not implemented. Supported modes: 'qformer_1' "
-                "(ORCA hybrid is out of scope of the MI355X hot path, SURVEY.md §8f)")
+                 qformer_dropout: float = 0.1, orca_enabled=False, orca_use_all_layers=False, orca_local_enabled=True,
+                 orca_global_cross_attn=False, orca_deep_injection_enabled=True, orca_audio_position_scale=2.5,
+                 orca_global_num_tokens=4, orca_local_downsample=4, orca_local_kernel_size=5, orca_gate_init=0.1,
+                 orca_ortho_weight_global=0.01, orca_ortho_diversity_weight=0.01, orca_ortho_weight_qformer_local=0.01,
+                 orca_align_weight_local=0.05, **kwargs):
+        if connector_mode not in ("qformer_1", "orca_hybrid"):
+            raise NotImplementedError(f"mode {connector_mode} not implemented")        # modeling_desta25.py:627
+        if connector_mode == "qformer_1" and orca_enabled:
+            raise NotImplementedError("orca_enabled with connector_mode 'qformer_1' (the Q-Former auxiliary losses, modeling_desta25.py:846-930) "
+                                      "is not implemented")
+        if connector_mode == "orca_hybrid" and (orca_use_all_layers or not orca_local_enabled):
+            raise NotImplementedError("orca_hybrid: orca_use_all_layers / orca_local_enabled=False ablations are not implemented")
+        # ORCA hybrid, FIRST SLICE: the forward (connector, deep injection, auxiliary losses) runs on the device and
+        # is pinned to the reference's golden; the backward is not built (training raises).  Field names and defaults: :645-692.
+        self.orca_enabled = bool(orca_enabled) or connector_mode == "orca_hybrid"
+        self.orca_use_all_layers, self.orca_local_enabled = bool(orca_use_all_layers), bool(orca_local_enabled)
+        self.orca_global_cross_attn, self.orca_deep_injection_enabled = bool(orca_global_cross_attn), bool(orca_deep_injection_enabled)
+        self.orca_audio_position_scale, self.orca_global_num_tokens = float(orca_audio_position_scale), int(orca_global_num_tokens)
+        self.orca_local_downsample, self.orca_local_kernel_size = int(orca_local_downsample), int(orca_local_kernel_size)
+        self.orca_gate_init, self.orca_ortho_weight_global = float(orca_gate_init), float(orca_ortho_weight_global)
+        self.orca_ortho_diversity_weight, self.orca_ortho_weight_qformer_local = float(orca_ortho_diversity_weight), float(orca_ortho_weight_qformer_local)
+        self.orca_align_weight_local = float(orca_align_weight_local)
         # use_lora: peft.LoraConfig(r=16, lora_alpha=16, lora_dropout=0.1, target_modules=[q_proj, k_proj, v_proj]) on the
         # decoder (modeling_desta25.py:720-729); the three constants are fixed there, kept as fields for tests
         self.lora_r, self.lora_alpha = int(kwargs.pop("lora_r", 16)), float(kwargs.pop("lora_alpha", 16))
@@ -128,7 +145,6 @@ class DeSTA25Config:
         self.llm_model_id, self.encoder_model_id = llm_model_id, encoder_model_id
         self.connector_mode, self.qformer_num_hidden_layers, self.prompt_size = connector_mode, qformer_num_hidden_layers, prompt_size
         self.use_lora, self.audio_locator, self.placeholder_token = bool(use_lora), audio_locator, placeholder_token
-        self.orca_enabled = False
         self.qformer_intermediate_size = qformer_intermediate_size   # BertConfig() default (never overridden, :156-162)
         # BertConfig() defaults hidden_dropout_prob = attention_probs_dropout_prob = 0.1 are never overridden
         # either (hazard H3): active in training mode, own counter-based RNG (not torch's Philox stream)
@@ -171,7 +187,11 @@ class DeSTA25Config:
         return {"model_type": self.model_type, "llm_model_id": self.llm_model_id, "encoder_model_id": self.encoder_model_id,
                 "connector_mode": self.connector_mode, "qformer_num_hidden_layers": self.qformer_num_hidden_layers,
                 "prompt_size": self.prompt_size, "use_lora": self.use_lora, "audio_locator": self.audio_locator,
-                "placeholder_token": self.placeholder_token, "orca_enabled": False,
+                "placeholder_token": self.placeholder_token, "orca_enabled": self.orca_enabled,
+                **{k: getattr(self, k) for k in ("orca_use_all_layers", "orca_local_enabled", "orca_global_cross_attn", "orca_deep_injection_enabled",
+                                                 "orca_audio_position_scale", "orca_global_num_tokens", "orca_local_downsample", "orca_local_kernel_size",
+                                                 "orca_gate_init", "orca_ortho_weight_global", "orca_ortho_diversity_weight",
+                                                 "orca_ortho_weight_qformer_local", "orca_align_weight_local")},
                 "qformer_intermediate_size": self.qformer_intermediate_size, "target_layer_ids": self.target_layer_ids,
                 "qformer_dropout": self.qformer_dropout, "lora_r": self.lora_r, "lora_alpha": self.lora_alpha, "lora_dropout": self.lora_dropout,
                 "llm_config": asdict(self.llm_config), "encoder_config": asdict(self.encoder_config), "info": self.info}
@@ -194,14 +214,17 @@ def connector_param_shapes(cfg: DeSTA25Config) -> "OrderedDict[str, Tuple[int, .
     """Trainable tensors with the reference's state-dict names, in ARENA order:
     query/key/value weights (and biases) of every attention block are adjacent so that the fused
     QKV / KV projection GEMMs read them as one [3d, d] / [2d, d] operand."""
-    d, K, nt = cfg.encoder_config.d_model, cfg.prompt_size, len(cfg.target_layer_ids)
+    orca = cfg.connector_mode == "orca_hybrid"
+    d, K, nt = cfg.encoder_config.d_model, (cfg.orca_global_num_tokens if orca else cfg.prompt_size), len(cfg.target_layer_ids)
     inter, h = cfg.qformer_intermediate_size, cfg.llm_config.hidden_size
     s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    n_prompts, n_weights, n_qf, n_proj = (("global_queries.", "global_layer_weights", "global_qformer.layer.", "global_proj.") if orca
+                                          else ("layer_prompts.", "layer_weights", "qformer.layer.", "proj."))
     for j in range(nt):
-        s[f"{CON}layer_prompts.{j}"] = (1, K, d)
-    s[f"{CON}layer_weights"] = (K, nt)
+        s[f"{CON}{n_prompts}{j}"] = (1, K, d)
+    s[f"{CON}{n_weights}"] = (K, nt)
     for i in range(cfg.qformer_num_hidden_layers):
-        p = f"{CON}qformer.layer.{i}."
+        p = f"{CON}{n_qf}{i}."
         for blk in ("attention", "crossattention"):
             for lin in ("query", "key", "value"):
                 s[f"{p}{blk}.self.{lin}.weight"] = (d, d)
@@ -217,10 +240,33 @@ def connector_param_shapes(cfg: DeSTA25Config) -> "OrderedDict[str, Tuple[int, .
         s[p + "output.dense.bias"] = (d,)
         s[p + "output.LayerNorm.weight"] = (d,)
         s[p + "output.LayerNorm.bias"] = (d,)
-    s[CON + "proj.0.weight"] = (d,)
-    s[CON + "proj.0.bias"] = (d,)
-    s[CON + "proj.1.weight"] = (h, d)
-    s[CON + "proj.1.bias"] = (h,)
+    s[CON + n_proj + "0.weight"] = (d,)
+    s[CON + n_proj + "0.bias"] = (d,)
+    s[CON + n_proj + "1.weight"] = (h, d)
+    s[CON + n_proj + "1.bias"] = (h,)
+    if orca:
+        # local branch (modeling_desta25.py:266-287) and the gated cross-attention of every decoder layer (:359-393, :1084-1098)
+        k = cfg.orca_local_kernel_size
+        s[CON + "local_layer_weights"] = (nt,)
+        s[CON + "local_proj_in.weight"] = (h, d)
+        s[CON + "local_proj_in.bias"] = (h,)
+        s[CON + "local_conv.weight"] = (h, h, k)
+        s[CON + "local_conv.bias"] = (h,)
+        s[CON + "local_ln.weight"] = (h,)
+        s[CON + "local_ln.bias"] = (h,)
+        if cfg.orca_deep_injection_enabled:
+            for l in range(cfg.llm_config.num_hidden_layers):
+                q = f"orca_cross_attns.{l}."
+                s[q + "cross_attn.in_proj_weight"] = (3 * h, h)
+                s[q + "cross_attn.in_proj_bias"] = (3 * h,)
+                s[q + "cross_attn.out_proj.weight"] = (h, h)
+                s[q + "cross_attn.out_proj.bias"] = (h,)
+                s[q + "gate_proj.0.weight"] = (h // 4, h)
+                s[q + "gate_proj.0.bias"] = (h // 4,)
+                s[q + "gate_proj.2.weight"] = (1, h // 4)
+                s[q + "gate_proj.2.bias"] = (1,)
+                s[q + "ln.weight"] = (h,)
+                s[q + "ln.bias"] = (h,)
     return s
 
 
@@ -397,7 +443,14 @@ class QformerConnectorHIP:
 
     def __init__(self, cfg: DeSTA25Config, arena: ParamArena, device):
         self.cfg, self.arena, self.dev = cfg, arena, device
-        self.d, self.K, self.nt = cfg.encoder_config.d_model, cfg.prompt_size, len(cfg.target_layer_ids)
+        # qformer_1: the whole connector.  orca_hybrid: the GLOBAL branch of ORCAHybridConnector (modeling_desta25.py:241-264, 318-334) is
+        # the same Q-Former block under other tensor names with `orca_global_num_tokens` queries
+        orca = cfg.connector_mode == "orca_hybrid"
+        self.n_prompts = CON + ("global_queries." if orca else "layer_prompts.")
+        self.n_weights = CON + ("global_layer_weights" if orca else "layer_weights")
+        self.n_qf = CON + ("global_qformer.layer." if orca else "qformer.layer.")
+        self.n_proj = CON + ("global_proj." if orca else "proj.")
+        self.d, self.K, self.nt = cfg.encoder_config.d_model, (cfg.orca_global_num_tokens if orca else cfg.prompt_size), len(cfg.target_layer_ids)
         self.heads, self.T = cfg.encoder_config.encoder_attention_heads, cfg.encoder_config.max_source_positions
         self.inter, self.Lq, self.h = cfg.qformer_intermediate_size, cfg.qformer_num_hidden_layers, cfg.llm_config.hidden_size
         assert self.d // self.heads == 64 and self.d % 64 == 0 and self.inter % 64 == 0 and self.h % 64 == 0
@@ -444,7 +497,7 @@ class QformerConnectorHIP:
         H.cast_bf16(self.arena.params, self.w16, self.arena.numel)
         d, inter = self.d, self.inter
         for i in range(self.Lq):
-            p = f"{CON}qformer.layer.{i}."
+            p = f"{self.n_qf}{i}."
             for key, name, rows, cols in (
                     ("s.qkv", p + "attention.self.query.weight", 3 * d, d), ("s.o", p + "attention.output.dense.weight", d, d),
                     ("c.q", p + "crossattention.self.query.weight", d, d), ("c.o", p + "crossattention.output.dense.weight", d, d),
@@ -455,7 +508,7 @@ class QformerConnectorHIP:
                 H.transpose_to_bf16(self.W16(name, rows), rows, cols, self.wT[k], rows)
         if "proj" not in self.wT:
             self.wT["proj"] = torch.empty(d, self.h, dtype=BF16, device=self.dev)
-        H.transpose_to_bf16(self.W16(CON + "proj.1.weight"), self.h, d, self.wT["proj"], self.h)
+        H.transpose_to_bf16(self.W16(self.n_proj + "1.weight"), self.h, d, self.wT["proj"], self.h)
 
     def _alloc(self, B: int):
         d, K, nt, T, dev, inter = self.d, self.K, self.nt, self.T, self.dev, self.inter
@@ -497,7 +550,7 @@ class QformerConnectorHIP:
             self._alloc(B)
         d, K, nt, T, R, E = self.d, self.K, self.nt, self.T, self.R, self.E
         self.enc = enc_all.view(E, d)
-        H.prompt_expand(self.P32(f"{CON}layer_prompts.0", nt * K * d), nt, B, K * d, self.x0_32, self.x0_16)
+        H.prompt_expand(self.P32(self.n_prompts + "0", nt * K * d), nt, B, K * d, self.x0_32, self.x0_16)
         x32, x16 = self.x0_32, self.x0_16
         scale = 64 ** -0.5
         pd = self.p_drop
@@ -512,13 +565,13 @@ class QformerConnectorHIP:
             kv_ev = []
             with torch.cuda.stream(self._kv_stream):
                 for i in range(self.Lq):
-                    p = f"{CON}qformer.layer.{i}."
+                    p = f"{self.n_qf}{i}."
                     H.gemm(self.enc, self.W16(p + "crossattention.self.key.weight", 2 * d), self.sv[i]["kv"], E, 2 * d, d, bias=self.P32(p + "crossattention.self.key.bias", 2 * d))
                     ev = torch.cuda.Event()
                     ev.record(self._kv_stream)
                     kv_ev.append(ev)
         for i in range(self.Lq):
-            p, s = f"{CON}qformer.layer.{i}.", self.sv[i]
+            p, s = f"{self.n_qf}{i}.", self.sv[i]
             sd = [site_seed(self.seed_base, 1, i, k) for k in range(5)]   # attn-self, out1, attn-cross, out2, out3
             s["seeds"], s["pd"] = sd, pd
             # self-attention over the K queries (bidirectional, H5)
@@ -554,9 +607,9 @@ class QformerConnectorHIP:
             s["x_in32"], s["x_in16"] = x32, x16
             x32, x16 = s["x3_32"], s["x3_16"]
         self.qf_out = x32
-        H.tap_mix_fwd(x32, self.P32(CON + "layer_weights"), nt, B, K, d, self.mixed)
-        H.layernorm_fwd(self.mixed, self.P32(CON + "proj.0.weight"), self.P32(CON + "proj.0.bias"), 1e-5, y16=self.pb, stats=self.st_p)
-        H.gemm(self.pb, self.W16(CON + "proj.1.weight"), self.af, B * K, self.h, d, bias=self.P32(CON + "proj.1.bias"))
+        H.tap_mix_fwd(x32, self.P32(self.n_weights), nt, B, K, d, self.mixed)
+        H.layernorm_fwd(self.mixed, self.P32(self.n_proj + "0.weight"), self.P32(self.n_proj + "0.bias"), 1e-5, y16=self.pb, stats=self.st_p)
+        H.gemm(self.pb, self.W16(self.n_proj + "1.weight"), self.af, B * K, self.h, d, bias=self.P32(self.n_proj + "1.bias"))
         return self.af
 
     def __call__(self, encoder_hidden_states) -> torch.Tensor:
@@ -633,16 +686,16 @@ class QformerConnectorHIP:
         d, K, nt, T, R, E, B, inter, h = self.d, self.K, self.nt, self.T, self.R, self.E, self.B, self.inter, self.h
         BK = B * K
         # projector
-        self._dW(d_af, self.pb, BK, h, d, CON + "proj.1.weight", CON + "proj.1.bias", self.BKp)
+        self._dW(d_af, self.pb, BK, h, d, self.n_proj + "1.weight", self.n_proj + "1.bias", self.BKp)
         H.gemm(d_af, self.wT["proj"], self.dpb, BK, d, h)
-        H.layernorm_bwd(self.dpb, self.mixed, self.P32(CON + "proj.0.weight"), self.st_p, dx32=self.dmixed,
-                        dgamma=self.G32(CON + "proj.0.weight"), dbeta=self.G32(CON + "proj.0.bias"))
+        H.layernorm_bwd(self.dpb, self.mixed, self.P32(self.n_proj + "0.weight"), self.st_p, dx32=self.dmixed,
+                        dgamma=self.G32(self.n_proj + "0.weight"), dbeta=self.G32(self.n_proj + "0.bias"))
         dx = self.g32a                                                        # grad wrt current layer output (fp32 [R,d])
-        H.tap_mix_bwd(self.qf_out, self.P32(CON + "layer_weights"), self.dmixed, nt, B, K, d, dx, self.G32(CON + "layer_weights"))
+        H.tap_mix_bwd(self.qf_out, self.P32(self.n_weights), self.dmixed, nt, B, K, d, dx, self.G32(self.n_weights))
         other = self.g32b
         H.transpose_to_bf16(self.enc, E, d, self.tE, self.Ep)
         for i in reversed(range(self.Lq)):
-            p, s = f"{CON}qformer.layer.{i}.", self.sv[i]
+            p, s = f"{self.n_qf}{i}.", self.sv[i]
             # --- FFN block: x3 = LN(pre3), pre3 = hact@Wo^T + b + x2
             dpre, dpre16, dh, da, dq, dqkv = other, self.dpre16, self.dh, self.da, self.dq, self.dqkv
             self._join_dw()
@@ -687,8 +740,146 @@ class QformerConnectorHIP:
             H.attention_bwd(s["ad_s"], da, dqkv, dqkv, dqkv, dq_off=0, dk_off=d, dv_off=2 * d)
             self._dW(dqkv, s["x_in16"], R, 3 * d, d, p + "attention.self.query.weight", p + "attention.self.query.bias", self.Rp)
             H.gemm(dqkv, self.wT[f"{i}.s.qkv"], dx, R, d, 3 * d, residual=dpre)                # dx := d x_in32
-        H.prompt_grad(dx, nt, B, K * d, self.G32(f"{CON}layer_prompts.0", nt * K * d))
+        H.prompt_grad(dx, nt, B, K * d, self.G32(self.n_prompts + "0", nt * K * d))
         self._join_dw()
+
+
+# =========================================================================================== ORCA hybrid (forward only)
+class OrcaHIP:
+    """ORCA hybrid, FIRST SLICE: forward of the local branch of `ORCAHybridConnector` (modeling_desta25.py:336-352),
+    of `ORCAGatedCrossAttention` behind every decoder layer (:395-490, installed by `_enable_orca_deep_injection` :1052-1143) and of
+    `compute_orca_losses` (:1159-1206), composed from the C-ABI entry points of the qformer_1 path (GEMM, flash attention, LayerNorm)
+    plus the row-wise `desta_orca_*` kernels.  The global branch is `QformerConnectorHIP` under the ORCA tensor names.  No backward:
+    `DeSTA25AudioModel.backward` raises for this mode.  Pinned to the reference's own classes at tiny size
+    (tests/golden/ref_orca_tiny.safetensors, tests/test_gpu_orca.py)."""
+
+    def __init__(self, cfg: DeSTA25Config, connector: "QformerConnectorHIP", device):
+        c = cfg.llm_config
+        self.cfg, self.con, self.dev = cfg, connector, device
+        self.h, self.d, self.nt = c.hidden_size, cfg.encoder_config.d_model, len(cfg.target_layer_ids)
+        self.heads, self.L = c.num_attention_heads, c.num_hidden_layers
+        self.hd = self.h // self.heads
+        if self.hd not in (64, 128):
+            raise NotImplementedError(f"orca_hybrid: cross-attention head size {self.hd} (hidden {self.h} / {self.heads} heads); 64 and 128 are built")
+        self.k, self.stride = cfg.orca_local_kernel_size, cfg.orca_local_downsample
+        self.pad = self.k // 2
+        assert self.h % 64 == 0 and (self.h // 4) % 4 == 0
+        # the reference reads `llm_config.rope_theta` (modeling_desta25.py:1087; 4.x config attribute); transformers 5.x keeps it under
+        # rope_parameters and the reference's getattr then falls back to 10000.0 — LLMConfig carries the model's value (4.x semantics)
+        self.rope_theta = float(cfg.extra.get("orca_rope_theta", c.rope_theta))
+        self.conv_w = None
+        self.B = 0
+
+    def refresh_weights(self) -> None:
+        """bf16 operand of the Conv1d as an im2col GEMM: [out, in, k] -> [out, k * in] (tap-major rows of the padded token stream)."""
+        w = self.con.arena.param(CON + "local_conv.weight")
+        self.conv_w = w.permute(0, 2, 1).reshape(self.h, self.k * self.h).to(BF16).contiguous()
+
+    def _alloc(self, B: int, T: int) -> None:
+        dev, h = self.dev, self.h
+        self.B, self.T = B, T
+        self.Tl = (T + 2 * self.pad - self.k) // self.stride + 1
+        self.fused = torch.empty(B * T, self.d, dtype=BF16, device=dev)
+        self.loc_in = torch.zeros(B, T + 2 * self.pad, h, dtype=BF16, device=dev)      # zero rows = the convolution's padding
+        self.conv_out = torch.empty(B * self.Tl, h, dtype=F32, device=dev)
+        self.local16 = torch.empty(B * self.Tl, h, dtype=BF16, device=dev)
+
+    def local_forward(self, enc_all: torch.Tensor, B: int) -> torch.Tensor:
+        """enc_all [taps, B*T, d] bf16 -> local tokens [B*T', h] bf16."""
+        con, h, d = self.con, self.h, self.d
+        T = enc_all.shape[1] // B
+        if (B, T) != (self.B, getattr(self, "T", -1)):
+            self._alloc(B, T)
+        if self.conv_w is None:
+            self.refresh_weights()
+        H.orca_local_mix(enc_all, con.P32(CON + "local_layer_weights"), self.nt, B * T, d, self.fused)
+        Tp = T + 2 * self.pad
+        H.gemm(self.fused, con.W16(CON + "local_proj_in.weight"), self.loc_in[:, self.pad:], T, h, d, bias=con.P32(CON + "local_proj_in.bias"),
+               batch=B, stride_a=T * d, stride_c=Tp * h, ldc=h)
+        # Conv1d(k, stride, pad) over time as a zero-copy im2col GEMM: output t' reads rows [t' stride, t' stride + k) of the padded stream
+        H.gemm(self.loc_in, self.conv_w, self.conv_out, self.Tl, h, self.k * h, lda=self.stride * h, ldc=h, bias=con.P32(CON + "local_conv.bias"),
+               batch=B, stride_a=Tp * h, stride_c=self.Tl * h)
+        H.layernorm_fwd(self.conv_out, con.P32(CON + "local_ln.weight"), con.P32(CON + "local_ln.bias"), 1e-5, y16=self.local16)
+        return self.local16
+
+    # -- deep injection
+    def begin(self, global16: torch.Tensor, local16: Optional[torch.Tensor], B: int, S: int, spans, training: bool) -> None:
+        """Audio tokens the gated cross-attention of every layer attends to (modeling_desta25.py:792-806): the local tokens, or
+        global | local with `orca_global_cross_attn`; rotated ONCE (the rotation does not depend on the layer, :422-438)."""
+        cfg, h, dev = self.cfg, self.h, self.dev
+        self.audio = None
+        self.aligns: List[torch.Tensor] = []
+        if not cfg.orca_deep_injection_enabled:
+            return
+        Kg = cfg.orca_global_num_tokens
+        if cfg.orca_global_cross_attn:
+            g3 = global16.view(B, Kg, h)
+            a = torch.cat([g3, local16.view(B, -1, h)], dim=1).contiguous() if local16 is not None else g3.contiguous()
+        else:
+            a = local16.view(B, -1, h) if local16 is not None else None
+        if a is None or a.shape[1] == 0:
+            return
+        Ta = a.shape[1]
+        self.Ta, self.M, self.Bq, self.S = Ta, B * S, B, S
+        self.audio = torch.empty(B * Ta, h, dtype=BF16, device=dev)
+        H.orca_rope(a, self.audio, B, Ta, h, self.rope_theta, cfg.orca_audio_position_scale, round_cos_sin=True)
+        M = B * S
+        self.q16, self.att16 = torch.empty(M, h, dtype=BF16, device=dev), torch.empty(M, h, dtype=BF16, device=dev)
+        self.kv16 = torch.empty(B * Ta, 2 * h, dtype=BF16, device=dev)
+        self.lse = torch.empty(B, self.heads, S, dtype=F32, device=dev)
+        self.cross32, self.cross16 = torch.empty(M, h, dtype=F32, device=dev), torch.empty(M, h, dtype=BF16, device=dev)
+        self.g1 = torch.empty(M, h // 4, dtype=BF16, device=dev)
+        self.spans = None
+        if training:
+            # per-layer alignment loss (:459-488): transcription spans when the batch carries any, else the whole sequence
+            if spans is not None and len(spans) > 0:
+                ok = [(r, s0, s1) for r, s0, s1 in spans if s0 < s1 and s1 <= S]
+                self.spans = torch.tensor(ok, dtype=torch.int32, device=dev).reshape(-1, 3) if ok else False
+            else:
+                self.spans = torch.tensor([(b, 0, S) for b in range(B)], dtype=torch.int32, device=dev)
+
+    def inject(self, l: int, x: torch.Tensor) -> None:
+        """x [B*S, h] bf16 = output of decoder layer l (batch-major rows), updated IN PLACE: x + sigmoid(gate(x)) * LN(cross_attn(x, audio))."""
+        if self.audio is None:
+            return
+        con, h, M, B, S, Ta = self.con, self.h, self.M, self.Bq, self.S, self.Ta
+        p = f"orca_cross_attns.{l}."
+        w_in, b_in = con.W16(p + "cross_attn.in_proj_weight"), con.P32(p + "cross_attn.in_proj_bias")
+        if self.spans is not None and self.spans is not False:
+            n = min(B, self.spans.shape[0])                                      # "audio_pooled may have different batch size, align by taking first N"
+            out = torch.empty(n, dtype=F32, device=self.dev)
+            H.orca_align(self.audio, Ta, x, h, S * h, h, self.spans, n, out)
+            self.aligns.append(out)
+        H.gemm(x, w_in[:h], self.q16, M, h, h, bias=b_in[:h])
+        H.gemm(self.audio, w_in[h:], self.kv16, B * Ta, 2 * h, h, bias=b_in[h:])
+        ad = H.attn_desc(self.q16, self.kv16, self.kv16, self.att16, self.lse, batch=B, hq=self.heads, hkv=self.heads, sq=S, sk=Ta, hd=self.hd,
+                         scale=self.hd ** -0.5, q_off=0, k_off=0, v_off=h)
+        H.attention_fwd(ad)
+        H.gemm(self.att16, con.W16(p + "cross_attn.out_proj.weight"), self.cross32, M, h, h, bias=con.P32(p + "cross_attn.out_proj.bias"))
+        H.layernorm_fwd(self.cross32, con.P32(p + "ln.weight"), con.P32(p + "ln.bias"), 1e-5, y16=self.cross16)
+        H.gemm(x, con.W16(p + "gate_proj.0.weight"), self.g1, M, h // 4, h, bias=con.P32(p + "gate_proj.0.bias"), act=1)
+        H.orca_gate_residual(x, h, self.cross16, self.g1, con.P32(p + "gate_proj.2.weight"), con.P32(p + "gate_proj.2.bias"), M, h, h // 4)
+
+    def losses(self, global16: torch.Tensor, local16: Optional[torch.Tensor], B: int) -> "OrderedDict[str, torch.Tensor]":
+        """`compute_orca_losses` (:1159-1206): 0-d fp32 device tensors, weighted like the reference's."""
+        cfg, h, dev = self.cfg, self.h, self.dev
+        Kg = cfg.orca_global_num_tokens
+        out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+        part = torch.empty(B * Kg, dtype=F32, device=dev)
+        H.orca_sim_loss(global16, global16, None, B, Kg, Kg, Kg, h, True, part)
+        out["L_ortho_diversity"] = cfg.orca_ortho_diversity_weight * part.sum() / (B * Kg * Kg)
+        if local16 is not None:
+            Tl = local16.shape[0] // B
+            idx, ny = None, Tl
+            if Tl > 100:                                                          # uniform sample of 100 local tokens (:1190-1194)
+                idx = torch.linspace(0, Tl - 1, 100, dtype=torch.long).to(dev, torch.int32)
+                ny = 100
+            part2 = torch.empty(B * Kg, dtype=F32, device=dev)
+            H.orca_sim_loss(global16, local16, idx, B, Kg, ny, Tl, h, False, part2)
+            out["L_ortho_qformer_local"] = cfg.orca_ortho_weight_qformer_local * part2.sum() / (B * Kg * ny)
+        if self.aligns:
+            out["L_align_layerwise"] = cfg.orca_align_weight_local * torch.stack([a.mean() for a in self.aligns]).mean()
+        return out
 
 
 # =========================================================================================== causal LM
@@ -898,7 +1089,7 @@ class CausalLMHIP:
 
     def forward(self, x0_filler, B: int, S: int, kv_start: Optional[torch.Tensor], labels: Optional[torch.Tensor], need_grad: bool,
                 pos_shift: Optional[torch.Tensor] = None, cos_sin: Optional[torch.Tensor] = None, last_logits: Optional[torch.Tensor] = None,
-                kv_cache: Optional[List[torch.Tensor]] = None, target_rows=None, s_major: bool = False):
+                kv_cache: Optional[List[torch.Tensor]] = None, target_rows=None, s_major: bool = False, layer_hook=None):
         """`x0_filler(buf)` writes inputs_embeds [B*S, h] bf16 into buf.  Returns the logits buffer [B*S, Vp].
         Training uses position_ids = arange(S) (H7); generate() passes pos_shift (= -left_pad per sequence, with a
         `cos_sin` table that also covers the new tokens), `last_logits` [B, Vp] to project only the last row, and the
@@ -973,6 +1164,8 @@ class CausalLMHIP:
                     H.gemm(self.hb[t0:], ly["wgu"], s["gu"][t0:], Mt, 2 * self.I, h)
                     H.swiglu_fwd(s["gu"][t0:], self.act[t0:], Mt, self.I)
                 H.gemm(self.act[t0:], ly["wd"], self.xs[i + 1][t0:], Mt, h, self.I, residual=s["xm"][t0:])
+            if layer_hook is not None:                                        # ORCA deep injection: the wrapped decoder layer's output (batch-major grid)
+                layer_hook(i, self.xs[i + 1])
         t0 = self.tail0
         if M - t0 > 0:
             H.rmsnorm_fwd(self.xs[self.L][t0:], self.norm, c.rms_norm_eps, self.hb[t0:], self.rf[t0:])
@@ -1205,6 +1398,9 @@ class DeSTA25AudioModel:
             self.connector = QformerConnectorHIP(config, self.arena, self.device)
             if config.use_lora:
                 self.llm.attach_lora(self.arena, config.lora_r, config.lora_alpha, config.lora_dropout)
+            self.orca = OrcaHIP(config, self.connector, self.device) if config.connector_mode == "orca_hybrid" else None
+        # tokens one audio occupies in the text stream in front of its transcription (modeling_desta25.py:535, 540, 1570-1574)
+        self.audio_tokens = config.orca_global_num_tokens if self.orca is not None else config.prompt_size
         self._init_connector(weights)
         e = config.encoder_config
         self.enc_all = None
@@ -1247,16 +1443,24 @@ class DeSTA25AudioModel:
                 continue
             if ".lora_B." in name:
                 v = torch.zeros(*shape)                                # peft: B = 0, A = kaiming_uniform(a = sqrt 5) = U(+-1/sqrt(fan_in)), the `.weight` rule below
-            elif "layer_prompts" in name:
+            elif "layer_prompts" in name or "global_queries" in name:
                 v = torch.randn(*shape, generator=g)
             elif name.endswith("layer_weights"):
                 v = torch.zeros(*shape)
-            elif "LayerNorm" in name or ".proj.0." in name:
+            elif "LayerNorm" in name or "proj.0." in name.replace("gate_proj", "") or ".local_ln." in name or ".ln." in name:
                 v = torch.ones(*shape) if name.endswith("weight") else torch.zeros(*shape)
+            elif name.endswith("gate_proj.2.weight"):                   # ORCAGatedCrossAttention.__init__ (:382-383): gate starts at sigmoid(gate_init)
+                v = torch.zeros(*shape)
+            elif name.endswith("gate_proj.2.bias"):
+                v = torch.full(shape, self.config.orca_gate_init)
+            elif name.endswith("in_proj_weight"):                       # nn.MultiheadAttention: xavier_uniform_, zero biases
+                v = (torch.rand(*shape, generator=g) * 2 - 1) * math.sqrt(6.0 / (shape[0] + shape[1]))
+            elif name.endswith("in_proj_bias") or name.endswith("cross_attn.out_proj.bias"):
+                v = torch.zeros(*shape)
             elif name.endswith(".weight"):
-                v = (torch.rand(*shape, generator=g) * 2 - 1) / math.sqrt(shape[1])
+                v = (torch.rand(*shape, generator=g) * 2 - 1) / math.sqrt(int(math.prod(shape[1:])))
             else:
-                fan_in = self.arena.shapes[name[:-4] + "weight"][1]
+                fan_in = int(math.prod(self.arena.shapes[name[:-4] + "weight"][1:]))
                 v = (torch.rand(*shape, generator=g) * 2 - 1) / math.sqrt(fan_in)
             self.arena.param(name).copy_(v.to(self.device))
 
@@ -1312,6 +1516,8 @@ class DeSTA25AudioModel:
         """bf16 operand copies of every trainable tensor from the fp32 arena, on the current stream (the trainer calls this right
         behind the optimizer step; a forward does it itself when `mark_weights_updated` / `load_state_dict` flagged a change)."""
         self.connector.refresh_weights()
+        if self.orca is not None:
+            self.orca.refresh_weights()
         if self.llm.lora is not None:
             self.llm.lora["dirty"] = True
             self.llm.refresh_lora()
@@ -1321,7 +1527,7 @@ class DeSTA25AudioModel:
         """Flat row indices of the audio slots of inputs_embeds ([N_audio * K] int64, device) and the source-map values that
         mark them (-(audio_row + 1), int32), cached per (starts, B, S, layout) signature: batches of one run share a handful of
         signatures, so neither forward nor backward rebuilds and re-uploads index tensors every step."""
-        K = self.config.prompt_size
+        K = self.audio_tokens
         key = (tuple(starts), B, S, bool(s_major))
         hit = self._slot_cache.get(key)
         if hit is None:
@@ -1336,7 +1542,7 @@ class DeSTA25AudioModel:
     def _src_rows(self, input_ids, batch_transcription_ids, batch_start_positions, audio_lengths):
         """int32 map [B*S]: >=0 token row of the embedding table, <0 -(audio_row+1)."""
         B, S = input_ids.shape
-        K = self.config.prompt_size
+        K = self.audio_tokens
         src = input_ids.to(torch.int32).clone()
         starts = [(int(r), int(s)) for r, s in batch_start_positions]
         for a, (row, start) in enumerate(starts):
@@ -1380,6 +1586,8 @@ class DeSTA25AudioModel:
                 src = input_ids.to(torch.int32).reshape(-1).contiguous()
             kv_start = (attention_mask == 0).sum(dim=1).to(torch.int32).contiguous()
             h = cfg.llm_config.hidden_size
+            if self.orca is not None:
+                return self._forward_orca(input_ids, attention_mask, batch_transcription_ids, batch_start_positions, labels, af, src, kv_start, N_audio)
 
             def fill(buf):
                 H.embed_gather(self.llm.embed, af, src, B * S, h, buf)
@@ -1411,6 +1619,43 @@ class DeSTA25AudioModel:
                              has_grad=labels is not None and self.training and (N_audio > 0 or self.llm.lora is not None), s_major=s_major)
         return _Out(loss, out_logits)
 
+    def _forward_orca(self, input_ids, attention_mask, batch_transcription_ids, batch_start_positions, labels, af, src, kv_start, N_audio):
+        """The ORCA branch of the reference's forward (modeling_desta25.py:775-841), FORWARD ONLY: global tokens spliced at the audio
+        positions, the local tokens injected behind every decoder layer through the gated cross-attention, LM loss + `orca_losses`
+        (the trainer adds them up, desta_trainer.py:56-92).  Batch-major token grid, logits kept.  One audio per text row, in row
+        order: the reference's cross-attention pairs audio row b with text row b (`query=hidden_states, key=audio_local`, :447-453)."""
+        cfg, dev, orca = self.config, self.device, self.orca
+        B, S = input_ids.shape
+        hdim, V = cfg.llm_config.hidden_size, cfg.llm_config.vocab_size
+        local16, spans = None, None
+        if N_audio > 0:
+            rows = [int(r) for r, _ in batch_start_positions]
+            assert N_audio == B and rows == list(range(B)), "orca_hybrid: one audio per text row, in row order"
+            if self.connector.p_drop > 0.0:
+                raise NotImplementedError("orca_hybrid: Q-Former dropout in the global branch needs the backward, which is not built (forward-only slice)")
+            local16 = orca.local_forward(self.enc_all, N_audio)
+            Kg = cfg.orca_global_num_tokens
+            spans = [(int(r), int(s) + Kg, int(s) + Kg + int(t.numel())) for (r, s), t in zip(batch_start_positions, batch_transcription_ids)]
+            orca.begin(af, local16, B, S, spans, self.training)
+            hook = orca.inject
+        else:
+            orca.audio, orca.aligns = None, []
+            hook = None
+
+        def fill(buf):
+            H.embed_gather(self.llm.embed, af, src, B * S, hdim, buf)
+        logits = self.llm.forward(fill, B, S, kv_start, labels, False, layer_hook=hook)
+        out_logits = logits.view(B, S, self.llm.Vp)[:, :, :V]
+        loss = None
+        if labels is not None:
+            loss = self.llm.loss_and_grad(labels.to(dev).contiguous(), write_grad=False).clone().view(())
+        out = _Out(loss, out_logits)
+        out.orca_losses = orca.losses(af, local16, B) if N_audio > 0 else OrderedDict()
+        out.audio_global = af.view(B, cfg.orca_global_num_tokens, hdim) if N_audio > 0 else None
+        out.audio_local = local16.view(B, -1, hdim) if local16 is not None else None
+        self._fwd = dict(orca=True, has_grad=False)
+        return out
+
     __call__ = forward
 
     @torch.no_grad()
@@ -1422,6 +1667,9 @@ class DeSTA25AudioModel:
         ignored, as the reference nulls them).  do_sample=True: temperature -> top-p -> one multinomial draw per step
         with the library's counter RNG (`seed`; same distribution as HF, not torch's random stream)."""
         cfg, dev = self.config, self.device
+        if self.orca is not None and cfg.orca_deep_injection_enabled:
+            raise NotImplementedError("orca_hybrid: generation with deep injection (the gated cross-attention inside the KV-cached decode, "
+                                      "modeling_desta25.py:1375-1408) is not built yet — forward-only first slice")
         input_ids = inputs["context_input_ids"].to(dev)                      # only the context (prompt) part of the batch
         attention_mask = inputs["context_attention_mask"].to(dev)
         B, S = input_ids.shape
@@ -1669,6 +1917,9 @@ class DeSTA25AudioModel:
     def backward_llm(self) -> torch.Tensor:
         """First half of `backward`: dX through the frozen LLM down to the audio rows; returns dL/d audio_features [N_audio*K, h]."""
         f = self._fwd
+        if f and f.get("orca"):
+            raise NotImplementedError("orca_hybrid: the backward (connector local branch, gated cross-attention of every decoder layer, "
+                                      "auxiliary losses) is not built yet — forward-only first slice, SURVEY.md §8f-4b")
         if not f or not f["has_grad"]:
             raise RuntimeError("backward() needs a training-mode forward with labels and at least one audio")
         K, S, B = self.config.prompt_size, f["S"], f["B"]

@@ -65,7 +65,8 @@ def decay_mask(names: Sequence[str]) -> List[bool]:
     `proj.0`; `layer_prompts` and `layer_weights` ARE decayed."""
     out = []
     for n in names:
-        nd = ("bias" in n) or ("LayerNorm" in n) or (".proj.0." in n) or ("layernorm" in n.lower()) or ("_norm" in n)
+        nd = (("bias" in n) or ("LayerNorm" in n) or (".proj.0." in n) or ("layernorm" in n.lower()) or ("_norm" in n)
+              or (".global_proj.0." in n) or (".local_ln." in n) or n.endswith(".ln.weight"))          # ORCA: nn.LayerNorm modules under other names
         out.append(not nd)
     return out
 

@@ -263,6 +263,28 @@ int desta_tap_mix_bwd(const float* x, const float* layer_weights, const float* d
                       int prompt, int d, float* dx, float* dlayer_weights, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * ORCA hybrid connector / deep injection, FORWARD ONLY (ABI 6; SURVEY §8f-4b, first slice).  The ORCA branch shares the GEMM,
+ * attention and LayerNorm entry points with the qformer_1 path; these are the row-wise pieces it adds
+ * (/root/reference/desta/models/modeling_desta25.py, line numbers per entry).  All bf16 streams, fp32 arithmetic.
+ *   desta_orca_local_mix      :336-343  out[r,:] = sum_l softmax(layer_weights)[l] x[l,r,:]; x [taps][rows][d], taps <= 8
+ *   desta_orca_rope           :22-95, :422-438  rotation of the WHOLE hidden vector (pairs i, i + hidden/2) by the angle
+ *                             (t / position_scale) theta^(-i / (hidden/2)); round_cos_sin: cos / sin rounded to bf16 first (bf16 model)
+ *   desta_orca_gate_residual  :456-490  hidden[m,:] += sigmoid(gate_hidden[m,:] . gate_w2 + gate_b2[0]) * cross[m,:], in place;
+ *                             gate_hidden = GELU(Linear(hidden)) [rows, gate_width] from a GEMM; gate_out (fp32 [rows]) optional
+ *   desta_orca_sim_loss       :1174-1198  partials[b * nx + i] = sum_j (xhat_i . yhat_j - [subtract_identity and i == j])^2 over
+ *                             L2-normalised rows; y rows picked through y_index[ny] (NULL: 0..ny-1) out of y_rows per batch entry
+ *   desta_orca_align          :460-486  out[e] = 1 - cos(mean_t audio[e,t,:], mean_{s0 <= s < s1} hidden[row, s, :]),
+ *                             spans[e] = (text row, s0, s1); hidden addressed as row * batch_stride + s * row_stride */
+int desta_orca_local_mix(const void* x, const float* layer_weights, int taps, int64_t rows, int d, void* out, void* stream);
+int desta_orca_rope(const void* x, void* y, int batch, int tokens, int hidden, float theta, float position_scale, int round_cos_sin, void* stream);
+int desta_orca_gate_residual(void* hidden, int64_t ld_hidden, const void* cross, const void* gate_hidden, const float* gate_w2, const float* gate_b2,
+                             int64_t rows, int hidden_size, int gate_width, float* gate_out, void* stream);
+int desta_orca_sim_loss(const void* x, const void* y, const int32_t* y_index, int batch, int nx, int ny, int64_t y_rows, int hidden,
+                        int subtract_identity, float* partials, void* stream);
+int desta_orca_align(const void* audio, int tokens, const void* hidden, int64_t hidden_row_stride, int64_t hidden_batch_stride, int hidden_size,
+                     const int32_t* spans, int n_spans, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Flash-style attention, forward and backward (bf16 operands, fp32 softmax, MFMA 32x32x16).
  * Element (b, s, h, d) of a tensor X lives at X + b*x_batch_stride + s*x_row_stride + h*head_dim + d,
  * so q/k/v may be slices of one fused projection buffer.  GQA: kv head = q head / (n_q/n_kv).

@@ -1,0 +1,127 @@
+"""GPU: ORCA hybrid, first slice — the product's FORWARD for `connector_mode="orca_hybrid"` against the golden made by
+the reference's own ORCAHybridConnector / ORCAGatedCrossAttention / compute_orca_losses / forward (tests/golden/ref_orca_tiny.safetensors,
+tests/golden/make_golden_from_reference.py::make_orca_case; the CPU oracle restatement is pinned to the same file in
+tests/test_oracle_pin.py).  Tolerances: the product computes in bf16 with fp32 accumulation / statistics like the reference under
+autocast, the golden is fp32 — the bounds of the qformer_1 tiny goldens (tests/test_gpu_model.py)."""
+import copy
+import os
+
+import pytest
+import torch
+from safetensors.torch import load_file
+
+import desta_oracle as O
+import orca_oracle as R
+from helpers import cfg_from_dims, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(golden_dir):
+    g = load_file(os.path.join(golden_dir, "ref_orca_tiny.safetensors"))
+    kg, ds, ks, ntr = (int(x) for x in g["orca_dims"])
+    d = O.tiny_dims(False)
+    o = R.OrcaDims(global_num_tokens=kg, local_downsample=ds, local_kernel_size=ks, ortho_diversity_weight=0.05,
+                   ortho_weight_qformer_local=0.05, align_weight_local=0.05)
+    w = R.init_weights(d, o, seed=7)
+    d = copy.copy(d)
+    d.prompt_size = kg + ntr
+    n = g["starts"].shape[0]
+    batch = {"input_ids": g["input_ids"], "attention_mask": g["attention_mask"], "labels": g["labels"], "batch_features": g["batch_features"],
+             "batch_start_positions": [(int(b), int(s)) for b, s in g["starts"].tolist()],
+             "batch_transcription_ids": [g["transcription_ids"][i:i + 1] for i in range(n)]}
+    cfg = cfg_from_dims(d, connector_mode="orca_hybrid", orca_enabled=True, orca_global_num_tokens=kg, orca_local_downsample=ds,
+                        orca_local_kernel_size=ks, orca_ortho_diversity_weight=0.05, orca_ortho_weight_qformer_local=0.05,
+                        orca_align_weight_local=0.05, orca_rope_theta=float(g["rope_theta_used"]))
+    return g, d, o, w, batch, cfg
+
+
+def test_orca_forward_vs_reference_golden(golden_dir):
+    from desta.models.modeling_desta25 import DeSTA25AudioModel, DeSTA25Config
+    g, d, o, w, batch, cfg = _case(golden_dir)
+    model = DeSTA25AudioModel(cfg, weights=w)
+    assert sorted(model.trainable_parameter_names) == sorted(R.trainable_names(d, o))       # the reference's state-dict keys
+    for n in R.trainable_names(d, o):
+        assert torch.equal(model.arena.param(n).cpu(), w[n].reshape(model.arena.shapes[n])), n
+    model.train()
+    out = model(**batch)
+    m = g["attention_mask"].bool()
+    rec = dict(dloss=abs(float(out.loss) - float(g["loss"])), logits=rel_err(out.logits.float().cpu()[m], g["logits"][m]),
+               global_tokens=rel_err(out.audio_global.float().cpu(), g["global_tokens"]), local_tokens=rel_err(out.audio_local.float().cpu(), g["local_tokens"]),
+               hidden_1=rel_err(model.llm.xs[1].float().cpu().view(g["hidden_1"].shape)[m], g["hidden_1"][m]))            # output of decoder layer 0 INCLUDING its injection
+    losses = {k: float(v) for k, v in out.orca_losses.items()}
+    ref = {k[len("orca_loss::"):]: float(v) for k, v in g.items() if k.startswith("orca_loss::")}
+    print("orca forward:", {k: (round(v, 6) if isinstance(v, float) else v) for k, v in rec.items()}, losses, ref)
+    assert sorted(losses) == sorted(ref)
+    assert rec["global_tokens"] < 1e-2 and rec["local_tokens"] < 1e-2, rec
+    assert rec["hidden_1"] < 1.5e-2 and rec["logits"] < 2e-2 and rec["dloss"] < 3e-3, rec
+    for k in ref:
+        assert abs(losses[k] - ref[k]) < 2e-2 * abs(ref[k]) + 2e-6, (k, losses[k], ref[k])
+    total = float(out.loss) + sum(losses.values())                                           # what the trainer optimises (desta_trainer.py:56-92)
+    assert abs(total - (float(g["loss"]) + sum(ref.values()))) < 4e-3
+    # eval mode: no alignment loss (modeling_desta25.py:487-488), the other two stay; logits of the eval forward
+    model.eval()
+    out_e = model(**batch)
+    assert "L_align_layerwise" not in out_e.orca_losses and "L_ortho_diversity" in out_e.orca_losses
+    assert rel_err(out_e.logits.float().cpu()[m], g["logits_eval"][m]) < 2e-2
+    # forward-only slice: the backward and generation with deep injection say so
+    model.train()
+    model(**batch)
+    with pytest.raises(NotImplementedError, match="backward"):
+        model.backward()
+    # config round trip keeps the mode and every orca_* field
+    c2 = DeSTA25Config(**{k: v for k, v in cfg.to_dict().items() if k not in ("model_type", "info")})
+    assert c2.connector_mode == "orca_hybrid" and c2.orca_global_num_tokens == cfg.orca_global_num_tokens and c2.orca_enabled
+    with pytest.raises(NotImplementedError):
+        DeSTA25Config(**{**{k: v for k, v in cfg.to_dict().items() if k not in ("model_type", "info")}, "connector_mode": "something_else"})
+
+
+def test_orca_kernels_vs_oracle(golden_dir):
+    """The row-wise `desta_orca_*` entry points one by one against the oracle's restatement on random inputs."""
+    from desta import _hip as H
+    gen = torch.Generator().manual_seed(3)
+    B, T, Hd = 3, 10, 256
+    x = torch.randn(B, T, Hd, generator=gen).to(torch.bfloat16)
+    y = torch.empty(B * T, Hd, dtype=torch.bfloat16, device="cuda")
+    H.orca_rope(x.cuda(), y, B, T, Hd, 10000.0, 2.5, round_cos_sin=False)
+    assert rel_err(y.float().cpu().view(B, T, Hd), R.rope_whole_vector(x.float(), 10000.0, 2.5)) < 6e-3
+    # local mix
+    taps, rows, dd = 4, 50, 128
+    e = torch.randn(taps, rows, dd, generator=gen).to(torch.bfloat16)
+    lw = torch.randn(taps, generator=gen)
+    out = torch.empty(rows, dd, dtype=torch.bfloat16, device="cuda")
+    H.orca_local_mix(e.cuda(), lw.cuda(), taps, rows, dd, out)
+    ref = (e.float() * torch.softmax(lw, 0).view(-1, 1, 1)).sum(0)
+    assert rel_err(out.float().cpu(), ref) < 4e-3
+    # similarity losses
+    gt = torch.randn(B, 8, Hd, generator=gen).to(torch.bfloat16)
+    lt = torch.randn(B, 130, Hd, generator=gen).to(torch.bfloat16)
+    od = R.OrcaDims(ortho_diversity_weight=1.0, ortho_weight_qformer_local=1.0)
+    want = R.orca_losses(od, gt.float(), lt.float(), [])
+    part = torch.empty(B * 8, device="cuda")
+    H.orca_sim_loss(gt.cuda(), gt.cuda(), None, B, 8, 8, 8, Hd, True, part)
+    assert abs(float(part.sum()) / (B * 64) - float(want["L_ortho_diversity"])) < 1e-5 + 1e-4 * float(want["L_ortho_diversity"])
+    idx = torch.linspace(0, 129, 100, dtype=torch.long).to("cuda", torch.int32)
+    H.orca_sim_loss(gt.cuda(), lt.cuda(), idx, B, 8, 100, 130, Hd, False, part)
+    assert abs(float(part.sum()) / (B * 800) - float(want["L_ortho_qformer_local"])) < 1e-6 + 1e-4 * float(want["L_ortho_qformer_local"])
+    # gate + residual
+    M = 37
+    hs = torch.randn(M, Hd, generator=gen).to(torch.bfloat16)
+    cr = torch.randn(M, Hd, generator=gen).to(torch.bfloat16)
+    g1 = torch.randn(M, Hd // 4, generator=gen).to(torch.bfloat16)
+    w2, b2 = torch.randn(Hd // 4, generator=gen) / 8, torch.tensor([0.1])
+    hsd = hs.clone().cuda()
+    gate = torch.empty(M, device="cuda")
+    H.orca_gate_residual(hsd, Hd, cr.cuda(), g1.cuda(), w2.cuda(), b2.cuda(), M, Hd, Hd // 4, gate_out=gate)
+    gref = torch.sigmoid(g1.float() @ w2 + b2)
+    assert rel_err(gate.cpu(), gref) < 1e-5
+    assert rel_err(hsd.float().cpu(), hs.float() + gref[:, None] * cr.float()) < 6e-3
+    # alignment
+    a = torch.randn(B, T, Hd, generator=gen).to(torch.bfloat16)
+    S = 12
+    hid = torch.randn(B, S, Hd, generator=gen).to(torch.bfloat16)
+    spans = torch.tensor([[0, 2, 7], [1, 0, 12], [2, 11, 12]], dtype=torch.int32)
+    outa = torch.empty(3, device="cuda")
+    H.orca_align(a.cuda(), T, hid.cuda(), Hd, S * Hd, Hd, spans.cuda(), 3, outa)
+    ra = torch.stack([1 - torch.nn.functional.cosine_similarity(a[i].float().mean(0), hid[r, s0:s1].float().mean(0), dim=0) for i, (r, s0, s1) in enumerate(spans.tolist())])
+    assert float((outa.cpu() - ra).abs().max()) < 1e-4
