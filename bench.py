@@ -282,6 +282,12 @@ def main():
     ap.add_argument("--no-dead-row-skip", action="store_true", help="A/B: the last decoder layer's o_proj / MLP (forward and backward) on every row instead of the target tail, layer 0's input gradient on every row instead of the audio rows")
     ap.add_argument("--attn-q64-two-kernels", action="store_true", help="A/B: the Q-Former's cross-attention backward on the separate dQ and dK/dV kernels instead of the one-pass kernel")
     ap.add_argument("--no-kv-side", action="store_true", help="A/B: the Q-Former's K | V projections inside the layer loop on the main stream instead of up front on a second stream")
+    ap.add_argument("--data", choices=["synthetic", "wav"], default="synthetic",
+                    help="wav: the REAL data path inside the timed region — B x 30-s RIFF/WAVE files (written under --wav-dir at start: half 16 kHz mono, "
+                         "half 22.05 kHz stereo) -> BaseAudioTextDataset -> DataLoader workers (decode, resample, tokenise) -> H2D -> device log-mel; "
+                         "NOT the headline line (BASELINE.json's metric is on synthetic inputs resident in HBM): printed beside it for VERDICT r3 item 8")
+    ap.add_argument("--workers", type=int, default=4, help="--data wav: DataLoader worker processes (dataset.train_ds.num_workers); 0 = collate inline")
+    ap.add_argument("--wav-dir", default="/tmp/desta_bench_wav")
     ap.add_argument("--gelu-poly", action="store_true", help="A/B: bf16-output GELU epilogues on the packed degree-12 polynomial instead of the A&S 7.1.26 form (measured equal)")
     ap.add_argument("--no-swiglu-fusion", action="store_true", help="A/B: silu(gate) * up and its backward as their own HBM passes instead of inside the gate|up / d(act) GEMM epilogues")
     ap.add_argument("--full-lm-head", action="store_true", help="A/B: lm_head / CE over the whole token grid, not only the target rows")
@@ -384,6 +390,45 @@ def main():
         b = dict(toks[i % 2])
         b["batch_features"] = H.logmel(waves[i % 2], n_mels)              # A1 runs inside the step
         return b
+
+    data_note = None
+    if a.data == "wav":
+        # the real data path: manifest records -> BaseAudioTextDataset -> per-epoch index batches -> DataLoader worker
+        # processes running BaseCollateFn.host_collate -> BaseCollateFn.finish (H2D + device log-mel) in this process
+        from desta.synthetic import WordTokenizer, write_synthetic_wav_dataset
+        from desta.trainer.data.simple_dataset import BaseAudioTextDataset
+        from desta.utils.audio import HipLogMelProcessor
+        n_files = 4 * B
+        recs = write_synthetic_wav_dataset(os.path.join(a.wav_dir, f"rank{rank}"), n_files, seed=1234 + rank)
+        tokz = WordTokenizer(cfg.llm_config.vocab_size)
+        tokz.pad_token, tokz.pad_token_id = tokz.eos_token, tokz.eos_token_id
+        dcfg = {"model": {"audio_locator": cfg.audio_locator, "placeholder_token": "<|video_pad|>", "connector": {"prompt_size": cfg.prompt_size, "mode": "qformer_1"}}}
+        # prompts / responses sized so that a sample is a.ctx context tokens + prompt_size audio tokens + a.tgt target tokens, like the synthetic batch
+        probe = BaseAudioTextDataset(dcfg, {"data_root": os.path.join(a.wav_dir, f"rank{rank}"), "max_seq_length": S}, tokz, None, records=recs[:1])
+        n_ctx0 = len(tokz.tokenize(probe[0]["audio_context"])) - cfg.prompt_size
+        for r_ in recs:
+            r_["prompt"] = r_["prompt"] + "".join(f" w{j}" for j in range(max(0, a.ctx - n_ctx0)))
+            r_["response"] = " ".join(f"t{j % 97}" for j in range(a.tgt))
+        wav_ds = BaseAudioTextDataset(dcfg, {"data_root": os.path.join(a.wav_dir, f"rank{rank}"), "max_seq_length": S}, tokz,
+                                      HipLogMelProcessor(n_mels, dev), records=recs)
+        trainer.train_dataset, trainer.data_collator = wav_ds, wav_ds.collate_fn
+        trainer.args.per_device_train_batch_size, trainer.args.dataloader_num_workers = B, a.workers
+        wav_iter = {"it": None, "epoch": 0}
+
+        def batch(i):                                                     # noqa: F811 — the next collated batch of the (cycled) epoch stream
+            while True:
+                if wav_iter["it"] is None:
+                    wav_iter["it"] = iter(trainer._epoch_batches(wav_iter["epoch"]))
+                    wav_iter["epoch"] += 1
+                b = next(wav_iter["it"], None)
+                if b is not None:
+                    return b
+                wav_iter["it"] = None
+        b0 = batch(0)
+        data_note = (f"{n_files} RIFF/WAVE clips of 30 s per rank (half 16 kHz mono, half 22.05 kHz stereo PCM16) -> BaseAudioTextDataset -> "
+                     f"DataLoader(num_workers={a.workers}, pin_memory, prefetch 2) running BaseCollateFn.host_collate -> finish (H2D + device log-mel); "
+                     f"batch {tuple(b0['input_ids'].shape)} tokens, features {tuple(b0['batch_features'].shape)}")
+        assert tuple(b0["input_ids"].shape) == (B, S), (b0["input_ids"].shape, (B, S))
 
     step_events = []
     carried = {}                                         # {index: batch} prefetched by the previous run()'s last step
@@ -523,7 +568,8 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
             "ms_per_step_mean_sd": [mean_ps, sd_ps], "ms_per_step_min_max": [min(per_step), max(per_step)] if per_step else None,
             "ms_per_step_each": [round(x, 2) for x in per_step],        # main-stream event deltas, in order
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic" if a.data == "synthetic" else f"synthetic WAVE files through the real data path: {data_note}",
             "config": {"workload": f"{a.config}: {os.path.basename(cfg.encoder_model_id)} + {os.path.basename(cfg.llm_model_id)}, "
                                    f"Q-Former {cfg.qformer_num_hidden_layers}L, per-GPU batch {B} x 30 s clips, "
                                    f"S={S} ({a.ctx} ctx + {cfg.prompt_size} audio + {a.tgt} target tokens), random-init weights at true shapes"

@@ -143,3 +143,93 @@ FULL_CONFIGS = {
         qformer_num_hidden_layers=6, prompt_size=64, placeholder_token="<|video_pad|>",
         llm_config=_qwen3(1024, 28, 16, 8, 3072, True), encoder_config=_ENC_LARGE_V3),
 }
+
+
+# ------------------------------------------------------------------------------------------------ real-data-path stand-ins (bench.py --data wav)
+class WordTokenizer:
+    """Deterministic word-level tokenizer with the slice of the HF tokenizer protocol that `BaseCollateFn` / `BaseAudioTextDataset`
+    touch (left padding, right truncation, `return_length`, special tokens kept whole): stands in for the LLM's tokenizer where no
+    tokenizer files exist offline (`bench.py --data wav`; the tests use the same class shape, tests/helpers.py)."""
+    padding_side = "left"
+    eos_token = "<|eos|>"
+    pad_token_id, eos_token_id = 0, 2
+    pad_token = None
+    _SPLIT = re.compile(r"<\|[^|\s]*\|>|<[a-z_]+>|[A-Za-z0-9']+|[^\sA-Za-z0-9]")
+
+    class _Enc(dict):
+        def to(self, device):
+            return self
+
+    def __init__(self, vocab_size: int = 128256):
+        self.vocab_size = vocab_size
+        self._fixed = {"<|pad|>": 0, "<|bos|>": 1, "<|eos|>": 2, "<|AUDIO|>": 3, "<|video_pad|>": 4, "<|start|>": 5, "<|end|>": 6,
+                       "<|reserved_special_token_87|>": 7}
+
+    def add_tokens(self, toks):
+        return 0
+
+    def tokenize(self, text, add_special_tokens=False, **kw):
+        return self._SPLIT.findall(text)
+
+    def convert_tokens_to_string(self, tokens):
+        return " ".join(tokens)
+
+    def convert_tokens_to_ids(self, tokens):
+        import zlib
+        one = isinstance(tokens, str)
+        ids = [self._fixed.get(t, 8 + zlib.crc32(t.encode()) % (self.vocab_size - 8)) for t in ([tokens] if one else tokens)]
+        return ids[0] if one else ids
+
+    def encode(self, text, add_special_tokens=False, return_tensors=None, **kw):
+        ids = self.convert_tokens_to_ids(self.tokenize(text))
+        return torch.tensor([ids], dtype=torch.long).reshape(1, len(ids)) if return_tensors == "pt" else ids
+
+    def __call__(self, texts, truncation=False, padding=False, max_length=None, return_tensors=None, return_length=False,
+                 add_special_tokens=False, **kw):
+        rows = [self.encode(t) for t in ([texts] if isinstance(texts, str) else texts)]
+        if truncation and max_length is not None:
+            rows = [r[:max_length] for r in rows]
+        L = max(len(r) for r in rows)
+        ids = torch.full((len(rows), L), self.pad_token_id, dtype=torch.long)
+        am = torch.zeros(len(rows), L, dtype=torch.long)
+        for i, r in enumerate(rows):
+            if r:
+                ids[i, L - len(r):] = torch.tensor(r)
+                am[i, L - len(r):] = 1
+        out = self._Enc({"input_ids": ids, "attention_mask": am})
+        if return_length:
+            out["length"] = torch.full((len(rows),), L, dtype=torch.long)
+        return out
+
+    def apply_chat_template(self, messages, tokenize=False, add_generation_prompt=True, **kw):
+        if messages and isinstance(messages[0], list):
+            return [self.apply_chat_template(m, tokenize, add_generation_prompt) for m in messages]
+        s = "".join(f"<|start|>{m['role']}\n{m['content']}<|end|>\n" for m in messages)
+        return s + ("<|start|>assistant\n" if add_generation_prompt else "")
+
+    def batch_decode(self, ids, skip_special_tokens=False):
+        return [" ".join(str(int(t)) for t in row if not (skip_special_tokens and int(t) < 8)) for row in ids]
+
+
+def write_synthetic_wav_dataset(root: str, n_files: int = 16, seed: int = 1234):
+    """`n_files` 30-s RIFF/WAVE clips of seeded noise under `root` — even files 16 kHz mono PCM16, odd files 22.05 kHz STEREO PCM16
+    (decode + channel average + polyphase resample on the host) — and the matching manifest records (id / prompt / response)."""
+    import os
+    import wave
+    import numpy as np
+    os.makedirs(root, exist_ok=True)
+    rng = np.random.default_rng(seed)
+    words = ["alpha", "bravo", "charlie", "delta", "echo", "foxtrot", "golf", "hotel", "india", "juliet", "kilo", "lima", "mike", "november"]
+    records = []
+    for i in range(n_files):
+        sr, ch = (16000, 1) if i % 2 == 0 else (22050, 2)
+        x = (0.1 * rng.standard_normal((30 * sr, ch))).clip(-1, 1)
+        path = os.path.join(root, f"clip{i:03d}.wav")
+        with wave.open(path, "wb") as w:
+            w.setnchannels(ch)
+            w.setsampwidth(2)
+            w.setframerate(sr)
+            w.writeframes((x * 32767).astype("<i2").tobytes())
+        records.append(dict(id=f"clip{i:03d}.wav", prompt=" ".join(words[(i + j) % len(words)] for j in range(8)),
+                            response=" ".join(words[(3 * i + j) % len(words)] for j in range(16))))
+    return records

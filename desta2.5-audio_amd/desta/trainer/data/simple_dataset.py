@@ -129,6 +129,14 @@ class BaseCollateFn:
                               return_length=True, add_special_tokens=False)
 
     def __call__(self, batch: List[Dict[str, Any]]) -> Dict[str, Any]:
+        """The reference's one-call collate (`simple_dataset.py:130-301`) = the host half + the device half below."""
+        return self.finish(self.host_collate(batch))
+
+    def host_collate(self, batch: List[Dict[str, Any]]) -> Dict[str, Any]:
+        """Everything of the collate that needs no device: audio decode + resample, the two tokenisations, the index arithmetic
+        and the decoded clips as a list of 1-D float32 tensors `_waves`.  This is what runs in the DataLoader WORKER processes (`dataset.train_ds.num_workers`,
+        reference: examples/train/train_desta.py:158-159 -> HF `dataloader_num_workers`); the reference's workers also run the CPU
+        log-mel there, here the log-mel is a device kernel and is applied by `finish` in the training process."""
         tok = self.tokenizer
         assert tok.padding_side == "left", f"padding_side must be left, got {tok.padding_side}"
         # 1. decode; a sample with any undecodable audio is dropped, an all-bad batch becomes the empty marker
@@ -167,12 +175,15 @@ class BaseCollateFn:
             tr_ids += [tok.encode(t, add_special_tokens=False, return_tensors="pt").long() for t in it["transcription_list"]]
             starts += [(i, s + pad[i]) for s in it["start_positions"]]
             ctx_starts += [(i, s + ctx_pad[i]) for s in it["start_positions"]]
-        feats = self.processor(features, sampling_rate=16000, return_tensors="pt").input_features
-        assert len(feats) == len(starts) == len(tr_ids), \
-            f"Length mismatch: features={len(feats)}, positions={len(starts)}, transcriptions={len(tr_ids)}"
+        import numpy as np
+        assert len(features) == len(starts) == len(tr_ids), \
+            f"Length mismatch: features={len(features)}, positions={len(starts)}, transcriptions={len(tr_ids)}"
         out = {"input_ids": ids, "attention_mask": mask, "labels": labels,
                "audio_start_answer_positions": list(answer_start.unbind(0)),
-               "batch_features": feats, "batch_transcription_ids": tr_ids, "batch_start_positions": starts,
+               # the decoded waveforms as 1-D float32 tensors (zero-copy views: tensors travel from worker processes through shared
+               # memory and can be pinned by the loader); the processor still receives them as the reference's list of clips
+               "_waves": [w if isinstance(w, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32)) for w in features],
+               "batch_transcription_ids": tr_ids, "batch_start_positions": starts,
                "context_input_ids": ctx["input_ids"], "context_attention_mask": ctx["attention_mask"],
                "context_batch_start_positions": ctx_starts, "metadata": list(batch)}
         # optional ORCA prosody side inputs are carried through untouched in shape (zero-filled where a sample has none)
@@ -185,6 +196,20 @@ class BaseCollateFn:
             out["f0_energy_local"] = torch.stack([torch.zeros(T, 2) if t is None else torch.nn.functional.pad(t, (0, 0, 0, T - t.shape[0]))
                                                   for t in loc])
         return out
+
+    def finish(self, partial: Dict[str, Any]) -> Dict[str, Any]:
+        """Device half: `processor(...)` on the padded clips (`simple_dataset.py:239-243`) -> `batch_features`."""
+        if partial.get("_empty_batch", False) or "_waves" not in partial:
+            return partial
+        out = dict(partial)
+        waves = out.pop("_waves")
+        feats = self.processor(waves, sampling_rate=16000, return_tensors="pt").input_features
+        assert len(feats) == len(out["batch_start_positions"]) == len(out["batch_transcription_ids"]), \
+            f"Length mismatch: features={len(feats)}, positions={len(out['batch_start_positions'])}, transcriptions={len(out['batch_transcription_ids'])}"
+        # key order of the reference's dict (`:248-264`): batch_features sits between the answer positions and the transcription ids
+        order = ["input_ids", "attention_mask", "labels", "audio_start_answer_positions", "batch_features"]
+        out["batch_features"] = feats
+        return {**{k: out[k] for k in order}, **{k: v for k, v in out.items() if k not in order}}
 
 
 class BaseAudioTextDataset:

@@ -49,6 +49,9 @@ class TrainingArguments:
     steps_per_epoch: Optional[int] = None          # len(train dataloader) = MICRO-batches per epoch when the dataset is not sized (synthetic streams)
     eval_strategy: str = "no"                      # "steps" (every eval_steps optimizer steps) | "epoch" | "no" (train_desta.py:147-148)
     eval_steps: Optional[int] = None
+    dataloader_num_workers: int = 0                # `dataset.train_ds.num_workers` (train_desta.py:158): worker PROCESSES running the collate's host half (decode, resample, tokenise)
+    dataloader_pin_memory: bool = True             # `dataset.train_ds.pin_memory` (train_desta.py:159): the loader pins the tensors the workers hand over
+    dataloader_prefetch_factor: int = 2            # batches in flight per worker (torch DataLoader default)
     seed: int = 42                                 # map-style datasets: the epoch's sample order is randperm(seed + epoch)
     shuffle: bool = True                           # (HF: RandomSampler unless group_by_length); False = manifest order
 
@@ -371,7 +374,30 @@ class DeSTA25Trainer:
         while len(order) < total:
             order += order[:total - len(order)]
         idx = order[self.rank:total:self.world]
-        return (self.data_collator([ds[i] for i in idx[s:s + bs]]) for s in range(0, len(idx), bs))
+        return self._collated(ds, [idx[s:s + bs] for s in range(0, len(idx), bs)])
+
+    def _collated(self, ds, index_batches: List[List[int]]):
+        """Collated batches of one epoch.  `dataloader_num_workers` > 0 and a collator with the host / device split
+        (`BaseCollateFn.host_collate` / `.finish`): a torch DataLoader whose worker processes run the host half — WAVE decode,
+        resampling, tokenisation, index arithmetic — `prefetch_factor` batches ahead, pinned by the loader's pin thread, while this
+        process only applies the device half (H2D + log-mel kernel) and enqueues the step: the reference's
+        `DataLoader(num_workers, pin_memory)` semantics (examples/train/train_desta.py:158-159, config/dataset/*.yaml).  Workers are
+        FORKED and never touch the device.  Otherwise: inline on this thread."""
+        coll, nw = self.data_collator, int(self.args.dataloader_num_workers)
+        host, finish = getattr(coll, "host_collate", None), getattr(coll, "finish", None)
+        if nw <= 0 or host is None or finish is None or not index_batches:
+            return (coll([ds[i] for i in b]) for b in index_batches)
+        from torch.utils.data import DataLoader, Dataset
+
+        class _Rows(Dataset):
+            def __len__(self_inner):
+                return len(ds)
+
+            def __getitem__(self_inner, i):
+                return ds[i]
+        dl = DataLoader(_Rows(), batch_sampler=index_batches, collate_fn=host, num_workers=nw, pin_memory=bool(self.args.dataloader_pin_memory),
+                        prefetch_factor=max(1, int(self.args.dataloader_prefetch_factor)), multiprocessing_context="fork")
+        return (finish(p) for p in dl)
 
     def _train_pass(self, it, max_steps: Optional[int]) -> List[torch.Tensor]:
         """One pass over an iterator of MICRO-batches (one epoch, or the caller's iterable).  Look-ahead and triggers follow

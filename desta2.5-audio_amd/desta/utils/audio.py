@@ -203,7 +203,12 @@ class HipLogMelProcessor:
         from .. import _hip
         if isinstance(raw_speech, (np.ndarray, torch.Tensor)) and getattr(raw_speech, "ndim", 1) == 1:
             raw_speech = [raw_speech]
-        wave = pad_or_trim(raw_speech, self.n_samples)
+        if isinstance(raw_speech, torch.Tensor) and raw_speech.ndim == 2 and raw_speech.shape[1] == self.n_samples and raw_speech.dtype == torch.float32:
+            wave = raw_speech                              # already padded / trimmed by the collate's host half (possibly in pinned memory)
+        else:
+            wave = pad_or_trim(raw_speech, self.n_samples)
         with torch.cuda.device(self.device):
-            feats = _hip.logmel(wave.pin_memory().to(self.device, non_blocking=True), self.feature_size)
+            if wave.device.type == "cpu" and not wave.is_pinned():
+                wave = wave.pin_memory()
+            feats = _hip.logmel(wave.to(self.device, non_blocking=True), self.feature_size)
         return _Features(feats)

@@ -105,7 +105,16 @@ def create_model(cfg: Cfg, device="cuda:0"):
         llm_model_id=llm.model_id, encoder_model_id=enc.model_id, connector_mode=con.mode,
         qformer_num_hidden_layers=con.num_hidden_layers, prompt_size=con.prompt_size,
         use_lora=llm.get("use_lora", False), audio_locator=cfg.model.audio_locator,
-        placeholder_token=cfg.model.placeholder_token, orca_enabled=orca.get("enabled", False),
+        placeholder_token=cfg.model.placeholder_token,
+        # model.orca.* -> orca_* with the reference's own fallbacks (reference train_desta.py:110-124; note kernel 7 / scale 5.0 here
+        # against 5 / 2.5 in DeSTA25Config's signature)
+        orca_enabled=orca.get("enabled", False), orca_local_enabled=orca.get("local_enabled", True),
+        orca_global_cross_attn=orca.get("global_cross_attn", False), orca_deep_injection_enabled=orca.get("deep_injection_enabled", True),
+        orca_audio_position_scale=orca.get("audio_position_scale", 5.0), orca_global_num_tokens=orca.get("global_num_tokens", 4),
+        orca_local_downsample=orca.get("local_downsample", 4), orca_local_kernel_size=orca.get("local_kernel_size", 7),
+        orca_gate_init=orca.get("gate_init", 0.1), orca_ortho_weight_global=orca.get("ortho_weight_global", 0.01),
+        orca_ortho_diversity_weight=orca.get("ortho_diversity_weight", 0.01),
+        orca_ortho_weight_qformer_local=orca.get("ortho_weight_qformer_local", 0.01), orca_align_weight_local=orca.get("align_weight_local", 0.05),
         llm_config=dict(llm.config) if llm.get("config") else None,
         encoder_config=dict(enc.config) if enc.get("config") else None,
         qformer_intermediate_size=con.get("intermediate_size", 3072))
@@ -130,6 +139,8 @@ def create_training_args(cfg: Cfg):
         eval_strategy="steps" if isinstance(cfg.trainer.get("val_check_interval"), int) else "epoch",      # reference :147-148
         eval_steps=cfg.trainer.get("val_check_interval") if isinstance(cfg.trainer.get("val_check_interval"), int) else None,
         per_device_eval_batch_size=cfg.dataset.validation_ds.batch_size,
+        dataloader_num_workers=int(cfg.dataset.train_ds.get("num_workers", 0) or 0),        # reference :158
+        dataloader_pin_memory=bool(cfg.dataset.train_ds.get("pin_memory", True)),           # reference :159
         overlap_comm=bool(cfg.trainer.get("overlap_comm", True)),
         overlap_encoder=bool(cfg.trainer.get("overlap_encoder", True)),
         overlap_connector_backward=bool(cfg.trainer.get("overlap_connector_backward", False)),

@@ -266,3 +266,46 @@ def test_manifest_disk_cache_two_ranks(tmp_path):
         assert p.exitcode == 0, p.exitcode
     assert res[0][1] == res[1][1] == 4 and res[0][3] == res[1][3]
     assert res[0][2] >= 1 and res[1][2] == 0
+
+
+def test_worker_process_loader_equals_inline_collate(tmp_path):
+    """`dataset.train_ds.num_workers` > 0 (reference: examples/train/train_desta.py:158-159 -> HF `dataloader_num_workers`): the
+    trainer's loader runs `BaseCollateFn.host_collate` in forked DataLoader worker processes and `finish` (the processor call) in
+    the training process — every field of every batch equals the inline collate, in the same order, incl. a batch that loses one
+    sample to a decode error and one that becomes `_empty_batch`; the processor sees the same clips as one-call collate does."""
+    import types
+    from desta.trainer.data.simple_dataset import BaseCollateFn
+    from desta.trainer.desta_trainer import DeSTA25Trainer, TrainingArguments
+    records, batches, bad = COLLATE_CASES["basic"]
+    ds = _dataset(tmp_path, records, None)
+
+    def loader(a):
+        key = os.path.basename(a)
+        if key in bad:
+            raise RuntimeError(f"cannot decode {key}")
+        return _wave_for(key)
+    index_batches = [[i for i in b if i < len(ds)] for b in batches]
+    index_batches = [b for b in index_batches if b]
+    res = {}
+    for nw in (0, 2):
+        coll = BaseCollateFn({"max_seq_length": 4096}, ToyTokenizer(), StubProcessor(), audio_loader=loader)
+        host = types.SimpleNamespace(data_collator=coll, args=TrainingArguments(dataloader_num_workers=nw, dataloader_pin_memory=False))
+        res[nw] = (list(DeSTA25Trainer._collated(host, ds, index_batches)), coll.processor.calls if hasattr(coll.processor, "calls") else [])
+    (b0, c0), (b2, c2) = res[0], res[2]
+    assert len(b0) == len(b2) == len(index_batches) and c0 == c2 and len(c0) >= 2
+    assert any(b.get("_empty_batch") for b in b0)
+    for x, y in zip(b0, b2):
+        assert list(x.keys()) == list(y.keys())
+        for k in x:
+            if torch.is_tensor(x[k]):
+                assert torch.equal(x[k], y[k]), k
+            elif k in ("batch_start_positions", "context_batch_start_positions"):
+                assert [(int(i), int(s)) for i, s in x[k]] == [(int(i), int(s)) for i, s in y[k]], k
+            elif k in ("batch_transcription_ids", "audio_start_answer_positions"):
+                assert all(torch.equal(p, q) for p, q in zip(x[k], y[k])), k
+            else:
+                assert x[k] == y[k], k
+    # key order of a finished batch = the reference's dict (simple_dataset.py:248-264)
+    full = next(b for b in b0 if not b.get("_empty_batch"))
+    assert list(full.keys())[:7] == ["input_ids", "attention_mask", "labels", "audio_start_answer_positions", "batch_features",
+                                     "batch_transcription_ids", "batch_start_positions"]

@@ -52,8 +52,12 @@ def test_full_configs_parse_and_map_to_model_config():
         assert mc.llm_config.tie_word_embeddings == ("qwen3-4B" in name or "0.6b" in name)
         args = m.create_training_args(cfg)                 # epochs-only: 5 x (256 // 8) steps from the synthetic stream
         assert args.max_steps == -1 and args.steps_per_epoch == 32 and args.save_strategy == "epoch"
+    # orca_hybrid is accepted since round 4 (forward-only first slice, tests/test_gpu_orca.py); an unknown mode raises like the reference (:627)
+    oc = DeSTA25Config(connector_mode="orca_hybrid", orca_global_num_tokens=64, llm_config=FULL_CONFIGS[name]["llm_config"],
+                       encoder_config=FULL_CONFIGS[name]["encoder_config"])
+    assert oc.orca_enabled and oc.to_dict()["orca_global_num_tokens"] == 64 and oc.to_dict()["connector_mode"] == "orca_hybrid"
     with pytest.raises(NotImplementedError):
-        DeSTA25Config(connector_mode="orca_hybrid", llm_config=FULL_CONFIGS[name]["llm_config"],
+        DeSTA25Config(connector_mode="qformer_2", llm_config=FULL_CONFIGS[name]["llm_config"],
                       encoder_config=FULL_CONFIGS[name]["encoder_config"])
     with pytest.raises(FileNotFoundError):
         DeSTA25Config(llm_model_id="/nonexistent/llm", encoder_model_id="/nonexistent/enc")

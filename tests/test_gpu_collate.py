@@ -70,3 +70,33 @@ def test_wav_files_through_collate_into_the_model(tmp_path):
     assert abs(l0 - float(loss_o)) < 3e-2 and not torch.equal(before, model.arena.params)
     ids = tr._predict_step(batch, {"max_new_tokens": 4})
     assert ids.shape == (3, 4) and len(tr.prediction_step_outputs) == 3 and "prediction" in tr.prediction_step_outputs[0]
+
+
+def test_trainer_with_dataloader_workers_equals_inline(tmp_path):
+    """`dataset.train_ds.num_workers` on the device path: 4 optimizer steps of `DeSTA25Trainer.train()` over WAVE files with the
+    collate's host half in 2 forked worker processes (+ pinned hand-over, device log-mel in the training process, encoder prefetch
+    on its own stream) end with bit-identical losses and parameters to the same run with the collate inline."""
+    from desta.models.modeling_desta25 import DeSTA25AudioModel
+    from desta.synthetic import WordTokenizer, write_synthetic_wav_dataset
+    from desta.trainer.data.simple_dataset import BaseAudioTextDataset
+    from desta.trainer.desta_trainer import DeSTA25Trainer, TrainingArguments
+    from desta.utils.audio import HipLogMelProcessor
+    d = O.tiny_dims(False)
+    d.enc_T = 1500
+    recs = write_synthetic_wav_dataset(str(tmp_path), 8, seed=5)
+    cfg = {"model": {"audio_locator": "<|AUDIO|>", "placeholder_token": "<|video_pad|>", "connector": {"prompt_size": 64, "mode": "qformer_1"}}}
+    w = O.init_weights(d, seed=7)
+    res = {}
+    for nw in (0, 2):
+        tok = WordTokenizer(vocab_size=d.vocab)
+        ds = BaseAudioTextDataset(cfg, {"data_root": str(tmp_path), "max_seq_length": 512}, tok, HipLogMelProcessor(d.n_mels), records=recs)
+        model = DeSTA25AudioModel(cfg_from_dims(d), weights=w)
+        tr = DeSTA25Trainer(model, args=TrainingArguments(learning_rate=1e-3, warmup_steps=0, max_steps=4, logging_steps=1, per_device_train_batch_size=2,
+                                                          dataloader_num_workers=nw, num_train_epochs=1),
+                            train_dataset=ds, data_collator=ds.collate_fn, processing_class=tok)
+        losses = tr.train()
+        torch.cuda.synchronize()
+        assert tr.global_step == 4
+        res[nw] = (losses, model.arena.params.clone())
+    assert res[0][0] == res[2][0], (res[0][0], res[2][0])
+    assert torch.equal(res[0][1], res[2][1])
