@@ -908,6 +908,23 @@ extern "C" int desta_dropout_mask_u8(uint64_t seed, int64_t n, float p, uint8_t*
     return DESTA_OK;
 }
 
+// logits[r, ids[i]] = -inf for every row: the SuppressTokens / SuppressTokensAtBegin logits processors of Whisper's generate
+// (TF:generation/logits_process.py SuppressTokensLogitsProcessor) in front of the argmax
+namespace {
+__global__ __launch_bounds__(256) void mask_tokens_k(bf16_t* __restrict__ x, long ld, int rows, const int* __restrict__ ids, int n, int cols) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)rows * n) return;
+    const int r = (int)(i / n), c = ids[i % n];
+    if (c >= 0 && c < cols) x[(long)r * ld + c] = (bf16_t)0xff80;      // bf16 -inf
+}
+}  // namespace
+extern "C" int desta_mask_tokens_bf16(void* logits, int64_t ld, int rows, int cols, const int32_t* ids, int n, void* stream) {
+    DESTA_CHECK_ARG(logits && ids && rows > 0 && n > 0 && cols > 0 && ld >= cols, "mask_tokens: bad argument");
+    hipLaunchKernelGGL(mask_tokens_k, dim3((unsigned)(((long)rows * n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)logits, (long)ld, rows, ids, n, cols);
+    DESTA_CHECK_LAUNCH("mask_tokens");
+    return DESTA_OK;
+}
+
 extern "C" size_t desta_argmax_workspace_bytes(int rows) { return (size_t)(rows > 0 ? rows : 0) * ARGMAX_SPLIT * sizeof(unsigned long); }
 extern "C" int desta_argmax_bf16(const void* x, int64_t ld, int rows, int cols, int64_t* out, void* workspace, void* stream) {
     DESTA_CHECK_ARG(x && out && workspace && rows > 0 && cols > 0, "argmax: bad argument");

@@ -540,6 +540,14 @@ def argmax_bf16(x, ld, rows, cols, out):
     check(_argmax(p(x), ld, rows, cols, p(out), p(ws), stream()), "desta_argmax_bf16")
 
 
+_mask_tokens = _sig("desta_mask_tokens_bf16", vp, i64, i32, i32, vp, i32, vp)
+
+
+def mask_tokens_bf16(logits, ld, rows, cols, ids):
+    """logits[:, ids] = -inf (ids int32 on the device)."""
+    check(_mask_tokens(p(logits), ld, rows, cols, p(ids), int(ids.numel()), stream()), "desta_mask_tokens_bf16")
+
+
 _rope_kv = _sig("desta_rope_kv_append", vp, i64, i32, i32, i32, i32, i32, vp, vp, vp, f32, vp, vp, i64, i64, i32, vp)
 
 

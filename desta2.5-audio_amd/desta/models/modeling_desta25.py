@@ -72,6 +72,12 @@ class EncoderConfig:
     encoder_attention_heads: int = 20
     encoder_ffn_dim: int = 5120
     max_source_positions: int = 1500
+    # Whisper DECODER (only the ASR leg of generate() uses it, modeling_desta25.py:1580-1590); defaults = whisper-large-v3
+    decoder_layers: int = 32
+    decoder_attention_heads: int = 20
+    decoder_ffn_dim: int = 5120
+    vocab_size: int = 51866
+    max_target_positions: int = 448
 
 
 @dataclass
@@ -430,6 +436,186 @@ class WhisperEncoderHIP:
             if i in taps:                                   # the Q-Former's K/V projections read the tapped state as a bf16 operand
                 H.cast_bf16(nxt, enc_all[taps.index(i)], M * d)
             cur, nxt = nxt, cur
+        self.last32 = cur                                   # output of the last layer, fp32 [B*T, d] (the ASR decoder applies encoder.layer_norm to it)
+
+
+# =========================================================================================== Whisper decoder (ASR leg of generate)
+DEC = "perception.whisper.model.decoder."
+
+
+class WhisperDecoderHIP:
+    """Greedy KV-cached Whisper decoder: the `self.perception.whisper.generate(input_features=..., attention_mask=None,
+    max_new_tokens=128)` call of the reference's chat-level `generate` (modeling_desta25.py:1580-1590), which transcribes every clip
+    that has speech and no text.  The arithmetic the reference delegates to `WhisperForConditionalGeneration` (TF:models/whisper/
+    modeling_whisper.py decoder layers :415-520, generation_whisper.py): pre-LN decoder layers with causal self-attention over a
+    cache, cross-attention over the 1500 final encoder states (encoder.layer_norm applied, which the perception taps skip, H2),
+    GELU FFN, tied output projection; init tokens [start, detected language, no-timestamps] for a multilingual checkpoint with
+    language / task unset, the `suppress_tokens` / `begin_suppress_tokens` lists, greedy until EOS or max_new_tokens.  Every GEMM runs on
+    the weight-streaming (decode) kernel, attention on the Sq = 1 flash kernel, bf16 operands with an fp32 residual stream (the
+    reference runs this call in fp32).  Returns the NEW tokens (init tokens stripped, finished rows padded with pad_token_id),
+    i.e. what the reference's plain-tensor return holds for a clip that ends with EOS inside one 30-s segment.
+    Pinned to `WhisperForConditionalGeneration.generate` on a tiny local-config model: tests/test_gpu_generate.py."""
+
+    def __init__(self, cfg: DeSTA25Config, w: Dict[str, torch.Tensor], device, gen_cfg: Optional[dict] = None):
+        e = cfg.encoder_config
+        self.e, self.dev = e, device
+        self.d, self.L, self.heads, self.ffn, self.V, self.Tmax = e.d_model, e.decoder_layers, e.decoder_attention_heads, e.decoder_ffn_dim, e.vocab_size, e.max_target_positions
+        assert self.d // self.heads == 64, "Whisper head_dim is 64"
+        self.Vp = _r64(self.V)
+        dev = device
+
+        def g(name):
+            return w[name].to(dev)
+        d = self.d
+        self.emb32 = g(DEC + "embed_tokens.weight").float().contiguous()
+        self.emb16 = torch.zeros(self.Vp, d, dtype=BF16, device=dev)
+        self.emb16[: self.V] = self.emb32.to(BF16)                                 # proj_out is tied to embed_tokens
+        self.pos32 = g(DEC + "embed_positions.weight").float().contiguous()
+        self.ln_post = (g(ENC + "layer_norm.weight").float().contiguous(), g(ENC + "layer_norm.bias").float().contiguous())
+        self.ln_f = (g(DEC + "layer_norm.weight").float().contiguous(), g(DEC + "layer_norm.bias").float().contiguous())
+        self.layers = []
+        for i in range(self.L):
+            p = f"{DEC}layers.{i}."
+            z = torch.zeros(d, dtype=F32, device=dev)
+            self.layers.append(dict(
+                ln1=(g(p + "self_attn_layer_norm.weight").float().contiguous(), g(p + "self_attn_layer_norm.bias").float().contiguous()),
+                wq=g(p + "self_attn.q_proj.weight").to(BF16).contiguous(), bq=g(p + "self_attn.q_proj.bias").float().contiguous(),
+                wkv=torch.cat([g(p + "self_attn.k_proj.weight"), g(p + "self_attn.v_proj.weight")], 0).to(BF16).contiguous(),
+                bkv=torch.cat([z, g(p + "self_attn.v_proj.bias").float()]).contiguous(),           # k_proj has no bias
+                wo=g(p + "self_attn.out_proj.weight").to(BF16).contiguous(), bo=g(p + "self_attn.out_proj.bias").float().contiguous(),
+                ln2=(g(p + "encoder_attn_layer_norm.weight").float().contiguous(), g(p + "encoder_attn_layer_norm.bias").float().contiguous()),
+                cwq=g(p + "encoder_attn.q_proj.weight").to(BF16).contiguous(), cbq=g(p + "encoder_attn.q_proj.bias").float().contiguous(),
+                cwkv=torch.cat([g(p + "encoder_attn.k_proj.weight"), g(p + "encoder_attn.v_proj.weight")], 0).to(BF16).contiguous(),
+                cbkv=torch.cat([z, g(p + "encoder_attn.v_proj.bias").float()]).contiguous(),
+                cwo=g(p + "encoder_attn.out_proj.weight").to(BF16).contiguous(), cbo=g(p + "encoder_attn.out_proj.bias").float().contiguous(),
+                ln3=(g(p + "final_layer_norm.weight").float().contiguous(), g(p + "final_layer_norm.bias").float().contiguous()),
+                w1=g(p + "fc1.weight").to(BF16).contiguous(), b1=g(p + "fc1.bias").float().contiguous(),
+                w2=g(p + "fc2.weight").to(BF16).contiguous(), b2=g(p + "fc2.bias").float().contiguous()))
+        gc = dict(gen_cfg or {})
+        self.start_id = int(gc.get("decoder_start_token_id", 50258))
+        eos = gc.get("eos_token_id", 50257)
+        self.eos_ids = [int(t) for t in (eos if isinstance(eos, (list, tuple)) else [eos])]
+        self.pad_id = int(gc.get("pad_token_id", self.eos_ids[0]))
+        self.lang_ids = sorted(int(v) for v in (gc.get("lang_to_id") or {}).values()) if gc.get("is_multilingual", False) else []
+        self.no_ts_id = gc.get("no_timestamps_token_id")
+        self.suppress = [int(t) for t in (gc.get("suppress_tokens") or [])]
+        self.begin_suppress = [int(t) for t in (gc.get("begin_suppress_tokens") or [])]
+
+        def idx(v):
+            return torch.tensor(v, dtype=torch.int32, device=dev) if v else None
+        self._sup, self._bsup = idx(self.suppress), idx(self.begin_suppress)
+        self._not_lang = idx([t for t in range(self.V) if t not in set(self.lang_ids)]) if self.lang_ids else None
+        self.B = 0
+
+    def _alloc(self, B: int, T: int, steps: int):
+        d, dev = self.d, self.dev
+
+        def b16(*s):
+            return torch.empty(*s, dtype=BF16, device=dev)
+        self.B, self.T, self.steps = B, T, steps
+        self.enc16 = b16(B * T, d)
+        self.ckv = [b16(B * T, 2 * d) for _ in range(self.L)]
+        self.cache = [b16(B, steps, 2 * d) for _ in range(self.L)]
+        self.x32 = torch.empty(B, d, dtype=F32, device=dev)
+        self.hb, self.q16, self.att = b16(B, d), b16(B, d), b16(B, d)
+        self.ff = b16(B, self.ffn)
+        self.lse = torch.empty(B, self.heads, 1, dtype=F32, device=dev)
+        self.logits = torch.zeros(B, self.Vp, dtype=BF16, device=dev)
+        self.nxt = torch.zeros(B, dtype=torch.int64, device=dev)
+
+    def _step(self, tok: torch.Tensor, t: int) -> torch.Tensor:
+        """Token ids `tok` [B] at decoder position t -> logits [B, Vp] for position t + 1."""
+        B, d, T = self.B, self.d, self.T
+        scale = 64 ** -0.5
+        self.x32.copy_(self.emb32[tok] + self.pos32[t])                            # embedding lookup + learned position (index plumbing)
+        for ly, cache, ckv in zip(self.layers, self.cache, self.ckv):
+            H.layernorm_fwd(self.x32, ly["ln1"][0], ly["ln1"][1], 1e-5, y16=self.hb)
+            H.gemm(self.hb, ly["wq"], self.q16, B, d, d, bias=ly["bq"])
+            H.gemm(self.hb, ly["wkv"], cache[:, t], B, 2 * d, d, bias=ly["bkv"], ldc=self.steps * 2 * d)       # K | V of this position straight into the cache
+            ad = H.attn_desc(self.q16, cache, cache, self.att, self.lse, batch=B, hq=self.heads, hkv=self.heads, sq=1, sk=t + 1, hd=64, scale=scale,
+                             q_off=0, k_off=0, v_off=d, q_rs=d, k_rs=2 * d, v_rs=2 * d, o_rs=d, q_bs=d, k_bs=self.steps * 2 * d, v_bs=self.steps * 2 * d, o_bs=d)
+            H.attention_fwd(ad)
+            H.gemm(self.att, ly["wo"], self.x32, B, d, d, bias=ly["bo"], residual=self.x32)
+            H.layernorm_fwd(self.x32, ly["ln2"][0], ly["ln2"][1], 1e-5, y16=self.hb)
+            H.gemm(self.hb, ly["cwq"], self.q16, B, d, d, bias=ly["cbq"])
+            ad = H.attn_desc(self.q16, ckv, ckv, self.att, self.lse, batch=B, hq=self.heads, hkv=self.heads, sq=1, sk=T, hd=64, scale=scale,
+                             q_off=0, k_off=0, v_off=d, q_rs=d, k_rs=2 * d, v_rs=2 * d, o_rs=d, q_bs=d, k_bs=T * 2 * d, v_bs=T * 2 * d, o_bs=d)
+            H.attention_fwd(ad)
+            H.gemm(self.att, ly["cwo"], self.x32, B, d, d, bias=ly["cbo"], residual=self.x32)
+            H.layernorm_fwd(self.x32, ly["ln3"][0], ly["ln3"][1], 1e-5, y16=self.hb)
+            H.gemm(self.hb, ly["w1"], self.ff, B, self.ffn, d, bias=ly["b1"], act=1)
+            H.gemm(self.ff, ly["w2"], self.x32, B, d, self.ffn, bias=ly["b2"], residual=self.x32)
+        H.layernorm_fwd(self.x32, self.ln_f[0], self.ln_f[1], 1e-5, y16=self.hb)
+        H.gemm(self.hb, self.emb16, self.logits, B, self.V, d, ldc=self.Vp)
+        return self.logits
+
+    @torch.no_grad()
+    def generate(self, encoder: "WhisperEncoderHIP", mel: torch.Tensor, max_new_tokens: int = 128, collect_logits: bool = False,
+                 forced_tokens: Optional[torch.Tensor] = None):
+        """mel [B, n_mels, 3000] -> new token ids [B, n] (int64; init tokens stripped, rows padded with pad_token_id after their EOS);
+        with collect_logits also the RAW logits of every generated position [n, B, V] and the init tokens [B, n_init].  `forced_tokens`
+        [B, n] teacher-forces the continuation (parity tests compare per-step logits on the golden's own prefix)."""
+        dev = self.dev
+        B = mel.shape[0]
+        with torch.cuda.device(dev):
+            nt = len(encoder.cfg.target_layer_ids)
+            taps = torch.empty(nt, B * encoder.T, encoder.d, dtype=BF16, device=dev)
+            encoder.forward(mel.to(dev, F32).contiguous(), taps)
+            n_init_max = 1 + (1 if self.lang_ids else 0) + (1 if self.no_ts_id is not None else 0)
+            steps = min(self.Tmax, n_init_max + int(max_new_tokens))
+            if (B, encoder.T, steps) != (self.B, getattr(self, "T", -1), getattr(self, "steps", -1)):
+                self._alloc(B, encoder.T, steps)
+            H.layernorm_fwd(encoder.last32, self.ln_post[0], self.ln_post[1], 1e-5, y16=self.enc16)
+            for ly, ckv in zip(self.layers, self.ckv):
+                H.gemm(self.enc16, ly["cwkv"], ckv, B * encoder.T, 2 * self.d, self.d, bias=ly["cbkv"])
+            tok = torch.full((B,), self.start_id, dtype=torch.int64, device=dev)
+            init = [tok.clone()]
+            logits = self._step(tok, 0)
+            t = 1
+            if self.lang_ids:
+                # language detection (generation_whisper.py `detect_language`): argmax over the language tokens at the position behind <start>
+                H.mask_tokens_bf16(logits, self.Vp, B, self.V, self._not_lang)
+                H.argmax_bf16(logits, self.Vp, B, self.V, self.nxt)
+                tok = self.nxt.clone()
+                init.append(tok.clone())
+                logits = self._step(tok, t)
+                t += 1
+            if self.no_ts_id is not None:
+                tok = torch.full((B,), int(self.no_ts_id), dtype=torch.int64, device=dev)
+                init.append(tok.clone())
+                logits = self._step(tok, t)
+                t += 1
+            n_new = min(int(max_new_tokens), self.Tmax - t, steps - t + 1)
+            out = torch.full((B, max(n_new, 1)), self.pad_id, dtype=torch.int64, device=dev)
+            finished = torch.zeros(B, dtype=torch.bool, device=dev)
+            eos = torch.tensor(self.eos_ids, dtype=torch.int64, device=dev)
+            raw = []
+            made = 0
+            for k in range(n_new):
+                if collect_logits:
+                    raw.append(logits[:, : self.V].clone())
+                if self._sup is not None:
+                    H.mask_tokens_bf16(logits, self.Vp, B, self.V, self._sup)
+                if k == 0 and self._bsup is not None:
+                    H.mask_tokens_bf16(logits, self.Vp, B, self.V, self._bsup)
+                H.argmax_bf16(logits, self.Vp, B, self.V, self.nxt)
+                pick = self.nxt if forced_tokens is None else forced_tokens[:, k].to(dev, torch.int64)
+                nxt = torch.where(finished, torch.full_like(pick, self.pad_id), pick)
+                out[:, k] = nxt
+                made = k + 1
+                finished |= (nxt.unsqueeze(1) == eos.unsqueeze(0)).any(dim=1)
+                if k + 1 == n_new or ((k & 7) == 7 and bool(finished.all())):
+                    break
+                logits = self._step(nxt, t)
+                t += 1
+            out = out[:, :made]
+            if bool(finished.all()) and made > 1:                                # trim the columns behind the last EOS
+                last = int(((out.unsqueeze(2) == eos.view(1, 1, -1)).any(dim=2).int().argmax(dim=1) + 1).max())
+                out = out[:, :last]
+                raw = raw[:last]
+        if collect_logits:
+            return out, torch.stack(raw), torch.stack(init, dim=1)
+        return out
 
 
 # =========================================================================================== Q-Former connector
@@ -1399,6 +1585,17 @@ class DeSTA25AudioModel:
             if config.use_lora:
                 self.llm.attach_lora(self.arena, config.lora_r, config.lora_alpha, config.lora_dropout)
             self.orca = OrcaHIP(config, self.connector, self.device) if config.connector_mode == "orca_hybrid" else None
+            # Whisper's own decoder, when the checkpoint carries it: generate() then transcribes speech clips that arrive without text
+            # itself (modeling_desta25.py:1580-1590) instead of asking for an injected `asr`
+            self.asr_decoder = None
+            if (DEC + "embed_tokens.weight") in weights:
+                gc = config.extra.get("whisper_generation_config")
+                if gc is None:
+                    gp = os.path.join(config.encoder_model_id, "generation_config.json")
+                    if os.path.isfile(gp):
+                        with open(gp) as f:
+                            gc = json.load(f)
+                self.asr_decoder = WhisperDecoderHIP(config, weights, self.device, gc)
         # tokens one audio occupies in the text stream in front of its transcription (modeling_desta25.py:535, 540, 1570-1574)
         self.audio_tokens = config.orca_global_num_tokens if self.orca is not None else config.prompt_size
         self._init_connector(weights)
@@ -1422,7 +1619,8 @@ class DeSTA25AudioModel:
         """Base LLM + Whisper weights from LOCAL HF directories (safetensors only; nothing is executed)."""
         from safetensors import safe_open
         out: Dict[str, torch.Tensor] = {}
-        for path, prefix, keep in ((config.llm_model_id, LLM, None), (config.encoder_model_id, "perception.whisper.", "model.encoder.")):
+        # (Whisper: the encoder for the hot path and, for the ASR leg of generate(), the decoder of the same checkpoint)
+        for path, prefix, keep in ((config.llm_model_id, LLM, None), (config.encoder_model_id, "perception.whisper.", ("model.encoder.", "model.decoder."))):
             files = sorted(f for f in os.listdir(path) if f.endswith(".safetensors")) if os.path.isdir(path) else []
             if not files:
                 raise FileNotFoundError(f"no *.safetensors under '{path}' (local HF model directory required; no hub access)")
@@ -1709,7 +1907,18 @@ class DeSTA25AudioModel:
         finally:
             self.training = was_training
 
-    def _setup_generation(self, tokenizer=None, processor=None, vad=None, asr=None):
+    def _asr_whisper(self, waves) -> List[str]:
+        """`perception.whisper.generate(input_features, attention_mask=None, max_new_tokens=128)` + `processor.batch_decode(...,
+        skip_special_tokens=True)` (modeling_desta25.py:1580-1590) on the device: log-mel -> frozen encoder -> greedy decoder."""
+        if getattr(self, "asr_tokenizer", None) is None:
+            raise RuntimeError("ASR needs the Whisper tokenizer to turn token ids into text: model._setup_generation(asr_tokenizer=...) "
+                               "(an object with batch_decode(ids, skip_special_tokens=True); no hub access to build one by name)")
+        feats = self.processor(waves, sampling_rate=16000, return_tensors="pt").input_features
+        ids = self.asr_decoder.generate(self.encoder, feats, max_new_tokens=128)
+        self._last_asr_ids = ids
+        return self.asr_tokenizer.batch_decode(ids.tolist(), skip_special_tokens=True)
+
+    def _setup_generation(self, tokenizer=None, processor=None, vad=None, asr=None, asr_tokenizer=None):
         """The reference builds these from hub names (modeling_desta25.py:1465-1487): AutoTokenizer of the LLM (+ the audio locator
         token), the Whisper AutoProcessor, silero VAD from torch.hub and Whisper's own decoder for ASR.  Offline they are
         injected: `tokenizer` any object with the HF tokenizer call protocol, `processor` defaults to the device log-mel
@@ -1732,8 +1941,16 @@ class DeSTA25AudioModel:
             self.processor = processor or HipLogMelProcessor(self.config.encoder_config.num_mel_bins, self.device)
         if vad is not None or not hasattr(self, "get_speech_timestamps"):
             self.get_speech_timestamps = vad
+        if asr_tokenizer is not None or not hasattr(self, "asr_tokenizer"):
+            self.asr_tokenizer = asr_tokenizer
+            if asr_tokenizer is None and self.asr_decoder is not None and os.path.isdir(str(self.config.encoder_model_id)):
+                try:                                                                     # the Whisper tokenizer files of the local checkpoint
+                    from transformers import WhisperTokenizerFast
+                    self.asr_tokenizer = WhisperTokenizerFast.from_pretrained(self.config.encoder_model_id, local_files_only=True)
+                except Exception:                                                        # noqa: BLE001 — no tokenizer files: decode raises at use
+                    self.asr_tokenizer = None
         if asr is not None or not hasattr(self, "asr"):
-            self.asr = asr
+            self.asr = asr if asr is not None else (self._asr_whisper if self.asr_decoder is not None else None)
 
     def generate(self, messages, temperature=0.7, top_p=0.9, do_sample=True, max_new_tokens=512, seed=0):
         """The reference's chat-level `generate` (modeling_desta25.py:1491-1721): messages -> audio decode -> log-mel -> placeholder
@@ -1777,8 +1994,8 @@ class DeSTA25AudioModel:
                 texts[i] = " "
         if need_asr:
             if self.asr is None:
-                raise NotImplementedError("an audio with speech and no 'text' needs ASR; the Whisper decoder is not on the MI355X hot path: "
-                                          "pass the transcription in the message or inject asr= through _setup_generation")
+                raise NotImplementedError("an audio with speech and no 'text' needs ASR: the Whisper checkpoint in use carries no decoder "
+                                          "weights (model.decoder.*) — pass the transcription in the message or inject asr= through _setup_generation")
             for i, t in zip(need_asr, self.asr([waves[i] for i in need_asr])):
                 texts[i] = t.strip()
         feats = self.processor(waves, sampling_rate=16000, return_tensors="pt").input_features

@@ -379,6 +379,9 @@ int desta_scatter_rows_bf16(const void* in, const int32_t* idx, int rows, int hi
  * reduction; `workspace` holds desta_argmax_workspace_bytes(rows) bytes).
  * Replaces the argmax of `llm_model.generate(do_sample=False)` (modeling_desta25.py:1419). */
 size_t desta_argmax_workspace_bytes(int rows);
+/* logits[r, ids[i]] = -inf (bf16 rows of `cols` entries, row stride ld) for every row r: token suppression in front of the argmax
+ * (Whisper ASR leg of generate(), modeling_desta25.py:1580-1590 -> TF:generation/logits_process.py SuppressTokensLogitsProcessor). */
+int desta_mask_tokens_bf16(void* logits, int64_t ld, int rows, int cols, const int32_t* ids, int n, void* stream);
 int desta_argmax_bf16(const void* x, int64_t ld, int rows, int cols, int64_t* out, void* workspace, void* stream);
 
 /* `do_sample=True` step of `llm_model.generate` (modeling_desta25.py:1419-1427: temperature, top_p):

@@ -125,3 +125,43 @@ COLLATE_CASES = {
                dict(id="f.wav", prompt="empty response is skipped", response="")],
               [[0, 1, 2], [1], [2, 3, 0], [3], [2]], {"c.wav"}),
 }
+
+
+# ------------------------------------------------------------------------------------------------ Whisper decoder stand-in (ASR leg of generate)
+ASR_DIMS = dict(decoder_layers=2, vocab_size=96, max_target_positions=64)
+ASR_GEN_CFG = dict(decoder_start_token_id=1, eos_token_id=2, pad_token_id=2, bos_token_id=2, max_length=64, is_multilingual=True,
+                   lang_to_id={"<|en|>": 10, "<|de|>": 11, "<|fr|>": 12}, task_to_id={"transcribe": 13, "translate": 14}, no_timestamps_token_id=15,
+                   suppress_tokens=[5, 6, 20], begin_suppress_tokens=[7, 2], return_timestamps=False)
+
+
+def asr_weights(d: O.Dims, seed: int = 5):
+    """Seeded Whisper DECODER weights (+ the encoder's final layer_norm, which the perception taps skip) at tiny width under the
+    checkpoint's names — regenerated identically by the golden script and by the GPU test, never stored."""
+    g = torch.Generator().manual_seed(seed)
+    w, dm, ffn, V, P = {}, d.enc_d, d.enc_ffn, ASR_DIMS["vocab_size"], ASR_DIMS["max_target_positions"]
+    E, D = "perception.whisper.model.encoder.", "perception.whisper.model.decoder."
+
+    def lin(name, o, i, bias=True):
+        w[name + ".weight"] = 0.3 * torch.randn(o, i, generator=g)            # (large on purpose: a random decoder with small weights repeats one token)
+        if bias:
+            w[name + ".bias"] = 0.1 * torch.randn(o, generator=g)
+
+    def ln(name):
+        w[name + ".weight"] = 1.0 + 0.1 * torch.randn(dm, generator=g)
+        w[name + ".bias"] = 0.1 * torch.randn(dm, generator=g)
+    ln(E + "layer_norm")
+    w[D + "embed_tokens.weight"] = torch.randn(V, dm, generator=g)
+    w[D + "embed_positions.weight"] = 0.3 * torch.randn(P, dm, generator=g)
+    for i in range(ASR_DIMS["decoder_layers"]):
+        p = f"{D}layers.{i}."
+        for a in ("self_attn", "encoder_attn"):
+            lin(p + a + ".q_proj", dm, dm)
+            lin(p + a + ".k_proj", dm, dm, bias=False)
+            lin(p + a + ".v_proj", dm, dm)
+            lin(p + a + ".out_proj", dm, dm)
+            ln(p + a + "_layer_norm")
+        lin(p + "fc1", ffn, dm)
+        lin(p + "fc2", dm, ffn)
+        ln(p + "final_layer_norm")
+    ln(D + "layer_norm")
+    return w

@@ -4,6 +4,7 @@
 The product computes in bf16, the reference in fp32: per-step logits must agree to 3e-2 relative L2, and every
 greedy choice of the product must be (near-)optimal under the fp32 logits (argmax flips only between near-ties)."""
 import math
+import os
 
 import pytest
 import torch
@@ -254,3 +255,101 @@ def test_trainer_evaluate_loss_ppl_and_predictions(golden_dir):
     tr2.evaluate([full], generation_kwargs=dict(max_new_tokens=4, do_sample=False))
     o = tr2.prediction_step_outputs[0]
     assert set(o) >= {"context", "prediction", "label", "id"} and len(o["prediction"].split()) == 4
+
+
+def _asr_model(golden_dir, gen_cfg=None):
+    from helpers import ASR_DIMS, ASR_GEN_CFG, asr_weights, cfg_from_dims
+    from safetensors.torch import load_file
+    from desta.models.modeling_desta25 import DeSTA25AudioModel
+    d = O.tiny_dims(False)
+    w = {**O.init_weights(d, seed=7), **asr_weights(d, seed=5)}
+    cfg = cfg_from_dims(d, whisper_generation_config=dict(gen_cfg or ASR_GEN_CFG))
+    e = cfg.encoder_config
+    e.decoder_layers, e.vocab_size, e.max_target_positions = ASR_DIMS["decoder_layers"], ASR_DIMS["vocab_size"], ASR_DIMS["max_target_positions"]
+    e.decoder_attention_heads, e.decoder_ffn_dim = d.enc_heads, d.enc_ffn
+    g = load_file(os.path.join(golden_dir, "ref_asr_tiny.safetensors"))
+    return DeSTA25AudioModel(cfg, weights=w), g, d
+
+
+def test_whisper_asr_decoder_vs_reference_golden(golden_dir):
+    """The ASR leg of generate() (reference: `self.perception.whisper.generate(input_features, attention_mask=None, max_new_tokens=128)`,
+    modeling_desta25.py:1580-1590) on the device: frozen encoder + encoder.layer_norm -> KV-cached greedy decoder.  Golden
+    (tests/golden/ref_asr_tiny.safetensors): the model's own forward under the generate rules — init tokens [start, detected language,
+    no-timestamps], suppress / begin-suppress lists, EOS stop — which the golden script checks token for token against
+    WhisperForConditionalGeneration.generate on a short budget.  Asserted: the init tokens (language detection included), the raw
+    logits of every step on the golden's own prefix (teacher forcing), the free-running tokens, EOS stop + padding."""
+    from helpers import ASR_GEN_CFG
+    model, g, d = _asr_model(golden_dir)
+    assert model.asr_decoder is not None
+    n_init = int(g["n_init"])
+    seq = g["sequences"]
+    N = seq.shape[1] - n_init
+    feats = g["batch_features"]
+    ids, logits, init = model.asr_decoder.generate(model.encoder, feats, max_new_tokens=N, collect_logits=True, forced_tokens=seq[:, n_init:])
+    assert init.cpu().tolist() == seq[:, :n_init].tolist()                        # [start, <|de|> by detection, no-timestamps]; no task token (language unset)
+    assert ids.cpu().tolist() == seq[:, n_init:].tolist()
+    e = rel_err(logits.float().cpu(), g["logits"])
+    print("asr decoder: teacher-forced logits rel-L2", e)
+    assert e < 2e-2, e                                                            # bf16 operands / fp32 residual stream vs the fp32 reference
+    # free running: every token whose golden margin over the runner-up is comfortable must come out the same
+    free = model.asr_decoder.generate(model.encoder, feats, max_new_tokens=N).cpu()
+    gl = g["logits"].clone()                                                       # [N, B, V] raw; apply the suppress rules for the margin
+    gl[:, :, ASR_GEN_CFG["suppress_tokens"]] = -1e30
+    gl[0][:, ASR_GEN_CFG["begin_suppress_tokens"]] = -1e30
+    top2 = gl.topk(2, dim=-1).values
+    margin = (top2[..., 0] - top2[..., 1]).t()                                     # [B, N]
+    agree = 0
+    for b in range(free.shape[0]):
+        for k in range(min(N, free.shape[1])):
+            if int(free[b, k]) != int(seq[b, n_init + k]):
+                assert float(margin[b, k]) < 0.35, (b, k, float(margin[b, k]))     # only a near-tie may flip; the prefix differs from here on
+                break
+            agree += 1
+    assert agree >= 0.8 * free.numel(), (agree, free.tolist(), seq[:, n_init:].tolist())
+    # EOS variant: stop, pad with pad_token_id (= eos here), trim behind the last EOS
+    eos = int(g["eos_id"])
+    gc2 = {**ASR_GEN_CFG, "eos_token_id": eos, "pad_token_id": eos, "bos_token_id": eos, "begin_suppress_tokens": [7, eos]}
+    model2, _, _ = _asr_model(golden_dir, gc2)
+    out = model2.asr_decoder.generate(model2.encoder, feats, max_new_tokens=N).cpu()
+    want = g["sequences_eos"][:, n_init:]
+    assert out.shape[1] <= want.shape[1]
+    for b in range(out.shape[0]):
+        row = want[b].tolist()
+        if eos in row:                                                             # rows that finish: identical up to and including EOS, padding after it
+            k = row.index(eos) + 1
+            assert out[b, :k].tolist() == row[:k] and all(int(t) == eos for t in out[b, k:]), (b, out[b].tolist(), row)
+
+
+def test_chat_generate_transcribes_speech_without_text(golden_dir, tmp_path):
+    """Chat-level `generate(messages)` with an audio that has speech and NO 'text': the Whisper decoder of the checkpoint transcribes it
+    (no injected `asr`), the transcription's tokens follow the audio features in the prompt (modeling_desta25.py:1562-1600)."""
+    import numpy as np
+    from helpers import ToyTokenizer
+    from desta.utils.audio import HipLogMelProcessor
+    model, g, d = _asr_model(golden_dir)
+    d_T = d.enc_T
+
+    class AsrTok:
+        def batch_decode(self, ids, skip_special_tokens=True):
+            return [" ".join(f"w{int(t)}" for t in row if int(t) > 15) for row in ids]
+    # a 1-s WAVE file; the tiny encoder takes 2 * 96 mel frames, so the processor hands over the golden's features instead of a 3000-frame log-mel
+    import wave
+    p = tmp_path / "speech.wav"
+    with wave.open(str(p), "wb") as wv:
+        wv.setnchannels(1); wv.setsampwidth(2); wv.setframerate(16000)
+        wv.writeframes((0.1 * np.random.default_rng(0).standard_normal(16000) * 32767).astype("<i2").tobytes())
+
+    class Proc:
+        def __call__(self, waves, sampling_rate=None, return_tensors=None):
+            import types
+            return types.SimpleNamespace(input_features=g["batch_features"][:len(waves)].cuda())
+    model._setup_generation(tokenizer=ToyTokenizer(vocab_size=d.vocab), processor=Proc(), vad=lambda w: True, asr_tokenizer=AsrTok())
+    assert model.asr is not None                                                   # built from the decoder, not injected
+    out = model.generate([{"role": "user", "content": "What is said? <|AUDIO|>", "audios": [{"audio": str(p), "text": None}]}],
+                         do_sample=False, max_new_tokens=4)
+    text = out.audios[0][1]
+    want = " ".join(f"w{int(t)}" for t in model._last_asr_ids[0].tolist() if int(t) > 15)
+    assert text == want.strip() and len(text) > 0
+    n_tr = len(ToyTokenizer().tokenize(text))
+    assert model._last_generate_inputs["batch_transcription_ids"][0].shape == (1, n_tr)
+    assert len(out.generated_ids[0]) == 4
