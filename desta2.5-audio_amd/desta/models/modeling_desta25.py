@@ -1943,14 +1943,14 @@ class DeSTA25AudioModel:
             self.get_speech_timestamps = vad
         if asr_tokenizer is not None or not hasattr(self, "asr_tokenizer"):
             self.asr_tokenizer = asr_tokenizer
-            if asr_tokenizer is None and self.asr_decoder is not None and os.path.isdir(str(self.config.encoder_model_id)):
+            if asr_tokenizer is None and getattr(self, "asr_decoder", None) is not None and os.path.isdir(str(self.config.encoder_model_id)):
                 try:                                                                     # the Whisper tokenizer files of the local checkpoint
                     from transformers import WhisperTokenizerFast
                     self.asr_tokenizer = WhisperTokenizerFast.from_pretrained(self.config.encoder_model_id, local_files_only=True)
                 except Exception:                                                        # noqa: BLE001 — no tokenizer files: decode raises at use
                     self.asr_tokenizer = None
         if asr is not None or not hasattr(self, "asr"):
-            self.asr = asr if asr is not None else (self._asr_whisper if self.asr_decoder is not None else None)
+            self.asr = asr if asr is not None else (self._asr_whisper if getattr(self, "asr_decoder", None) is not None else None)
 
     def generate(self, messages, temperature=0.7, top_p=0.9, do_sample=True, max_new_tokens=512, seed=0):
         """The reference's chat-level `generate` (modeling_desta25.py:1491-1721): messages -> audio decode -> log-mel -> placeholder
