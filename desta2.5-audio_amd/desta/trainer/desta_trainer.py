@@ -388,15 +388,33 @@ class DeSTA25Trainer:
         if nw <= 0 or host is None or finish is None or not index_batches:
             return (coll([ds[i] for i in b]) for b in index_batches)
         from torch.utils.data import DataLoader, Dataset
+        key = (id(ds), id(coll), nw, bool(self.args.dataloader_pin_memory))
+        cached = getattr(self, "_loader", None)
+        if cached is None or cached[0] != key:
+            # ONE loader for the whole run: its worker processes are PERSISTENT and the batch sampler is an object whose contents are
+            # replaced per epoch — a fresh DataLoader per epoch forks the workers again (measured: a 2.2-s stall at every epoch
+            # boundary of `bench.py --data wav`, the parent holds 30 GB of page tables)
+            class _Rows(Dataset):
+                def __len__(self_inner):
+                    return len(ds)
 
-        class _Rows(Dataset):
-            def __len__(self_inner):
-                return len(ds)
+                def __getitem__(self_inner, i):
+                    return ds[i]
 
-            def __getitem__(self_inner, i):
-                return ds[i]
-        dl = DataLoader(_Rows(), batch_sampler=index_batches, collate_fn=host, num_workers=nw, pin_memory=bool(self.args.dataloader_pin_memory),
-                        prefetch_factor=max(1, int(self.args.dataloader_prefetch_factor)), multiprocessing_context="fork")
+            class _EpochIndexBatches:
+                batches: List[List[int]] = []
+
+                def __iter__(self_inner):
+                    return iter(self_inner.batches)
+
+                def __len__(self_inner):
+                    return len(self_inner.batches)
+            sampler = _EpochIndexBatches()
+            dl = DataLoader(_Rows(), batch_sampler=sampler, collate_fn=host, num_workers=nw, pin_memory=bool(self.args.dataloader_pin_memory),
+                            prefetch_factor=max(1, int(self.args.dataloader_prefetch_factor)), multiprocessing_context="fork", persistent_workers=True)
+            cached = self._loader = (key, dl, sampler)
+        _, dl, sampler = cached
+        sampler.batches = index_batches
         return (finish(p) for p in dl)
 
     def _train_pass(self, it, max_steps: Optional[int]) -> List[torch.Tensor]:

