@@ -288,6 +288,7 @@ def main():
                          "NOT the headline line (BASELINE.json's metric is on synthetic inputs resident in HBM): printed beside it for VERDICT r3 item 8")
     ap.add_argument("--workers", type=int, default=4, help="--data wav: DataLoader worker processes (dataset.train_ds.num_workers); 0 = collate inline")
     ap.add_argument("--wav-dir", default="/tmp/desta_bench_wav")
+    ap.add_argument("--no-gemm-tail-skip", action="store_true", help="A/B: the 256x256 GEMM re-loads dead LDS slots past its last K-tile (rounds 1-3) instead of stopping the half-tile stream there")
     ap.add_argument("--gelu-poly", action="store_true", help="A/B: bf16-output GELU epilogues on the packed degree-12 polynomial instead of the A&S 7.1.26 form (measured equal)")
     ap.add_argument("--no-swiglu-fusion", action="store_true", help="A/B: silu(gate) * up and its backward as their own HBM passes instead of inside the gate|up / d(act) GEMM epilogues")
     ap.add_argument("--full-lm-head", action="store_true", help="A/B: lm_head / CE over the whole token grid, not only the target rows")
@@ -349,6 +350,8 @@ def main():
         H.gemm_set_option(5, 1)
     if a.gelu_poly:
         H.gemm_set_option(9, 1)
+    if a.no_gemm_tail_skip:
+        H.gemm_set_option(10, 0)
     cfg = DeSTA25Config(**FULL_CONFIGS[a.config], use_lora=a.lora)
     t0 = time.time()
     model = DeSTA25AudioModel(cfg, weights=RandomWeights(cfg, dev, seed=0), device=dev)

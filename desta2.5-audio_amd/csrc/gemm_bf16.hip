@@ -47,6 +47,7 @@ struct GemmArgs {
     const float* rms_w; float rms_eps;                  // skinny kernel: RMSNorm(A rows; weight rms_w) applied on the fly
     const float* rope_cs; const int* rope_pos; int rope_cols, rope_hd;   // rotary embedding of output columns [0, rope_cols) in adjacent pairs
     int desync;                                         // 256-kernel: first-round blocks start up to desync x 0.5 us apart (see gemm_bf16_nt_256_kernel)
+    int tail_skip;                                      // 256-kernel, 2-phase schedule: past the last K-tile the half-tile stream STOPS (counted waits shrink) instead of re-loading dead slots (option 10)
     int gelu_poly;                                      // bf16-output GELU epilogues: 0 = A&S 7.1.26 with v_rcp / v_exp (default), 1 = packed polynomial form (option 9)
 };
 
@@ -732,7 +733,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
     const int kt1 = partial ? (int)((long)nk_all * (slice + 1) / p.split) : nk_all;
     const int nk = kt1 - kt0;
     // issue half-tile number j of the stream
+    // tail_skip (2-phase schedule): half-tiles past the end of the stream are NOT issued — without it the stream re-loads the last K-tile
+    // into dead slots so that the counted vmcnt stays constant: 7 x 16 KiB of L2 -> LDS traffic per tile that nothing reads (2.7 % of
+    // a K = 4096 tile's operand traffic, 8.8 % at K = 1280) and a drain behind the last MFMA
+    const bool tskip = PHASES == 2 && p.tail_skip != 0;
+    const int n_ht = 4 * nk;
     auto stage = [&](int j) {
+        if (tskip && j >= n_ht) return;                   // (wave-uniform)
         const int t = j >> 2, q = j & 3;                  // q: 0 A0, 1 B0, 2 B1, 3 A1
         const int kind = (q == 0) ? 0 : (q == 1) ? 2 : (q == 2) ? 3 : 1;
         const long koff = (long)(kt0 + min(t, nk - 1)) * BK;
@@ -740,6 +747,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             glds16(src[kind][i] + koff, dst + (i * 512 + wave * 64) * 16);
+    };
+    // counted wait in front of a barrier: all but the 4 youngest half-tiles of the UNCAPPED stream must have landed; `issued` = stream
+    // position after this slot's stage() calls.  Steady state: 4 half-tiles x 2 ops = vmcnt(8); in the tail the stream is shorter by
+    // the overshoot, so fewer ops may stay outstanding (wave-uniform branch on a scalar)
+    auto tail_wait = [&](int issued) __attribute__((always_inline)) {
+        const int ov = tskip ? issued - n_ht : 0;
+        if (ov <= 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ov == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (ov == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (ov == 3) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 
     f32x4 acc[8][4];
@@ -763,7 +781,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
 
 #pragma unroll
     for (int j = 0; j < 7; ++j) stage(j);
-    if (PHASES == 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (PHASES == 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else tail_wait(7);
     __builtin_amdgcn_s_barrier();
 
     bf16x8 a[4][2], b0[2][2], b1[2][2];
@@ -805,10 +824,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
                 for (int kk = 0; kk < 2; ++kk) a[i][kk] = *(const bf16x8*)(A0 + (offA[i] ^ (kk << 6)));
             stage(g + 7);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (STAGGER) { SLOT_END() }
+            if (STAGGER) { tail_wait(g + 8); __builtin_amdgcn_s_barrier(); }
             MFMA_SLOT(0, 0, b0)
             MFMA_SLOT(0, 2, b1)
-            SLOT_END()
+            tail_wait(g + 8); __builtin_amdgcn_s_barrier();
             // ---------------- P2: A1 (B in registers) -> Q11, Q10
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -818,10 +837,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
             stage(g + 9);
             stage(g + 10);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (STAGGER) { SLOT_END() }
+            if (STAGGER) { tail_wait(g + 11); __builtin_amdgcn_s_barrier(); }
             MFMA_SLOT(4, 2, b1)
             MFMA_SLOT(4, 0, b0)
-            SLOT_END()
+            tail_wait(g + 11); __builtin_amdgcn_s_barrier();
             continue;
         }
         // ---------------- P1: A0, B0 -> Q00
@@ -1423,6 +1442,7 @@ static int g_skinny = 0;          // 0 auto, else COLS*10 + U of the skinny (M <
 static int g_desync = 0;          // option 7: spread of the first round's block starts in 0.5-us units, grids of >= g_desync_min_items
 static int g_desync_min = 640;    // option 8: items from which the spread is applied (2.5 rounds)
 static int g_skinny_blocks = 512;  // persistent grid of the skinny kernel (2 blocks per CU)
+static int g_tail_skip = 1;        // option 10: the 2-phase 256x256 kernel stops its half-tile stream at the last K-tile (1, default) or re-loads dead slots (0: rounds 1-3)
 static int g_gelu_poly = 0;        // option 9: bf16-output GELU epilogues on A&S 7.1.26 (0, default) or on the packed polynomial (1): same step time in the same-box A/B (163.0 / 163.3 vs 163.1 / 163.2 ms), so the more accurate form stays
 extern "C" int desta_gemm_set_option(int option, int value) {
     if (option == 0) g_persistent = value;
@@ -1440,6 +1460,7 @@ extern "C" int desta_gemm_set_option(int option, int value) {
     else if (option == 7) g_desync = value;
     else if (option == 8) g_desync_min = value;
     else if (option == 9) g_gelu_poly = value;
+    else if (option == 10) g_tail_skip = value;
     else if (option == 3) {
         if (value < 1 || value > 65535) { desta_set_error("gemm_set_option: skinny grid %d out of range", value); return DESTA_EINVAL; }
         g_skinny_blocks = value;
@@ -1469,7 +1490,7 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
     a.sA = d->stride_a; a.sB = d->stride_b; a.sC = d->stride_c;
     a.bias = d->bias;
     a.res = d->residual; a.ldr = d->ldr; a.sR = d->stride_r; a.res_f32 = d->residual_f32;
-    a.act = d->act; a.out_f32 = d->out_f32; a.gelu_poly = g_gelu_poly;
+    a.act = d->act; a.out_f32 = d->out_f32; a.gelu_poly = g_gelu_poly; a.tail_skip = g_tail_skip;
     a.preact = (bf16_t*)d->preact; a.ldp = d->ldp; a.sP = d->stride_p;
     a.alpha = d->alpha;
     a.aux = (bf16_t*)d->aux; a.lda_x = d->ld_aux;

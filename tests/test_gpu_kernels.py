@@ -230,6 +230,32 @@ def test_gemm_transposed_operands(hip, M, N, K):
         hip.gemm_set_option(6, 1)
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 512, 64), (256, 512, 128), (300, 520, 192), (512, 768, 576), (2304, 1280, 1280), (5120, 4096, 2048), (700, 4096, 4096)])
+def test_gemm_256_tail_skip_is_bit_identical(hip, M, N, K):
+    """Round 4: the two-phase 256x256 kernel stops its LDS-DMA half-tile stream at the last K-tile (counted `s_waitcnt vmcnt` shrinks
+    8 -> 2 -> 0 over the last three slots) instead of re-loading dead slots to keep the count constant (option 10).  Same arithmetic in
+    the same order: bit-identical to the dummy-load form and to the four-phase kernel, for one to many K-tiles, ragged edges, and a
+    grid with a split-K tail (5120 x 4096: 64 tiles in 4 K-slices of 8 K-tiles); repeated runs agree (a mis-counted wait would race)."""
+    g = torch.Generator().manual_seed(M + 7 * N + K)
+    A = _bf(torch.randn(M, K, generator=g)).cuda()
+    B = _bf(torch.randn(N, K, generator=g)).cuda()
+    outs = {}
+    try:
+        for v, skip in ((2, 1), (6, 0), (6, 1), (7, 1)):
+            hip.gemm_force_variant(v)
+            hip.gemm_set_option(10, skip)
+            o = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+            for _ in range(4):
+                hip.gemm(A, B, o, M, N, K)
+            outs[(v, skip)] = o.clone()
+    finally:
+        hip.gemm_force_variant(0)
+        hip.gemm_set_option(10, 1)
+    for k, o in outs.items():
+        assert torch.equal(o, outs[(2, 1)]), k
+    assert torch.isfinite(outs[(6, 1)]).all()
+
+
 def test_gemm_256_identity_and_k64(hip):
     K = 64                                        # a single K-tile: the whole loop is prologue + dummy tail loads
     A = _bf(torch.eye(256)[:, :K]).cuda()
