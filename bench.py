@@ -288,6 +288,8 @@ def main():
                          "NOT the headline line (BASELINE.json's metric is on synthetic inputs resident in HBM): printed beside it for VERDICT r3 item 8")
     ap.add_argument("--workers", type=int, default=4, help="--data wav: DataLoader worker processes (dataset.train_ds.num_workers); 0 = collate inline")
     ap.add_argument("--wav-dir", default="/tmp/desta_bench_wav")
+    ap.add_argument("--main-priority", type=int, default=None, help="A/B: run the whole step on a non-default HIP stream of this priority (-1 = high) instead of torch's default stream")
+    ap.add_argument("--side-priority", type=int, default=1, help="HIP priority of the encoder-prefetch / optimizer-tail streams (0 = same as the main stream: rounds 1-3; 1 = lower)")
     ap.add_argument("--no-gemm-tail-skip", action="store_true", help="A/B: the 256x256 GEMM re-loads dead LDS slots past its last K-tile (rounds 1-3) instead of stopping the half-tile stream there")
     ap.add_argument("--gelu-poly", action="store_true", help="A/B: bf16-output GELU epilogues on the packed degree-12 polynomial instead of the A&S 7.1.26 form (measured equal)")
     ap.add_argument("--no-swiglu-fusion", action="store_true", help="A/B: silu(gate) * up and its backward as their own HBM passes instead of inside the gate|up / d(act) GEMM epilogues")
@@ -357,7 +359,7 @@ def main():
     model = DeSTA25AudioModel(cfg, weights=RandomWeights(cfg, dev, seed=0), device=dev)
     args = TrainingArguments(learning_rate=1e-4, weight_decay=0.01, warmup_steps=5000, max_steps=10 ** 6, logging_steps=10 ** 9,
                              overlap_comm=not a.no_overlap, overlap_encoder=a.encoder_overlap and not a.no_overlap,
-                             overlap_connector_backward=a.connector_overlap)
+                             overlap_connector_backward=a.connector_overlap, side_stream_priority=a.side_priority)
     trainer = DeSTA25Trainer(model, args=args)
     if a.no_dw_overlap:
         model.connector.overlap_dw = False
@@ -464,6 +466,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if rank == 0:
+        print(f"[bench] HIP stream priority range (least, greatest): {torch.cuda.Stream.priority_range()}; side streams at {a.side_priority}"
+              + (f", main stream at {a.main_priority}" if a.main_priority is not None else ""), file=sys.stderr)
+    if a.main_priority is not None:
+        _main = torch.cuda.Stream(device=dev, priority=a.main_priority)
+        _main.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.set_stream(_main)
     calib = None
     if rank == 0 and not a.no_calibration:
         calib = box_calibration(H, dev)

@@ -45,6 +45,7 @@ class TrainingArguments:
     overlap_comm: bool = True
     overlap_connector_backward: bool = False       # with overlap_comm: the connector's backward ALSO runs on the side stream (bit-identical results; round 3: -0.4 ms WITHOUT the encoder stream; round 4, beside `overlap_encoder`: +0.5 ms and 4x the step-time spread, same-box A/B -> off)
     overlap_encoder: bool = True                   # next batch's frozen Whisper forward on its own HIP stream beside the connector / LLM of the current batch (bit-identical results; default since round 4)
+    side_stream_priority: int = 1                  # HIP priority of the encoder-prefetch and optimizer-tail streams (lower number = higher priority; 0 = the main stream's): 1 = below the main stream, so the critical path's blocks are dispatched first and the side work fills idle CUs
     save_strategy: str = "no"                      # "epoch" (train_desta.py:146, enable_checkpointing) | "no"
     steps_per_epoch: Optional[int] = None          # len(train dataloader) = MICRO-batches per epoch when the dataset is not sized (synthetic streams)
     eval_strategy: str = "no"                      # "steps" (every eval_steps optimizer steps) | "epoch" | "no" (train_desta.py:147-148)
@@ -127,8 +128,9 @@ class DeSTA25Trainer:
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
         model.dropout_seed = 1 + self.rank                                    # ranks draw different dropout masks (as under DDP)
-        self._side = torch.cuda.Stream(device=model.device) if self.args.overlap_comm else None
-        self._enc_stream = torch.cuda.Stream(device=model.device) if self.args.overlap_encoder else None
+        pr = int(self.args.side_stream_priority)
+        self._side = torch.cuda.Stream(device=model.device, priority=pr) if self.args.overlap_comm else None
+        self._enc_stream = torch.cuda.Stream(device=model.device, priority=pr) if self.args.overlap_encoder else None
         self._side_done: Optional[torch.cuda.Event] = None
         self._log_buffer: List[Dict[str, Any]] = []
         self.log_history: List[Dict[str, float]] = []
