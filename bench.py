@@ -289,7 +289,7 @@ def main():
     ap.add_argument("--workers", type=int, default=4, help="--data wav: DataLoader worker processes (dataset.train_ds.num_workers); 0 = collate inline")
     ap.add_argument("--wav-dir", default="/tmp/desta_bench_wav")
     ap.add_argument("--main-priority", type=int, default=None, help="A/B: run the whole step on a non-default HIP stream of this priority (-1 = high) instead of torch's default stream")
-    ap.add_argument("--side-priority", type=int, default=1, help="HIP priority of the encoder-prefetch / optimizer-tail streams (0 = same as the main stream: rounds 1-3; 1 = lower)")
+    ap.add_argument("--side-priority", type=int, default=0, help="HIP priority of the encoder-prefetch / optimizer-tail streams (0 = same as the main stream: rounds 1-3; 1 = lower)")
     ap.add_argument("--no-gemm-tail-skip", action="store_true", help="A/B: the 256x256 GEMM re-loads dead LDS slots past its last K-tile (rounds 1-3) instead of stopping the half-tile stream there")
     ap.add_argument("--gelu-poly", action="store_true", help="A/B: bf16-output GELU epilogues on the packed degree-12 polynomial instead of the A&S 7.1.26 form (measured equal)")
     ap.add_argument("--no-swiglu-fusion", action="store_true", help="A/B: silu(gate) * up and its backward as their own HBM passes instead of inside the gate|up / d(act) GEMM epilogues")

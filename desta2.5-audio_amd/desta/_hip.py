@@ -696,3 +696,45 @@ def orca_sim_loss(x, y, y_index, batch, nx, ny, y_rows, hidden, subtract_identit
 
 def orca_align(audio, tokens, hidden, row_stride, batch_stride, hidden_size, spans, n_spans, out):
     check(_orca_align(p(audio), tokens, p(hidden), row_stride, batch_stride, hidden_size, p(spans), n_spans, p(out), stream()), "desta_orca_align")
+
+
+_orca_gate_residual_bwd = _sig("desta_orca_gate_residual_bwd", vp, i64, vp, vp, i64, i32, vp, vp, vp)
+_orca_gate_mlp_bwd = _sig("desta_orca_gate_mlp_bwd", vp, vp, vp, vp, i64, i32, vp, vp, vp, vp)
+_orca_align_bwd = _sig("desta_orca_align_bwd", vp, i32, vp, i64, i64, i32, vp, i32, C.c_float, vp, i64, i64, vp)
+_orca_rope_bwd = _sig("desta_orca_rope_bwd", vp, i32, i32, i32, C.c_float, C.c_float, i32, i32, vp, vp, vp)
+_orca_col2im_add = _sig("desta_orca_col2im_add", vp, i32, i32, i32, i32, i32, i32, vp, vp)
+_orca_local_mix_bwd = _sig("desta_orca_local_mix_bwd", vp, vp, vp, i32, i64, i32, vp, vp, vp)
+_orca_sim_loss_bwd = _sig("desta_orca_sim_loss_bwd", vp, vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, C.c_float, vp, vp)
+
+
+def orca_gate_residual_bwd(d_out, ld, cross, gate, rows, hidden_size, d_cross, d_gate_pre):
+    check(_orca_gate_residual_bwd(p(d_out), ld, p(cross), p(gate), rows, hidden_size, p(d_cross), p(d_gate_pre), stream()), "desta_orca_gate_residual_bwd")
+
+
+def orca_gate_mlp_bwd(d_gate_pre, gate_preact, gate_hidden, gate_w2, rows, gate_width, d_preact, d_w2, d_b2):
+    check(_orca_gate_mlp_bwd(p(d_gate_pre), p(gate_preact), p(gate_hidden), p(gate_w2), rows, gate_width, p(d_preact), p(d_w2), p(d_b2), stream()),
+          "desta_orca_gate_mlp_bwd")
+
+
+def orca_align_bwd(audio, tokens, hidden, row_stride, batch_stride, hidden_size, spans, n_spans, coef, d_hidden, d_row_stride, d_batch_stride):
+    check(_orca_align_bwd(p(audio), tokens, p(hidden), row_stride, batch_stride, hidden_size, p(spans), n_spans, float(coef), p(d_hidden), d_row_stride,
+                          d_batch_stride, stream()), "desta_orca_align_bwd")
+
+
+def orca_rope_bwd(d_rotated, batch, tokens, hidden, theta, position_scale, round_cos_sin, n_first, d_first, d_rest):
+    check(_orca_rope_bwd(p(d_rotated), batch, tokens, hidden, float(theta), float(position_scale), int(round_cos_sin), n_first, p(d_first), p(d_rest), stream()),
+          "desta_orca_rope_bwd")
+
+
+def orca_col2im_add(d_col, batch, tokens_out, tokens_padded, hidden, kernel, stride, d_padded):
+    check(_orca_col2im_add(p(d_col), batch, tokens_out, tokens_padded, hidden, kernel, stride, p(d_padded), stream()), "desta_orca_col2im_add")
+
+
+def orca_local_mix_bwd(d_out, x, layer_weights, taps, rows, d, d_layer_weights):
+    ws = scratch(2048, d_out.device, tag="orca_mix")
+    check(_orca_local_mix_bwd(p(d_out), p(x), p(layer_weights), taps, rows, d, p(d_layer_weights), p(ws), stream()), "desta_orca_local_mix_bwd")
+
+
+def orca_sim_loss_bwd(x, x_index, x_rows, y, y_index, y_rows, batch, nx, ny, hidden, subtract_identity, coef, d_x):
+    check(_orca_sim_loss_bwd(p(x), p(x_index), x_rows, p(y), p(y_index), y_rows, batch, nx, ny, hidden, int(subtract_identity), float(coef), p(d_x), stream()),
+          "desta_orca_sim_loss_bwd")

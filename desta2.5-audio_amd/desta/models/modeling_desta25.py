@@ -306,15 +306,28 @@ def reference_parameter_names(cfg: DeSTA25Config) -> List[str]:
     if getattr(cfg, "use_lora", False):
         names += [f"{LLM}model.layers.{i}.self_attn.{m}_proj.lora_{ab}.default.weight"
                   for i in range(cfg.llm_config.num_hidden_layers) for m in LORA_TARGETS for ab in "AB"]
-    names += [f"{CON}layer_prompts.{j}" for j in range(len(cfg.target_layer_ids))] + [f"{CON}layer_weights"]
+    orca = getattr(cfg, "connector_mode", "qformer_1") == "orca_hybrid"
+    n_prompts, n_weights, n_qf, n_proj = (("global_queries.", "global_layer_weights", "global_qformer.layer.", "global_proj.") if orca
+                                          else ("layer_prompts.", "layer_weights", "qformer.layer.", "proj."))
+    names += [f"{CON}{n_prompts}{j}" for j in range(len(cfg.target_layer_ids))] + [f"{CON}{n_weights}"]
     for i in range(cfg.qformer_num_hidden_layers):
-        p = f"{CON}qformer.layer.{i}."
+        p = f"{CON}{n_qf}{i}."
         for blk in ("attention", "crossattention"):
             for lin in ("self.query", "self.key", "self.value", "output.dense", "output.LayerNorm"):
                 names += [f"{p}{blk}.{lin}.weight", f"{p}{blk}.{lin}.bias"]
         for lin in ("intermediate.dense", "output.dense", "output.LayerNorm"):
             names += [f"{p}{lin}.weight", f"{p}{lin}.bias"]
-    return names + [CON + "proj.0.weight", CON + "proj.0.bias", CON + "proj.1.weight", CON + "proj.1.bias"]
+    names += [CON + n_proj + "0.weight", CON + n_proj + "0.bias", CON + n_proj + "1.weight", CON + n_proj + "1.bias"]
+    if orca:
+        # ORCAHybridConnector.__init__ order (:266-287), then `orca_cross_attns` (registered after `perception`, :1084)
+        names += [CON + "local_layer_weights", CON + "local_proj_in.weight", CON + "local_proj_in.bias", CON + "local_conv.weight",
+                  CON + "local_conv.bias", CON + "local_ln.weight", CON + "local_ln.bias"]
+        if cfg.orca_deep_injection_enabled:
+            for l in range(cfg.llm_config.num_hidden_layers):
+                q = f"orca_cross_attns.{l}."
+                names += [q + "cross_attn.in_proj_weight", q + "cross_attn.in_proj_bias", q + "cross_attn.out_proj.weight", q + "cross_attn.out_proj.bias",
+                          q + "gate_proj.0.weight", q + "gate_proj.0.bias", q + "gate_proj.2.weight", q + "gate_proj.2.bias", q + "ln.weight", q + "ln.bias"]
+    return names
 
 
 def rope_inv_freq(c: LLMConfig) -> torch.Tensor:
@@ -935,9 +948,12 @@ class OrcaHIP:
     """ORCA hybrid, FIRST SLICE: forward of the local branch of `ORCAHybridConnector` (modeling_desta25.py:336-352),
     of `ORCAGatedCrossAttention` behind every decoder layer (:395-490, installed by `_enable_orca_deep_injection` :1052-1143) and of
     `compute_orca_losses` (:1159-1206), composed from the C-ABI entry points of the qformer_1 path (GEMM, flash attention, LayerNorm)
-    plus the row-wise `desta_orca_*` kernels.  The global branch is `QformerConnectorHIP` under the ORCA tensor names.  No backward:
-    `DeSTA25AudioModel.backward` raises for this mode.  Pinned to the reference's own classes at tiny size
-    (tests/golden/ref_orca_tiny.safetensors, tests/test_gpu_orca.py)."""
+    plus the row-wise `desta_orca_*` kernels.  The global branch is `QformerConnectorHIP` under the ORCA tensor names.
+    BACKWARD (round 4, second slice): hand-written like the rest of the path — `inject_bwd` (gate, gate MLP, LayerNorm, out-proj,
+    attention, q / k|v projections, alignment loss; called by the decoder's backward behind every layer), `backward_tail` (rotation
+    transpose, the two similarity losses, local branch: LayerNorm, Conv1d as im2col dW + col2im dX, Linear, tap mix; then the global
+    branch = `QformerConnectorHIP.backward`).  Pinned to the reference's own classes and autograd at tiny size
+    (tests/golden/ref_orca_tiny.safetensors, tests/test_gpu_orca.py).  LayerNorm backward is built for hidden <= 2048."""
 
     def __init__(self, cfg: DeSTA25Config, connector: "QformerConnectorHIP", device):
         c = cfg.llm_config
@@ -970,6 +986,29 @@ class OrcaHIP:
         self.conv_out = torch.empty(B * self.Tl, h, dtype=F32, device=dev)
         self.local16 = torch.empty(B * self.Tl, h, dtype=BF16, device=dev)
 
+    # -- views of the ORCA tensors in the connector's arena
+    def G32(self, name, n=None):
+        return self.con.G32(name, n)
+
+    def Gw(self, name):
+        return self.con.arena.grad(name)
+
+    def _dW(self, dY: torch.Tensor, X: torch.Tensor, M: int, N: int, Kin: int, gw: torch.Tensor, gb: Optional[torch.Tensor]) -> None:
+        """gw [N, Kin] (fp32, written) = dY[M, N]^T X[M, Kin];  gb [N] = column sums of dY.  Both operands in transposed storage (the
+        token index is the reduction index); a token count that is not a multiple of 64 goes through zero-padded copies."""
+        if M % 64 != 0:
+            Mp = _r64(M)
+            dYp = torch.zeros(Mp, N, dtype=BF16, device=self.dev)
+            Xp = torch.zeros(Mp, Kin, dtype=BF16, device=self.dev)
+            dYp[:M].copy_(dY[:M])
+            Xp[:M].copy_(X[:M])
+            dY_, X_, M_ = dYp, Xp, Mp
+        else:
+            dY_, X_, M_ = dY, X, M
+        H.gemm(dY_, X_, gw, N, Kin, M_, trans_a=True, trans_b=True, lda=N, ldb=Kin)
+        if gb is not None:
+            H.colsum(dY, M, N, N, gb)
+
     def local_forward(self, enc_all: torch.Tensor, B: int) -> torch.Tensor:
         """enc_all [taps, B*T, d] bf16 -> local tokens [B*T', h] bf16."""
         con, h, d = self.con, self.h, self.d
@@ -985,16 +1024,20 @@ class OrcaHIP:
         # Conv1d(k, stride, pad) over time as a zero-copy im2col GEMM: output t' reads rows [t' stride, t' stride + k) of the padded stream
         H.gemm(self.loc_in, self.conv_w, self.conv_out, self.Tl, h, self.k * h, lda=self.stride * h, ldc=h, bias=con.P32(CON + "local_conv.bias"),
                batch=B, stride_a=Tp * h, stride_c=self.Tl * h)
-        H.layernorm_fwd(self.conv_out, con.P32(CON + "local_ln.weight"), con.P32(CON + "local_ln.bias"), 1e-5, y16=self.local16)
+        self.local_st = torch.empty(B * self.Tl, 2, dtype=F32, device=self.dev)
+        H.layernorm_fwd(self.conv_out, con.P32(CON + "local_ln.weight"), con.P32(CON + "local_ln.bias"), 1e-5, y16=self.local16, stats=self.local_st)
+        self.enc_all = enc_all
         return self.local16
 
     # -- deep injection
-    def begin(self, global16: torch.Tensor, local16: Optional[torch.Tensor], B: int, S: int, spans, training: bool) -> None:
+    def begin(self, global16: torch.Tensor, local16: Optional[torch.Tensor], B: int, S: int, spans, training: bool, save: bool = False) -> None:
         """Audio tokens the gated cross-attention of every layer attends to (modeling_desta25.py:792-806): the local tokens, or
         global | local with `orca_global_cross_attn`; rotated ONCE (the rotation does not depend on the layer, :422-438)."""
         cfg, h, dev = self.cfg, self.h, self.dev
         self.audio = None
         self.aligns: List[torch.Tensor] = []
+        self.save, self.sv = bool(save), [dict() for _ in range(self.L)]
+        self.global16, self.local16_in = global16, local16
         if not cfg.orca_deep_injection_enabled:
             return
         Kg = cfg.orca_global_num_tokens
@@ -1028,23 +1071,130 @@ class OrcaHIP:
         """x [B*S, h] bf16 = output of decoder layer l (batch-major rows), updated IN PLACE: x + sigmoid(gate(x)) * LN(cross_attn(x, audio))."""
         if self.audio is None:
             return
-        con, h, M, B, S, Ta = self.con, self.h, self.M, self.Bq, self.S, self.Ta
+        con, h, M, B, S, Ta, dev = self.con, self.h, self.M, self.Bq, self.S, self.Ta, self.dev
         p = f"orca_cross_attns.{l}."
         w_in, b_in = con.W16(p + "cross_attn.in_proj_weight"), con.P32(p + "cross_attn.in_proj_bias")
         if self.spans is not None and self.spans is not False:
             n = min(B, self.spans.shape[0])                                      # "audio_pooled may have different batch size, align by taking first N"
-            out = torch.empty(n, dtype=F32, device=self.dev)
+            out = torch.empty(n, dtype=F32, device=dev)
             H.orca_align(self.audio, Ta, x, h, S * h, h, self.spans, n, out)
             self.aligns.append(out)
-        H.gemm(x, w_in[:h], self.q16, M, h, h, bias=b_in[:h])
-        H.gemm(self.audio, w_in[h:], self.kv16, B * Ta, 2 * h, h, bias=b_in[h:])
-        ad = H.attn_desc(self.q16, self.kv16, self.kv16, self.att16, self.lse, batch=B, hq=self.heads, hkv=self.heads, sq=S, sk=Ta, hd=self.hd,
+        if self.save:
+            # a training forward keeps what the hand-written backward of this layer's injection needs (bf16 unless noted): the layer
+            # output BEFORE the injection, q, k|v, the attention output + lse, the out-proj output (fp32) with its LayerNorm statistics,
+            # its normalised form, the gate MLP's pre-activation / activation, the gate (fp32)
+            s = self.sv[l]
+            s["xpre"] = x.clone()
+            q16, kv16, att16 = torch.empty(M, h, dtype=BF16, device=dev), torch.empty(B * Ta, 2 * h, dtype=BF16, device=dev), torch.empty(M, h, dtype=BF16, device=dev)
+            lse, cross32, cross16 = torch.empty(B, self.heads, S, dtype=F32, device=dev), torch.empty(M, h, dtype=F32, device=dev), torch.empty(M, h, dtype=BF16, device=dev)
+            g1, g1pre = torch.empty(M, h // 4, dtype=BF16, device=dev), torch.empty(M, h // 4, dtype=BF16, device=dev)
+            st, gate = torch.empty(M, 2, dtype=F32, device=dev), torch.empty(M, dtype=F32, device=dev)
+            s.update(q16=q16, kv16=kv16, att16=att16, lse=lse, cross32=cross32, cross16=cross16, g1=g1, g1pre=g1pre, st=st, gate=gate)
+        else:
+            q16, kv16, att16, lse, cross32, cross16, g1, g1pre, st, gate = (self.q16, self.kv16, self.att16, self.lse, self.cross32, self.cross16, self.g1,
+                                                                            None, None, None)
+        H.gemm(x, w_in[:h], q16, M, h, h, bias=b_in[:h])
+        H.gemm(self.audio, w_in[h:], kv16, B * Ta, 2 * h, h, bias=b_in[h:])
+        ad = H.attn_desc(q16, kv16, kv16, att16, lse, batch=B, hq=self.heads, hkv=self.heads, sq=S, sk=Ta, hd=self.hd,
                          scale=self.hd ** -0.5, q_off=0, k_off=0, v_off=h)
         H.attention_fwd(ad)
-        H.gemm(self.att16, con.W16(p + "cross_attn.out_proj.weight"), self.cross32, M, h, h, bias=con.P32(p + "cross_attn.out_proj.bias"))
-        H.layernorm_fwd(self.cross32, con.P32(p + "ln.weight"), con.P32(p + "ln.bias"), 1e-5, y16=self.cross16)
-        H.gemm(x, con.W16(p + "gate_proj.0.weight"), self.g1, M, h // 4, h, bias=con.P32(p + "gate_proj.0.bias"), act=1)
-        H.orca_gate_residual(x, h, self.cross16, self.g1, con.P32(p + "gate_proj.2.weight"), con.P32(p + "gate_proj.2.bias"), M, h, h // 4)
+        H.gemm(att16, con.W16(p + "cross_attn.out_proj.weight"), cross32, M, h, h, bias=con.P32(p + "cross_attn.out_proj.bias"))
+        H.layernorm_fwd(cross32, con.P32(p + "ln.weight"), con.P32(p + "ln.bias"), 1e-5, y16=cross16, stats=st)
+        H.gemm(x, con.W16(p + "gate_proj.0.weight"), g1, M, h // 4, h, bias=con.P32(p + "gate_proj.0.bias"), act=1, preact=g1pre)
+        H.orca_gate_residual(x, h, cross16, g1, con.P32(p + "gate_proj.2.weight"), con.P32(p + "gate_proj.2.bias"), M, h, h // 4, gate_out=gate)
+        if self.save:
+            self.sv[l]["ad"] = ad
+
+    # -- backward
+    def begin_backward(self) -> None:
+        h, dev = self.h, self.dev
+        Kg = self.cfg.orca_global_num_tokens
+        self.dglobal32 = torch.zeros(self.B * Kg, h, dtype=F32, device=dev)
+        self.dlocal32 = torch.zeros(self.B * self.Tl, h, dtype=F32, device=dev)
+        if self.audio is not None:
+            self.d_audio32 = torch.zeros(self.Bq * self.Ta, h, dtype=F32, device=dev)
+
+    def inject_bwd(self, l: int, dx: torch.Tensor) -> None:
+        """dx [B*S, h] bf16 = d(loss) / d(output of decoder layer l AFTER its injection), updated IN PLACE to the gradient w.r.t. the output
+        BEFORE it; the injection's parameter gradients go to the arena, the gradient of the rotated audio tokens accumulates in fp32."""
+        if self.audio is None:
+            return
+        con, h, M, B, S, Ta, dev, s = self.con, self.h, self.M, self.Bq, self.S, self.Ta, self.dev, self.sv[l]
+        p = f"orca_cross_attns.{l}."
+        w_in = con.W16(p + "cross_attn.in_proj_weight")
+        gw_in, gb_in = self.Gw(p + "cross_attn.in_proj_weight"), self.G32(p + "cross_attn.in_proj_bias")
+
+        def b16(*sh):
+            return torch.empty(*sh, dtype=BF16, device=dev)
+        dc16, dg2 = b16(M, h), torch.empty(M, dtype=F32, device=dev)
+        H.orca_gate_residual_bwd(dx, h, s["cross16"], s["gate"], M, h, dc16, dg2)
+        # gate MLP: Linear(h, h/4) -> GELU -> Linear(h/4, 1)
+        dpre16 = b16(M, h // 4)
+        H.orca_gate_mlp_bwd(dg2, s["g1pre"], s["g1"], con.P32(p + "gate_proj.2.weight"), M, h // 4, dpre16,
+                            self.G32(p + "gate_proj.2.weight"), self.G32(p + "gate_proj.2.bias"))
+        self._dW(dpre16, s["xpre"], M, h // 4, h, self.Gw(p + "gate_proj.0.weight"), self.G32(p + "gate_proj.0.bias"))
+        # LayerNorm(cross) -> out_proj -> attention -> q / k|v projections
+        dcross16 = b16(M, h)
+        H.layernorm_bwd(dc16, s["cross32"], con.P32(p + "ln.weight"), s["st"], dx16=dcross16, dgamma=self.G32(p + "ln.weight"), dbeta=self.G32(p + "ln.bias"))
+        self._dW(dcross16, s["att16"], M, h, h, self.Gw(p + "cross_attn.out_proj.weight"), self.G32(p + "cross_attn.out_proj.bias"))
+        datt16, dq16, dkv16 = b16(M, h), b16(M, h), b16(B * Ta, 2 * h)
+        H.gemm(dcross16, con.W16(p + "cross_attn.out_proj.weight"), datt16, M, h, h, trans_b=True, ldb=h)
+        H.attention_bwd(s["ad"], datt16, dq16, dkv16, dkv16, dk_off=0, dv_off=h)
+        self._dW(dq16, s["xpre"], M, h, h, gw_in[:h], gb_in[:h])
+        self._dW(dkv16, self.audio, B * Ta, 2 * h, h, gw_in[h:], gb_in[h:])
+        H.gemm(dkv16, w_in[h:], self.d_audio32, B * Ta, h, 2 * h, trans_b=True, ldb=h, residual=self.d_audio32)
+        # into the layer output's gradient: the alignment loss of this layer (on the hidden states the injection READ), q path, gate path
+        if self.spans is not None and self.spans is not False and self.aligns:
+            n = min(B, self.spans.shape[0])
+            coef = self.cfg.orca_align_weight_local / (len(self.aligns) * n)
+            H.orca_align_bwd(self.audio, Ta, s["xpre"], h, S * h, h, self.spans, n, coef, dx, h, S * h)
+        H.gemm(dq16, w_in[:h], dx, M, h, h, trans_b=True, ldb=h, residual=dx)
+        H.gemm(dpre16, con.W16(p + "gate_proj.0.weight"), dx, M, h, h // 4, trans_b=True, ldb=h, residual=dx)
+        self.sv[l] = {}                                                        # activations of this layer are dead
+
+    def backward_tail(self, d_af: torch.Tensor) -> None:
+        """d_af [B*Kg, h] bf16 = gradient of the spliced global tokens (from the decoder's input gradient).  Adds the deep injection's
+        audio gradient (rotated back), the diversity / orthogonality losses, then runs the local branch's and the global branch's
+        backward: every ORCA / connector gradient of the arena is written."""
+        cfg, con, h, d, dev, B = self.cfg, self.con, self.h, self.d, self.dev, self.B
+        Kg, Tl, T = cfg.orca_global_num_tokens, self.Tl, self.T
+        g16, loc16 = self.global16, self.local16_in
+        if self.audio is not None:
+            H.orca_rope_bwd(self.d_audio32, B, self.Ta, h, self.rope_theta, cfg.orca_audio_position_scale, True,
+                            Kg if cfg.orca_global_cross_attn else 0, self.dglobal32, self.dlocal32)
+        H.orca_sim_loss_bwd(g16, None, Kg, g16, None, Kg, B, Kg, Kg, h, True, cfg.orca_ortho_diversity_weight / (B * Kg * Kg), self.dglobal32)
+        idx, ny = None, Tl
+        if Tl > 100:
+            idx = torch.linspace(0, Tl - 1, 100, dtype=torch.long).to(dev, torch.int32)
+            ny = 100
+        assert ny <= 128
+        co = cfg.orca_ortho_weight_qformer_local / (B * Kg * ny)
+        H.orca_sim_loss_bwd(g16, None, Kg, loc16, idx, Tl, B, Kg, ny, h, False, co, self.dglobal32)
+        H.orca_sim_loss_bwd(loc16, idx, Tl, g16, None, Kg, B, ny, Kg, h, False, co, self.dlocal32)
+        # ---- local branch: LayerNorm -> Conv1d -> Linear -> tap mix
+        k, st_, pad = self.k, self.stride, self.pad
+        Tp = T + 2 * pad
+        dconv16 = torch.empty(B * Tl, h, dtype=BF16, device=dev)
+        H.layernorm_bwd(self.dlocal32, self.conv_out, con.P32(CON + "local_ln.weight"), self.local_st, dx16=dconv16,
+                        dgamma=self.G32(CON + "local_ln.weight"), dbeta=self.G32(CON + "local_ln.bias"))
+        # dW of the convolution = dY^T im2col(x): the im2col rows are MATERIALISED here (a strided copy, no arithmetic): the token
+        # reduction wants rows in multiples of 64 and one contiguous operand over the batch
+        xcol = self.loc_in.as_strided((B, Tl, k * h), (Tp * h, st_ * h, 1)).reshape(B * Tl, k * h).contiguous()
+        gwc = torch.empty(h, k * h, dtype=F32, device=dev)
+        self._dW(dconv16, xcol, B * Tl, h, k * h, gwc, self.G32(CON + "local_conv.bias"))
+        self.Gw(CON + "local_conv.weight").copy_(gwc.view(h, k, h).permute(0, 2, 1))          # [out, k, in] -> the parameter's [out, in, k]
+        dcol16 = torch.empty(B * Tl, k * h, dtype=BF16, device=dev)
+        H.gemm(dconv16, self.conv_w, dcol16, B * Tl, k * h, h, trans_b=True, ldb=k * h)
+        dpad16 = torch.empty(B, Tp, h, dtype=BF16, device=dev)
+        H.orca_col2im_add(dcol16, B, Tl, Tp, h, k, st_, dpad16)
+        dloc_in = dpad16[:, pad:pad + T].reshape(B * T, h).contiguous()
+        self._dW(dloc_in, self.fused, B * T, h, d, self.Gw(CON + "local_proj_in.weight"), self.G32(CON + "local_proj_in.bias"))
+        dfused16 = torch.empty(B * T, d, dtype=BF16, device=dev)
+        H.gemm(dloc_in, con.W16(CON + "local_proj_in.weight"), dfused16, B * T, d, h, trans_b=True, ldb=d)
+        H.orca_local_mix_bwd(dfused16, self.enc_all, con.P32(CON + "local_layer_weights"), self.nt, B * T, d, self.G32(CON + "local_layer_weights"))
+        # ---- global branch (the Q-Former under the ORCA names): spliced-token gradient + what the losses / the injection added
+        dg = (self.dglobal32 + d_af.float()).to(BF16)
+        con.backward(dg)
 
     def losses(self, global16: torch.Tensor, local16: Optional[torch.Tensor], B: int) -> "OrderedDict[str, torch.Tensor]":
         """`compute_orca_losses` (:1159-1206): 0-d fp32 device tensors, weighted like the reference's."""
@@ -1486,7 +1636,7 @@ class CausalLMHIP:
         H.causal_lm_loss(self.logits, self.Vp, labels, self.B, self.S, self.V, self.loss, write_grad=write_grad)
         return self.loss
 
-    def backward(self, first_needed_pos: int = 0, out_rows: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+    def backward(self, first_needed_pos: int = 0, out_rows: Optional[Tuple[int, int]] = None, layer_hook_bwd=None) -> torch.Tensor:
         """dlogits (in self.logits) -> dL/d inputs_embeds [B*S, h] bf16.  In the position-major training layout only the rows of
         positions >= first_needed_pos (the first audio span of the batch) are propagated: the rows in front of it are frozen
         text embeddings whose gradient nothing consumes (under the causal mask they do not feed any needed row either).
@@ -1523,6 +1673,8 @@ class CausalLMHIP:
         aw = self.hq * self.hd
         for i in reversed(range(self.L)):
             ly, s = self.layers[i], self.sv[i]
+            if layer_hook_bwd is not None:                                                    # ORCA: back through the injection behind this layer (dx in place)
+                layer_hook_bwd(i, dx)
             a0 = tl if i == self.L - 1 else r0                                                # first row with a non-zero d(layer output)
             Ma = M - a0
             if Ma > 0:
@@ -1798,7 +1950,8 @@ class DeSTA25AudioModel:
             kv_start = (attention_mask == 0).sum(dim=1).to(torch.int32).contiguous()
             h = cfg.llm_config.hidden_size
             if self.orca is not None:
-                return self._forward_orca(input_ids, attention_mask, batch_transcription_ids, batch_start_positions, labels, af, src, kv_start, N_audio)
+                return self._forward_orca(input_ids, attention_mask, batch_transcription_ids, batch_start_positions, labels, af, src, kv_start, N_audio,
+                                          keep_logits=bool(kwargs.get("keep_logits", False)))
 
             def fill(buf):
                 H.embed_gather(self.llm.embed, af, src, B * S, h, buf)
@@ -1830,24 +1983,24 @@ class DeSTA25AudioModel:
                              has_grad=labels is not None and self.training and (N_audio > 0 or self.llm.lora is not None), s_major=s_major)
         return _Out(loss, out_logits)
 
-    def _forward_orca(self, input_ids, attention_mask, batch_transcription_ids, batch_start_positions, labels, af, src, kv_start, N_audio):
-        """The ORCA branch of the reference's forward (modeling_desta25.py:775-841), FORWARD ONLY: global tokens spliced at the audio
+    def _forward_orca(self, input_ids, attention_mask, batch_transcription_ids, batch_start_positions, labels, af, src, kv_start, N_audio, keep_logits=False):
+        """The ORCA branch of the reference's forward (modeling_desta25.py:775-841): global tokens spliced at the audio
         positions, the local tokens injected behind every decoder layer through the gated cross-attention, LM loss + `orca_losses`
-        (the trainer adds them up, desta_trainer.py:56-92).  Batch-major token grid, logits kept.  One audio per text row, in row
+        (the trainer adds them up, desta_trainer.py:56-92).  Batch-major token grid; in training mode the activations the backward needs
+        are kept (`OrcaHIP.sv`) and `backward()` returns the gradients of that total loss.  One audio per text row, in row
         order: the reference's cross-attention pairs audio row b with text row b (`query=hidden_states, key=audio_local`, :447-453)."""
         cfg, dev, orca = self.config, self.device, self.orca
         B, S = input_ids.shape
         hdim, V = cfg.llm_config.hidden_size, cfg.llm_config.vocab_size
         local16, spans = None, None
+        need_grad = bool(self.training and labels is not None and N_audio > 0)
         if N_audio > 0:
             rows = [int(r) for r, _ in batch_start_positions]
             assert N_audio == B and rows == list(range(B)), "orca_hybrid: one audio per text row, in row order"
-            if self.connector.p_drop > 0.0:
-                raise NotImplementedError("orca_hybrid: Q-Former dropout in the global branch needs the backward, which is not built (forward-only slice)")
             local16 = orca.local_forward(self.enc_all, N_audio)
             Kg = cfg.orca_global_num_tokens
             spans = [(int(r), int(s) + Kg, int(s) + Kg + int(t.numel())) for (r, s), t in zip(batch_start_positions, batch_transcription_ids)]
-            orca.begin(af, local16, B, S, spans, self.training)
+            orca.begin(af, local16, B, S, spans, self.training, save=need_grad)
             hook = orca.inject
         else:
             orca.audio, orca.aligns = None, []
@@ -1855,16 +2008,18 @@ class DeSTA25AudioModel:
 
         def fill(buf):
             H.embed_gather(self.llm.embed, af, src, B * S, hdim, buf)
-        logits = self.llm.forward(fill, B, S, kv_start, labels, False, layer_hook=hook)
+        logits = self.llm.forward(fill, B, S, kv_start, labels, need_grad, layer_hook=hook)
         out_logits = logits.view(B, S, self.llm.Vp)[:, :, :V]
         loss = None
         if labels is not None:
-            loss = self.llm.loss_and_grad(labels.to(dev).contiguous(), write_grad=False).clone().view(())
+            if need_grad:                                                    # dlogits overwrite the logits buffer (as on the qformer_1 path)
+                out_logits = out_logits.clone() if keep_logits else None
+            loss = self.llm.loss_and_grad(labels.to(dev).contiguous(), write_grad=need_grad).clone().view(())
         out = _Out(loss, out_logits)
         out.orca_losses = orca.losses(af, local16, B) if N_audio > 0 else OrderedDict()
         out.audio_global = af.view(B, cfg.orca_global_num_tokens, hdim) if N_audio > 0 else None
         out.audio_local = local16.view(B, -1, hdim) if local16 is not None else None
-        self._fwd = dict(orca=True, has_grad=False)
+        self._fwd = dict(orca=True, has_grad=need_grad, B=B, S=S, N_audio=N_audio, starts=[(int(r), int(s)) for r, s in batch_start_positions], s_major=False)
         return out
 
     __call__ = forward
@@ -2147,9 +2302,19 @@ class DeSTA25AudioModel:
     def backward_llm(self) -> torch.Tensor:
         """First half of `backward`: dX through the frozen LLM down to the audio rows; returns dL/d audio_features [N_audio*K, h]."""
         f = self._fwd
-        if f and f.get("orca"):
-            raise NotImplementedError("orca_hybrid: the backward (connector local branch, gated cross-attention of every decoder layer, "
-                                      "auxiliary losses) is not built yet — forward-only first slice, SURVEY.md §8f-4b")
+        if f and f.get("orca") and f["has_grad"]:
+            # gradient of the trainer's total loss = LM loss + sum of the ORCA losses (desta_trainer.py:56-92)
+            K, S, B = self.audio_tokens, f["S"], f["B"]
+            with torch.cuda.device(self.device):
+                self.arena.grads.zero_()
+                self.orca.begin_backward()
+                dx0 = self.llm.backward(layer_hook_bwd=self.orca.inject_bwd)
+                idx = self._audio_slots(f["starts"], B, S, False)[2]
+                d_af = torch.empty(f["N_audio"] * K, self.config.llm_config.hidden_size, dtype=BF16, device=self.device)
+                H.gather_rows(dx0, idx, f["N_audio"] * K, self.config.llm_config.hidden_size, d_af)
+                self.orca.backward_tail(d_af)
+            self._fwd = None
+            return None
         if not f or not f["has_grad"]:
             raise RuntimeError("backward() needs a training-mode forward with labels and at least one audio")
         K, S, B = self.config.prompt_size, f["S"], f["B"]

@@ -45,7 +45,7 @@ class TrainingArguments:
     overlap_comm: bool = True
     overlap_connector_backward: bool = False       # with overlap_comm: the connector's backward ALSO runs on the side stream (bit-identical results; round 3: -0.4 ms WITHOUT the encoder stream; round 4, beside `overlap_encoder`: +0.5 ms and 4x the step-time spread, same-box A/B -> off)
     overlap_encoder: bool = True                   # next batch's frozen Whisper forward on its own HIP stream beside the connector / LLM of the current batch (bit-identical results; default since round 4)
-    side_stream_priority: int = 1                  # HIP priority of the encoder-prefetch and optimizer-tail streams (lower number = higher priority; 0 = the main stream's): 1 = below the main stream, so the critical path's blocks are dispatched first and the side work fills idle CUs
+    side_stream_priority: int = 0                  # HIP priority of the encoder-prefetch and optimizer-tail streams.  gfx950 offers (least, greatest) = (0, -1): nothing BELOW the default stream's 0 exists, so the side work cannot be demoted; promoting the main work instead (the whole step on a priority -1 stream, `bench.py --main-priority -1`) measured -0.5 ms (0.3 %) and is not shipped (every caller of the trainer would have to order its own default-stream work against that stream)
     save_strategy: str = "no"                      # "epoch" (train_desta.py:146, enable_checkpointing) | "no"
     steps_per_epoch: Optional[int] = None          # len(train dataloader) = MICRO-batches per epoch when the dataset is not sized (synthetic streams)
     eval_strategy: str = "no"                      # "steps" (every eval_steps optimizer steps) | "epoch" | "no" (train_desta.py:147-148)
@@ -169,8 +169,21 @@ class DeSTA25Trainer:
         total_loss = lm_loss
         # device scalars only: materialised in `_flush_logs` (the reference's 3 x .item() per step
         # serialise host and device every step, SURVEY §2.2 last row)
-        self.log({"train/lm_loss": lm_loss, "train/ppl": torch.exp(lm_loss), "train/loss": total_loss,
-                  "train/learning_rate": self.get_last_lr()})
+        log = {"train/lm_loss": lm_loss, "train/ppl": torch.exp(lm_loss)}
+        orca = getattr(outputs, "orca_losses", None)
+        if orca and getattr(getattr(model, "config", None), "connector_mode", "") == "orca_hybrid":
+            # desta_trainer.py:67-92: every ORCA auxiliary loss is added to the LM loss (already weighted) and logged under its name
+            orca_total = None
+            for name, l in orca.items():
+                if l is not None:
+                    total_loss = total_loss + l
+                    orca_total = l if orca_total is None else orca_total + l
+                    log[f"train/{name}"] = l
+            if orca_total is not None:
+                log["train/orca_total"] = orca_total
+        log["train/loss"] = total_loss
+        log["train/learning_rate"] = self.get_last_lr()
+        self.log(log)
         return (total_loss, outputs) if return_outputs else total_loss
 
     def log(self, d: Dict[str, Any]) -> None:

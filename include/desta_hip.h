@@ -263,7 +263,7 @@ int desta_tap_mix_bwd(const float* x, const float* layer_weights, const float* d
                       int prompt, int d, float* dx, float* dlayer_weights, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * ORCA hybrid connector / deep injection, FORWARD ONLY (ABI 6; SURVEY §8f-4b, first slice).  The ORCA branch shares the GEMM,
+ * ORCA hybrid connector / deep injection (ABI 6).  The ORCA branch shares the GEMM,
  * attention and LayerNorm entry points with the qformer_1 path; these are the row-wise pieces it adds
  * (/root/reference/desta/models/modeling_desta25.py, line numbers per entry).  All bf16 streams, fp32 arithmetic.
  *   desta_orca_local_mix      :336-343  out[r,:] = sum_l softmax(layer_weights)[l] x[l,r,:]; x [taps][rows][d], taps <= 8
@@ -275,6 +275,16 @@ int desta_tap_mix_bwd(const float* x, const float* layer_weights, const float* d
  *                             L2-normalised rows; y rows picked through y_index[ny] (NULL: 0..ny-1) out of y_rows per batch entry
  *   desta_orca_align          :460-486  out[e] = 1 - cos(mean_t audio[e,t,:], mean_{s0 <= s < s1} hidden[row, s, :]),
  *                             spans[e] = (text row, s0, s1); hidden addressed as row * batch_stride + s * row_stride */
+/* Backward pieces (autograd of the modules above; gradients of the trainer's total loss = LM loss + sum of the ORCA losses):
+ *   desta_orca_gate_residual_bwd  d_cross[m,:] = gate[m] d_out[m,:];  d_gate_pre[m] = (d_out[m,:] . cross[m,:]) gate[m] (1 - gate[m])
+ *   desta_orca_gate_mlp_bwd       d_preact = d_gate_pre (x) w2 * gelu'(preact);  d_w2 = sum_m d_gate_pre[m] gate_hidden[m,:];  d_b2 = sum_m d_gate_pre[m]
+ *   desta_orca_align_bwd          d_hidden[row, s, :] += coef * d(1 - cos)/d(mean over the span) / span length   (audio pooled under no_grad, :461-462)
+ *   desta_orca_rope_bwd           rotation by the negative angle of the fp32 gradient of the rotated tokens, ADDED to d_first (tokens [0, n_first)
+ *                                 of every clip: the global tokens under orca_global_cross_attn) resp. d_rest (the local tokens)
+ *   desta_orca_col2im_add         gradient of the Conv1d's im2col view: d_padded[b,t,:] = sum of the d_col windows that cover row t (bf16)
+ *   desta_orca_local_mix_bwd      d(local_layer_weights) through the softmax (workspace: 2048 floats)
+ *   desta_orca_sim_loss_bwd       d_x += gradient of coef * sum_ij (xhat_i . yhat_j - [identity])^2 w.r.t. the un-normalised rows of x (fp32, added;
+ *                                 rows of x / d_x and of y picked through optional index lists; ny <= 128) */
 int desta_orca_local_mix(const void* x, const float* layer_weights, int taps, int64_t rows, int d, void* out, void* stream);
 int desta_orca_rope(const void* x, void* y, int batch, int tokens, int hidden, float theta, float position_scale, int round_cos_sin, void* stream);
 int desta_orca_gate_residual(void* hidden, int64_t ld_hidden, const void* cross, const void* gate_hidden, const float* gate_w2, const float* gate_b2,
@@ -283,6 +293,19 @@ int desta_orca_sim_loss(const void* x, const void* y, const int32_t* y_index, in
                         int subtract_identity, float* partials, void* stream);
 int desta_orca_align(const void* audio, int tokens, const void* hidden, int64_t hidden_row_stride, int64_t hidden_batch_stride, int hidden_size,
                      const int32_t* spans, int n_spans, float* out, void* stream);
+int desta_orca_gate_residual_bwd(const void* d_out, int64_t ld, const void* cross, const float* gate, int64_t rows, int hidden_size, void* d_cross,
+                                 float* d_gate_pre, void* stream);
+int desta_orca_gate_mlp_bwd(const float* d_gate_pre, const void* gate_preact, const void* gate_hidden, const float* gate_w2, int64_t rows, int gate_width,
+                            void* d_preact, float* d_w2, float* d_b2, void* stream);
+int desta_orca_align_bwd(const void* audio, int tokens, const void* hidden, int64_t hidden_row_stride, int64_t hidden_batch_stride, int hidden_size,
+                         const int32_t* spans, int n_spans, float coef, void* d_hidden, int64_t d_row_stride, int64_t d_batch_stride, void* stream);
+int desta_orca_rope_bwd(const float* d_rotated, int batch, int tokens, int hidden, float theta, float position_scale, int round_cos_sin, int n_first,
+                        float* d_first, float* d_rest, void* stream);
+int desta_orca_col2im_add(const void* d_col, int batch, int tokens_out, int tokens_padded, int hidden, int kernel, int stride, void* d_padded, void* stream);
+int desta_orca_local_mix_bwd(const void* d_out, const void* x, const float* layer_weights, int taps, int64_t rows, int d, float* d_layer_weights,
+                             float* workspace, void* stream);
+int desta_orca_sim_loss_bwd(const void* x, const int32_t* x_index, int64_t x_rows, const void* y, const int32_t* y_index, int64_t y_rows, int batch, int nx,
+                            int ny, int hidden, int subtract_identity, float coef, float* d_x, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Flash-style attention, forward and backward (bf16 operands, fp32 softmax, MFMA 32x32x16).

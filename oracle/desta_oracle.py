@@ -609,7 +609,8 @@ def decay_mask(names: List[str]) -> List[bool]:
     ``proj.0`` is an nn.LayerNorm module so both of its tensors are not."""
     out = []
     for n in names:
-        nd = ("bias" in n) or ("LayerNorm" in n) or (".proj.0." in n) or ("layernorm" in n) or ("layer_norm" in n)
+        nd = (("bias" in n) or ("LayerNorm" in n) or (".proj.0." in n) or ("layernorm" in n) or ("layer_norm" in n)
+              or (".global_proj.0." in n) or (".local_ln." in n) or n.endswith(".ln.weight"))          # ORCA: nn.LayerNorm modules under other names
         out.append(not nd)
     return out
 

@@ -1,4 +1,4 @@
-"""GPU: ORCA hybrid, first slice — the product's FORWARD for `connector_mode="orca_hybrid"` against the golden made by
+"""GPU: ORCA hybrid — the product's forward AND backward for `connector_mode="orca_hybrid"` against the golden made by
 the reference's own ORCAHybridConnector / ORCAGatedCrossAttention / compute_orca_losses / forward (tests/golden/ref_orca_tiny.safetensors,
 tests/golden/make_golden_from_reference.py::make_orca_case; the CPU oracle restatement is pinned to the same file in
 tests/test_oracle_pin.py).  Tolerances: the product computes in bf16 with fp32 accumulation / statistics like the reference under
@@ -64,11 +64,23 @@ def test_orca_forward_vs_reference_golden(golden_dir):
     out_e = model(**batch)
     assert "L_align_layerwise" not in out_e.orca_losses and "L_ortho_diversity" in out_e.orca_losses
     assert rel_err(out_e.logits.float().cpu()[m], g["logits_eval"][m]) < 2e-2
-    # forward-only slice: the backward and generation with deep injection say so
+    # backward: every gradient of the trainer's total loss (LM + the three ORCA terms) against the reference's own autograd
     model.train()
-    model(**batch)
-    with pytest.raises(NotImplementedError, match="backward"):
-        model.backward()
+    out = model(**batch)
+    assert out.logits is None                                                               # dlogits took the buffer, as on the qformer_1 path
+    model.backward()
+    names = R.trainable_names(d, o)
+    gn = sorted(float(g["grad::" + n].double().norm()) for n in names)
+    floor = gn[len(gn) // 2] * 1e-2
+    errs = {n: float((model.arena.grad(n).double().cpu() - g["grad::" + n].double().reshape(model.arena.shapes[n])).norm()
+                     / max(float(g["grad::" + n].double().norm()), floor)) for n in names}
+    a = torch.cat([model.arena.grad(n).reshape(-1).double().cpu() for n in names])
+    b = torch.cat([g["grad::" + n].reshape(-1).double() for n in names])
+    worst = sorted(errs, key=errs.get)[-6:]
+    print("orca backward: whole arena rel", float((a - b).norm() / b.norm()), "cos", float((a @ b) / (a.norm() * b.norm())),
+          [(n.replace("perception.connector.", "").replace("orca_cross_attns.", "x."), round(errs[n], 4)) for n in reversed(worst)])
+    assert float((a - b).norm() / b.norm()) < 3e-2 and float((a @ b) / (a.norm() * b.norm())) > 0.999
+    assert errs[worst[-1]] < 8e-2, (worst[-1], errs[worst[-1]])
     # config round trip keeps the mode and every orca_* field
     c2 = DeSTA25Config(**{k: v for k, v in cfg.to_dict().items() if k not in ("model_type", "info")})
     assert c2.connector_mode == "orca_hybrid" and c2.orca_global_num_tokens == cfg.orca_global_num_tokens and c2.orca_enabled
@@ -125,3 +137,44 @@ def test_orca_kernels_vs_oracle(golden_dir):
     H.orca_align(a.cuda(), T, hid.cuda(), Hd, S * Hd, Hd, spans.cuda(), 3, outa)
     ra = torch.stack([1 - torch.nn.functional.cosine_similarity(a[i].float().mean(0), hid[r, s0:s1].float().mean(0), dim=0) for i, (r, s0, s1) in enumerate(spans.tolist())])
     assert float((outa.cpu() - ra).abs().max()) < 1e-4
+
+
+def test_orca_trainer_steps_follow_the_oracle(golden_dir):
+    """Three optimizer steps of `DeSTA25Trainer` on the ORCA model (total loss = LM + ORCA terms, clip 1.0, Adafactor over the whole
+    ORCA parameter set: connector + 2 x gated cross-attention) against the oracle's `train`-style restatement: same total loss per
+    step to bf16 noise, parameters move, loss goes down."""
+    from desta.models.modeling_desta25 import DeSTA25AudioModel
+    from desta.trainer.desta_trainer import DeSTA25Trainer, TrainingArguments
+    import orca_oracle
+    g, d, o, w, batch, cfg = _case(golden_dir)
+    model = DeSTA25AudioModel(cfg, weights=w)
+    tr = DeSTA25Trainer(model, args=TrainingArguments(learning_rate=2e-3, warmup_steps=0, max_steps=3, logging_steps=1, overlap_comm=False, overlap_encoder=False))
+    names = R.trainable_names(d, o)
+    wo = {k: v.clone() for k, v in w.items()}
+    st = O.adafactor_init([wo[n] for n in names])
+    theta = float(g["rope_theta_used"])
+    orig = orca_oracle.rope_whole_vector
+    orca_oracle.rope_whole_vector = lambda x, th, sc: orig(x, theta, sc)
+    try:
+        hip, ref = [], []
+        for i in range(3):
+            hip.append(float(tr.training_step(batch)))
+            for n in names:
+                wo[n].requires_grad_(True)
+                wo[n].grad = None
+            loss, _, losses = R.model_forward(wo, d, o, batch, training=True)
+            tot = R.total_loss(loss, losses)
+            tot.backward()
+            grads = [wo[n].grad.detach().clone() for n in names]
+            params = [wo[n].detach() for n in names]
+            O.clip_grad_norm(grads, 1.0)
+            O.adafactor_step(params, grads, st, O.linear_warmup_lr(i, 2e-3, 0, 3), [0.01 if dm else 0.0 for dm in O.decay_mask(names)])
+            for n, p_ in zip(names, params):
+                wo[n] = p_.detach()
+            ref.append(float(tot))
+    finally:
+        orca_oracle.rope_whole_vector = orig
+    print("orca trainer: total loss HIP", hip, "oracle", ref)
+    assert all(abs(a - b) < 2e-2 for a, b in zip(hip, ref)), (hip, ref)
+    assert hip[-1] < hip[0]
+    assert set(tr.log_history[0]) >= {"train/lm_loss", "train/L_ortho_diversity", "train/L_align_layerwise", "train/orca_total", "train/loss"}
