@@ -44,7 +44,7 @@ def test_orca_forward_vs_reference_golden(golden_dir):
     for n in R.trainable_names(d, o):
         assert torch.equal(model.arena.param(n).cpu(), w[n].reshape(model.arena.shapes[n])), n
     model.train()
-    out = model(**batch)
+    out = model(**batch, keep_logits=True)
     m = g["attention_mask"].bool()
     rec = dict(dloss=abs(float(out.loss) - float(g["loss"])), logits=rel_err(out.logits.float().cpu()[m], g["logits"][m]),
                global_tokens=rel_err(out.audio_global.float().cpu(), g["global_tokens"]), local_tokens=rel_err(out.audio_local.float().cpu(), g["local_tokens"]),
