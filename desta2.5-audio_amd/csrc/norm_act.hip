@@ -737,14 +737,15 @@ extern "C" int desta_layernorm_bwd(const void* dy, int dy_f32, const void* x, in
                                    const float* stats, int rows, int cols, float* dx_f32, void* dx_bf16, float* dgamma,
                                    float* dbeta, int accumulate, float* workspace, void* stream) {
     DESTA_CHECK_ARG(dy && x && gamma && stats && (dx_f32 || dx_bf16), "layernorm_bwd: null argument");
-    DESTA_CHECK_ARG(rows > 0 && cols % 8 == 0 && cols <= 2048, "layernorm_bwd: cols=%d must be a multiple of 8, <= 2048", cols);
+    DESTA_CHECK_ARG(rows > 0 && cols % 8 == 0 && cols <= 4096, "layernorm_bwd: cols=%d must be a multiple of 8, <= 4096", cols);
     DESTA_CHECK_ARG(!dgamma || (dbeta && workspace), "layernorm_bwd: dgamma needs dbeta and workspace");
     int nb = (rows + RPB - 1) / RPB;
     if (nb > 512) nb = 512;                                    // two blocks per CU (128 left half the chip idle: 19.5 us per call, 0.15 of the HBM rate)
     float* part = dgamma ? workspace : nullptr;
     if (cols <= 512) hipLaunchKernelGGL((layernorm_bwd_k<1>), dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, dy_f32, x, x_f32, gamma, stats, rows, cols, dx_f32, (bf16_t*)dx_bf16, part);
     else if (cols <= 1024) hipLaunchKernelGGL((layernorm_bwd_k<2>), dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, dy_f32, x, x_f32, gamma, stats, rows, cols, dx_f32, (bf16_t*)dx_bf16, part);
-    else hipLaunchKernelGGL((layernorm_bwd_k<4>), dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, dy_f32, x, x_f32, gamma, stats, rows, cols, dx_f32, (bf16_t*)dx_bf16, part);
+    else if (cols <= 2048) hipLaunchKernelGGL((layernorm_bwd_k<4>), dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, dy_f32, x, x_f32, gamma, stats, rows, cols, dx_f32, (bf16_t*)dx_bf16, part);
+    else hipLaunchKernelGGL((layernorm_bwd_k<8>), dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, dy_f32, x, x_f32, gamma, stats, rows, cols, dx_f32, (bf16_t*)dx_bf16, part);   // ORCA's LayerNorms over the LLM width (4096): 256 live floats per lane, off the hot path
     if (dgamma)
         hipLaunchKernelGGL(reduce_partials_k, dim3((2 * cols + 63) / 64), dim3(1024), 0, (hipStream_t)stream,
                            (const float*)part, nb, 2 * cols, dgamma, dbeta, cols, accumulate);

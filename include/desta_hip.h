@@ -189,7 +189,7 @@ int desta_logmel_f32(const float* wave, int batch, int n_samples, int64_t wave_s
  *   TF:models/bert/modeling_bert.py:296,350 (eps 1e-12), modeling_desta25.py:166; x is fp32 or bf16,
  *   outputs bf16 and/or fp32; stats [rows][2] = (mean, rstd) saved for backward.
  * layernorm_bwd: dx (fp32 and/or bf16) and dgamma/dbeta (written, or added when accumulate != 0);
- *   cols <= 2048; workspace from desta_layernorm_bwd_workspace_floats.
+ *   cols <= 4096; workspace from desta_layernorm_bwd_workspace_floats.
  * RMSNorm: LlamaRMSNorm TF:models/llama/modeling_llama.py:53-67 (bf16 in/out, fp32 weight copy);
  *   rmsnorm_bwd returns dx = dres + d(norm) (dres may be NULL), frozen weight (no dweight). */
 int desta_layernorm_fwd(const void* x, int x_f32, const float* gamma, const float* beta, float eps, int rows,

@@ -26,7 +26,7 @@ def rel_err(a, b):
     return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
 
 
-@pytest.mark.parametrize("rows,cols,f32in", [(37, 1280, True), (64, 384, False), (5, 128, True), (12, 2048, False)])
+@pytest.mark.parametrize("rows,cols,f32in", [(37, 1280, True), (64, 384, False), (5, 128, True), (12, 2048, False), (9, 4096, True), (70, 2560, False)])
 def test_layernorm_fwd_bwd(hip, rows, cols, f32in):
     g = torch.Generator().manual_seed(rows + cols)
     x = torch.randn(rows, cols, generator=g) * 2 + 0.5

@@ -79,8 +79,9 @@ def test_orca_forward_vs_reference_golden(golden_dir):
     worst = sorted(errs, key=errs.get)[-6:]
     print("orca backward: whole arena rel", float((a - b).norm() / b.norm()), "cos", float((a @ b) / (a.norm() * b.norm())),
           [(n.replace("perception.connector.", "").replace("orca_cross_attns.", "x."), round(errs[n], 4)) for n in reversed(worst)])
-    assert float((a - b).norm() / b.norm()) < 3e-2 and float((a @ b) / (a.norm() * b.norm())) > 0.999
-    assert errs[worst[-1]] < 8e-2, (worst[-1], errs[worst[-1]])
+    # measured: whole arena 6.5e-3 (cosine 0.99998), worst tensor 2.1 % (a gate-MLP bias); bounds at 3x
+    assert float((a - b).norm() / b.norm()) < 2e-2 and float((a @ b) / (a.norm() * b.norm())) > 0.9995
+    assert errs[worst[-1]] < 6.5e-2, (worst[-1], errs[worst[-1]])
     # config round trip keeps the mode and every orca_* field
     c2 = DeSTA25Config(**{k: v for k, v in cfg.to_dict().items() if k not in ("model_type", "info")})
     assert c2.connector_mode == "orca_hybrid" and c2.orca_global_num_tokens == cfg.orca_global_num_tokens and c2.orca_enabled
@@ -175,6 +176,6 @@ def test_orca_trainer_steps_follow_the_oracle(golden_dir):
     finally:
         orca_oracle.rope_whole_vector = orig
     print("orca trainer: total loss HIP", hip, "oracle", ref)
-    assert all(abs(a - b) < 2e-2 for a, b in zip(hip, ref)), (hip, ref)
+    assert all(abs(a - b) < 6e-3 for a, b in zip(hip, ref)), (hip, ref)                    # measured 6e-4 / 1.1e-3 / 1.4e-3
     assert hip[-1] < hip[0]
     assert set(tr.log_history[0]) >= {"train/lm_loss", "train/L_ortho_diversity", "train/L_align_layerwise", "train/orca_total", "train/loss"}
