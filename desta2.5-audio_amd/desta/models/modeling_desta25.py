@@ -1030,13 +1030,16 @@ class OrcaHIP:
         return self.local16
 
     # -- deep injection
-    def begin(self, global16: torch.Tensor, local16: Optional[torch.Tensor], B: int, S: int, spans, training: bool, save: bool = False) -> None:
+    def begin(self, global16: torch.Tensor, local16: Optional[torch.Tensor], B: int, S: int, spans, training: bool, save: bool = False,
+              keep_kv: bool = False) -> None:
         """Audio tokens the gated cross-attention of every layer attends to (modeling_desta25.py:792-806): the local tokens, or
         global | local with `orca_global_cross_attn`; rotated ONCE (the rotation does not depend on the layer, :422-438)."""
         cfg, h, dev = self.cfg, self.h, self.dev
         self.audio = None
         self.aligns: List[torch.Tensor] = []
         self.save, self.sv = bool(save), [dict() for _ in range(self.L)]
+        self.kv_layers: Optional[List[Optional[torch.Tensor]]] = [None] * self.L if keep_kv else None
+        self.decoding = False
         self.global16, self.local16_in = global16, local16
         if not cfg.orca_deep_injection_enabled:
             return
@@ -1067,6 +1070,18 @@ class OrcaHIP:
             else:
                 self.spans = torch.tensor([(b, 0, S) for b in range(B)], dtype=torch.int32, device=dev)
 
+    def begin_decode(self) -> None:
+        """generate(): after the prompt pass (`begin(..., keep_kv=True)` + `inject` per layer) every decode step injects into ONE new
+        row per sequence; the audio keys / values of each layer do not change between steps and stay in `kv_layers`."""
+        if self.audio is None:
+            return
+        B, h, dev = self.Bq, self.h, self.dev
+        self.M, self.S, self.decoding = B, 1, True
+        self.q16, self.att16 = torch.empty(B, h, dtype=BF16, device=dev), torch.empty(B, h, dtype=BF16, device=dev)
+        self.lse = torch.empty(B, self.heads, 1, dtype=F32, device=dev)
+        self.cross32, self.cross16 = torch.empty(B, h, dtype=F32, device=dev), torch.empty(B, h, dtype=BF16, device=dev)
+        self.g1 = torch.empty(B, h // 4, dtype=BF16, device=dev)
+
     def inject(self, l: int, x: torch.Tensor) -> None:
         """x [B*S, h] bf16 = output of decoder layer l (batch-major rows), updated IN PLACE: x + sigmoid(gate(x)) * LN(cross_attn(x, audio))."""
         if self.audio is None:
@@ -1094,7 +1109,12 @@ class OrcaHIP:
             q16, kv16, att16, lse, cross32, cross16, g1, g1pre, st, gate = (self.q16, self.kv16, self.att16, self.lse, self.cross32, self.cross16, self.g1,
                                                                             None, None, None)
         H.gemm(x, w_in[:h], q16, M, h, h, bias=b_in[:h])
-        H.gemm(self.audio, w_in[h:], kv16, B * Ta, 2 * h, h, bias=b_in[h:])
+        if self.decoding:
+            kv16 = self.kv_layers[l]                                             # projected in the prompt pass
+        else:
+            if self.kv_layers is not None:
+                kv16 = self.kv_layers[l] = torch.empty(B * Ta, 2 * h, dtype=BF16, device=dev)
+            H.gemm(self.audio, w_in[h:], kv16, B * Ta, 2 * h, h, bias=b_in[h:])
         ad = H.attn_desc(q16, kv16, kv16, att16, lse, batch=B, hq=self.heads, hkv=self.heads, sq=S, sk=Ta, hd=self.hd,
                          scale=self.hd ** -0.5, q_off=0, k_off=0, v_off=h)
         H.attention_fwd(ad)
@@ -1546,7 +1566,7 @@ class CausalLMHIP:
         self.g_logits = torch.zeros(B, self.Vp, dtype=BF16, device=dev)
         self.g_next = torch.zeros(B, dtype=torch.int64, device=dev)
 
-    def decode_step(self, tokens: torch.Tensor, cur: int, kv_start: torch.Tensor, pos_shift: torch.Tensor) -> torch.Tensor:
+    def decode_step(self, tokens: torch.Tensor, cur: int, kv_start: torch.Tensor, pos_shift: torch.Tensor, layer_hook=None) -> torch.Tensor:
         """One token per sequence: `tokens` [B] (ids) sit at cache slot `cur`; returns logits [B, Vp] for slot cur+1."""
         c, h, B = self.c, self.h, self._gen_shape[0]
         Smax = self._gen_shape[1]
@@ -1573,16 +1593,20 @@ class CausalLMHIP:
             H.gemm(self.g_att, ly["wo"], self.g_xm, B, h, self.hq * self.hd, residual=x)
             proj(self.g_xm, ly["n2"], ly["wgu"], self.g_act, self.I, act=4)                    # norm + gate|up projection + SwiGLU
             H.gemm(self.g_act, ly["wd"], self.g_x, B, h, self.I, residual=self.g_xm)
+            if layer_hook is not None:                                        # ORCA deep injection on the new row of every sequence
+                layer_hook(li, self.g_x)
         proj(self.g_x, self.norm, self.head, self.g_logits, self.V, ldc=self.Vp)
         return self.g_logits
 
     def generate_greedy(self, x0_filler, B: int, S: int, kv_start: torch.Tensor, max_new_tokens: int, pad_token_id: int,
                         eos_token_ids=None, forced_tokens: Optional[torch.Tensor] = None, collect_logits: bool = False,
-                        do_sample: bool = False, temperature: float = 1.0, top_p: float = 1.0, seed: int = 0):
+                        do_sample: bool = False, temperature: float = 1.0, top_p: float = 1.0, seed: int = 0, layer_hook=None,
+                        after_prompt=None):
         """Prompt pass + KV-cached decode (greedy, or temperature / top-p sampling with the library's counter RNG).  Returns new token ids [B, n_new] (int64; finished sequences are
         filled with pad_token_id, generation stops early once every sequence has produced an EOS), and, with
         collect_logits, the per-step logits [n_new, B, V] (bf16).  `forced_tokens` [B, T] teacher-forces the
-        continuation (parity tests compare per-step logits with the oracle on the same prefix)."""
+        continuation (parity tests compare per-step logits with the oracle on the same prefix).  `layer_hook(l, x)` runs behind every
+        decoder layer of the prompt pass ([B*S, h]) and of every decode step ([B, h]); `after_prompt()` between the two."""
         assert max_new_tokens >= 1
         Smax = S + max_new_tokens
         self._gen_alloc(B, Smax)
@@ -1590,7 +1614,9 @@ class CausalLMHIP:
         kv_start = kv_start.to(torch.int32).contiguous()
         neg_pad = (-kv_start).contiguous()                                   # prompt: position = index - left_pad
         logits = self.forward(x0_filler, B, S, kv_start, None, False, pos_shift=neg_pad, cos_sin=self.gen_cos_sin, last_logits=self.g_logits,
-                              kv_cache=self.kv_cache)
+                              kv_cache=self.kv_cache, layer_hook=layer_hook)
+        if after_prompt is not None:
+            after_prompt()
         out = torch.full((B, max_new_tokens), int(pad_token_id), dtype=torch.int64, device=dev)
         steps_logits = []
         finished = torch.zeros(B, dtype=torch.bool, device=dev)
@@ -1615,7 +1641,7 @@ class CausalLMHIP:
                 break
             cur = S + t
             shift = (cur - kv_start).to(torch.int32).contiguous()            # decode: position = slot - left_pad
-            logits = self.decode_step(nxt, cur, kv_start, shift)
+            logits = self.decode_step(nxt, cur, kv_start, shift, layer_hook=layer_hook)
         if eos is not None and n_new > 1:                                    # trim columns after every sequence finished
             done_at = (out.unsqueeze(2) == eos.view(1, 1, -1)).any(dim=2).int().argmax(dim=1)
             has = (out.unsqueeze(2) == eos.view(1, 1, -1)).any(dim=2).any(dim=1)
@@ -2033,9 +2059,6 @@ class DeSTA25AudioModel:
         ignored, as the reference nulls them).  do_sample=True: temperature -> top-p -> one multinomial draw per step
         with the library's counter RNG (`seed`; same distribution as HF, not torch's random stream)."""
         cfg, dev = self.config, self.device
-        if self.orca is not None and cfg.orca_deep_injection_enabled:
-            raise NotImplementedError("orca_hybrid: generation with deep injection (the gated cross-attention inside the KV-cached decode, "
-                                      "modeling_desta25.py:1375-1408) is not built yet — forward-only first slice")
         input_ids = inputs["context_input_ids"].to(dev)                      # only the context (prompt) part of the batch
         attention_mask = inputs["context_attention_mask"].to(dev)
         B, S = input_ids.shape
@@ -2064,6 +2087,16 @@ class DeSTA25AudioModel:
 
                 def fill(buf):
                     H.embed_gather(self.llm.embed, af, src, B * S, h, buf)
+                hook = after = None
+                if self.orca is not None and N_audio > 0:
+                    # ORCA branch (modeling_desta25.py:1375-1408): global tokens spliced above; the audio tokens reach every decoder layer
+                    # through the gated cross-attention, at the prompt pass and at every KV-cached step (no alignment loss in eval mode)
+                    assert N_audio == B and [int(r) for r, _ in starts] == list(range(B)), "orca_hybrid: one audio per text row, in row order"
+                    orca = self.orca
+                    local16 = orca.local_forward(self.enc_all, N_audio) if cfg.orca_local_enabled else None
+                    orca.begin(af, local16, B, S, None, False, keep_kv=True)
+                    if orca.audio is not None:
+                        hook, after = orca.inject, orca.begin_decode
                 eos = eos_token_id if eos_token_id is not None else cfg.llm_config.eos_token_id
                 if isinstance(eos, int):
                     eos = [eos]
@@ -2071,7 +2104,7 @@ class DeSTA25AudioModel:
                 return self.llm.generate_greedy(fill, B, S, kv_start, int(max_new_tokens), int(pad_token_id), eos,
                                                 forced_tokens=forced_tokens, collect_logits=collect_logits, do_sample=bool(do_sample),
                                                 temperature=1.0 if temperature is None else float(temperature),
-                                                top_p=1.0 if top_p is None else float(top_p), seed=int(seed))
+                                                top_p=1.0 if top_p is None else float(top_p), seed=int(seed), layer_hook=hook, after_prompt=after)
         finally:
             self.training = was_training
 

@@ -553,7 +553,7 @@ def generation_position_ids(attention_mask: Tensor) -> Tensor:
 
 
 def greedy_generate(w, d: Dims, inputs_embeds: Tensor, attention_mask: Tensor, max_new_tokens: int, pad_token_id: int,
-                    eos_token_ids: Optional[List[int]] = None, forced_tokens: Optional[Tensor] = None):
+                    eos_token_ids: Optional[List[int]] = None, forced_tokens: Optional[Tensor] = None, layer_hook=None):
     """Restatement of ``llm_model.generate(inputs_embeds=…, attention_mask=…, do_sample=False)``
     (reference call site modeling_desta25.py:1419-1427) WITHOUT a KV cache: every step re-runs the whole
     prefix, so the result is what any correct cache must reproduce.  Returns (new tokens [B,n], per-step
@@ -564,7 +564,7 @@ def greedy_generate(w, d: Dims, inputs_embeds: Tensor, attention_mask: Tensor, m
     unfinished = torch.ones(B, dtype=torch.long)
     toks, step_logits = [], []
     for t in range(max_new_tokens):
-        logits = llm_forward(w, d, x, mask, position_ids=generation_position_ids(mask))[:, -1]
+        logits = llm_forward(w, d, x, mask, position_ids=generation_position_ids(mask), layer_hook=layer_hook)[:, -1]
         step_logits.append(logits)
         nxt = logits.argmax(-1) if forced_tokens is None else forced_tokens[:, t]
         nxt = nxt * unfinished + pad_token_id * (1 - unfinished)

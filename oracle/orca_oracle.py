@@ -259,6 +259,30 @@ def model_forward(w, d: Dims, o: OrcaDims, batch: dict, training: bool = True, k
     return loss, logits, orca_losses(o, g, loc, aligns)
 
 
+def generate(w, d: Dims, o: OrcaDims, inputs: dict, max_new_tokens: int, pad_token_id: int, eos_token_ids: Optional[List[int]] = None,
+             forced_tokens: Optional[Tensor] = None):
+    """The ORCA branch of `_generate_step` (modeling_desta25.py:1358-1436) without a KV cache: global tokens spliced into the CONTEXT
+    part of the batch, the audio tokens injected behind every decoder layer at every step (eval mode: no alignment loss).
+    -> (new tokens [B, n], per-step logits [n, B, V])."""
+    ids, am = inputs["context_input_ids"], inputs["context_attention_mask"]
+    starts = [(int(r), int(s)) for r, s in inputs["context_batch_start_positions"]]
+    trs = inputs["batch_transcription_ids"]
+    emb = w[LLM + "model.embed_tokens.weight"]
+    x = F.embedding(ids, emb).clone()
+    taps = O.whisper_taps(w, d, inputs["batch_features"].float())
+    g, loc = connector(w, d, o, taps)
+    for a, (row, start) in enumerate(starts):
+        seg = torch.cat([g[a], F.embedding(trs[a].reshape(-1), emb)], dim=0)
+        x = x.index_put((torch.tensor(row), torch.arange(start, start + seg.shape[0])), seg.to(x.dtype))
+    audio = None
+    if o.deep_injection_enabled:
+        audio = (torch.cat([g, loc], dim=1) if loc is not None else g) if o.global_cross_attn else loc
+
+    def hook(l: int, hs: Tensor) -> Tensor:
+        return gated_cross_attention(w, d, o, l, hs, audio, None, False)[0]
+    return O.greedy_generate(w, d, x, am, max_new_tokens, pad_token_id, eos_token_ids, forced_tokens, layer_hook=hook if audio is not None else None)
+
+
 def total_loss(lm_loss: Tensor, losses: Dict[str, Tensor]) -> Tensor:
     """desta_trainer.py:56-92: every ORCA term is added to the LM loss."""
     t = lm_loss

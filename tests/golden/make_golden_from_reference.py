@@ -206,8 +206,8 @@ def make_case(name, d, encoder_model_id="openai/whisper-tiny", with_generate=Tru
         print(name, "loss", float(out.loss), "->", path, os.path.getsize(path) // 1024, "KiB")
 
 
-def make_orca_case():
-    """ORCA hybrid, first slice: the reference's own `ORCAHybridConnector`, `ORCAGatedCrossAttention` (deep injection
+def make_orca_case(gca: bool = False):
+    """ORCA hybrid: the reference's own `ORCAHybridConnector`, `ORCAGatedCrossAttention` (deep injection
     wrappers installed by `_enable_orca_deep_injection`), `_prepare_inputs_for_llm`, the ORCA branch of `forward` and
     `compute_orca_losses` on a tiny local-config model in TRAINING mode (alignment loss on), fp32, dropout 0, with a 3-token
     transcription behind every audio (so the transcription-span pooling of the alignment loss is exercised) ->
@@ -221,7 +221,7 @@ def make_orca_case():
     d = O.tiny_dims(False)
     NTR = 3
     o = R.OrcaDims(global_num_tokens=8, local_downsample=4, local_kernel_size=5, gate_init=0.1, audio_position_scale=2.5,
-                   global_cross_attn=False, ortho_diversity_weight=0.05, ortho_weight_qformer_local=0.05, align_weight_local=0.05)
+                   global_cross_attn=gca, ortho_diversity_weight=0.05, ortho_weight_qformer_local=0.05, align_weight_local=0.05)
     w = R.init_weights(d, o, seed=7)
     d.prompt_size = o.global_num_tokens + NTR                    # placeholders per audio in the token stream: global tokens + transcription
     base = {k: v for k, v in O.init_weights(d, seed=7).items()}
@@ -278,6 +278,16 @@ def make_orca_case():
             model, input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], batch_features=batch["batch_features"],
             batch_transcription_ids=batch["batch_transcription_ids"], batch_start_positions=starts, labels=batch["labels"])
     assert "L_align_layerwise" not in out_eval.orca_losses                         # eval mode: no alignment loss (:487-488)
+    # greedy generation through the reference's own ORCA `_generate_step` (:1358-1436): the wrapped decoder layers inject the audio
+    # tokens at the prompt pass AND at every KV-cached decode step
+    n_ctx = batch["input_ids"].shape[1] - 12 + 3
+    gen_inputs = {"context_input_ids": batch["input_ids"][:, :n_ctx], "context_attention_mask": batch["attention_mask"][:, :n_ctx],
+                  "context_batch_start_positions": starts, "batch_transcription_ids": batch["batch_transcription_ids"],
+                  "batch_features": batch["batch_features"]}
+    with torch.no_grad():
+        model.llm_model.generation_config.eos_token_id = None
+        gen = model._generate_step(gen_inputs, pad_token_id=0, max_new_tokens=8, do_sample=False)
+    print("orca generate:", gen.tolist())
     blob = {"loss": out.loss.detach().reshape(1), "logits": out.logits.detach().contiguous(),
             "global_tokens": out.audio_global.detach().contiguous(), "local_tokens": out.audio_local.detach().contiguous(),
             "hidden_last": out.hidden_states[-1].detach().contiguous(), "hidden_1": out.hidden_states[1].detach().contiguous(),
@@ -285,12 +295,22 @@ def make_orca_case():
             "batch_features": batch["batch_features"], "starts": torch.tensor([[b, int(s)] for b, s in batch["batch_start_positions"]]),
             "transcription_ids": torch.cat(batch["batch_transcription_ids"], 0), "rope_theta_used": torch.tensor([rope_theta_used]),
             "orca_dims": torch.tensor([o.global_num_tokens, o.local_downsample, o.local_kernel_size, NTR], dtype=torch.long),
-            "logits_eval": out_eval.logits.detach().contiguous()}
+            "logits_eval": out_eval.logits.detach().contiguous(), "gen_ctx_len": torch.tensor([n_ctx]), "gen_ids": gen.contiguous()}
     for k, v in out.orca_losses.items():
         blob["orca_loss::" + k] = v.detach().reshape(1)
-    for n in names:                            # (weights are not stored: orca_oracle.init_weights(d, o, seed=7) regenerates them)
+    keep_grad = names
+    if gca:
+        # the `orca_global_cross_attn: true` variant of the shipped ORCA configs (global | local tokens in the injected sequence): a
+        # SMALL second file — losses, logits, generation and a representative subset of the gradients
+        sub = ("global_queries.0", "global_layer_weights", "global_qformer.layer.1.crossattention.self.query.weight", "global_proj.1.weight",
+               "local_layer_weights", "local_proj_in.bias", "local_ln.weight", "orca_cross_attns.0.cross_attn.in_proj_bias",
+               "orca_cross_attns.1.gate_proj.0.weight", "orca_cross_attns.1.ln.weight", "orca_cross_attns.0.cross_attn.out_proj.bias")
+        keep_grad = [n for n in names if any(n.endswith(x) for x in sub)]
+        for k in ("batch_features", "global_tokens", "local_tokens", "hidden_last", "hidden_1", "logits_eval"):
+            blob.pop(k)
+    for n in keep_grad:                        # (weights are not stored: orca_oracle.init_weights(d, o, seed=7) regenerates them)
         blob["grad::" + n] = grads[n].contiguous() if n in grads else torch.zeros_like(w[n])
-    path = os.path.join(HERE, "ref_orca_tiny.safetensors")
+    path = os.path.join(HERE, "ref_orca_tiny_gca.safetensors" if gca else "ref_orca_tiny.safetensors")
     save_file({k: v.contiguous() for k, v in blob.items()}, path)
     print("orca: lm loss", float(out.loss.detach()), {k: float(v.detach()) for k, v in out.orca_losses.items()}, "rope_theta read by the reference:", rope_theta_used,
           "->", path, os.path.getsize(path) // 1024, "KiB")
@@ -413,7 +433,8 @@ def main():
         # not possible (taps 7..31 need 32 layers) -> tiny encoder id
         make_case("qwen3", O.tied_dims(), with_generate=True, prefix="ref_tied_")
     if "orca" in which:
-        make_orca_case()
+        make_orca_case(False)
+        make_orca_case(True)
     if "asr" in which:
         make_asr_case()
 

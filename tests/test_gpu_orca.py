@@ -17,12 +17,14 @@ from helpers import cfg_from_dims, rel_err
 pytestmark = pytest.mark.gpu
 
 
-def _case(golden_dir):
+def _case(golden_dir, gca=False):
     g = load_file(os.path.join(golden_dir, "ref_orca_tiny.safetensors"))
+    if gca:                                   # the second, small file (orca_global_cross_attn: true) does not repeat the inputs
+        g = {**load_file(os.path.join(golden_dir, "ref_orca_tiny_gca.safetensors")), "batch_features": g["batch_features"]}
     kg, ds, ks, ntr = (int(x) for x in g["orca_dims"])
     d = O.tiny_dims(False)
     o = R.OrcaDims(global_num_tokens=kg, local_downsample=ds, local_kernel_size=ks, ortho_diversity_weight=0.05,
-                   ortho_weight_qformer_local=0.05, align_weight_local=0.05)
+                   ortho_weight_qformer_local=0.05, align_weight_local=0.05, global_cross_attn=gca)
     w = R.init_weights(d, o, seed=7)
     d = copy.copy(d)
     d.prompt_size = kg + ntr
@@ -32,7 +34,7 @@ def _case(golden_dir):
              "batch_transcription_ids": [g["transcription_ids"][i:i + 1] for i in range(n)]}
     cfg = cfg_from_dims(d, connector_mode="orca_hybrid", orca_enabled=True, orca_global_num_tokens=kg, orca_local_downsample=ds,
                         orca_local_kernel_size=ks, orca_ortho_diversity_weight=0.05, orca_ortho_weight_qformer_local=0.05,
-                        orca_align_weight_local=0.05, orca_rope_theta=float(g["rope_theta_used"]))
+                        orca_align_weight_local=0.05, orca_rope_theta=float(g["rope_theta_used"]), orca_global_cross_attn=gca)
     return g, d, o, w, batch, cfg
 
 
@@ -179,3 +181,93 @@ def test_orca_trainer_steps_follow_the_oracle(golden_dir):
     assert all(abs(a - b) < 6e-3 for a, b in zip(hip, ref)), (hip, ref)                    # measured 6e-4 / 1.1e-3 / 1.4e-3
     assert hip[-1] < hip[0]
     assert set(tr.log_history[0]) >= {"train/lm_loss", "train/L_ortho_diversity", "train/L_align_layerwise", "train/orca_total", "train/loss"}
+
+
+def _oracle_with_theta(theta):
+    """The oracle's cross-attention rotation reads `d.rope_theta`; the golden was made under transformers 5.x where the reference's
+    getattr falls back to 10000.0 (see OrcaHIP.__init__) — same substitution as tests/test_oracle_pin.py."""
+    orig = R.rope_whole_vector
+    R.rope_whole_vector = lambda x, th, scale: orig(x, theta, scale)
+    return orig
+
+
+@pytest.mark.parametrize("gca", [False, True])
+def test_orca_generation_and_global_cross_attn_variant(golden_dir, gca):
+    """(a) `orca_global_cross_attn: true` (global | local tokens in the injected sequence; the shipped ORCA configs carry the switch):
+    forward against the reference-made golden, EVERY gradient against the oracle's autograd (the oracle is pinned to the golden's
+    subset in tests/test_oracle_pin.py) and the golden's subset directly.  (b) `_generate_step` with deep injection — gated
+    cross-attention behind every layer of the prompt pass and of every KV-cached decode step, audio K|V projected once per layer —
+    teacher-forced on the tokens the REFERENCE's own ORCA `_generate_step` produced, per-step logits against the oracle; then free
+    running (structure of tests/test_gpu_generate.py::test_generate_step_vs_reference_golden)."""
+    from desta.models.modeling_desta25 import DeSTA25AudioModel
+    g, d, o, w, batch, cfg = _case(golden_dir, gca)
+    model = DeSTA25AudioModel(cfg, weights=w)
+    names = R.trainable_names(d, o)
+    orig = _oracle_with_theta(float(g["rope_theta_used"]))
+    try:
+        if gca:
+            model.train()
+            out = model(**batch, keep_logits=True)
+            m = g["attention_mask"].bool()
+            rec = dict(dloss=abs(float(out.loss) - float(g["loss"])), logits=rel_err(out.logits.float().cpu()[m], g["logits"][m]))
+            losses = {k: float(v) for k, v in out.orca_losses.items()}
+            ref = {k[len("orca_loss::"):]: float(v) for k, v in g.items() if k.startswith("orca_loss::")}
+            assert rec["logits"] < 2e-2 and rec["dloss"] < 3e-3, rec
+            for k in ref:
+                assert abs(losses[k] - ref[k]) < 2e-2 * abs(ref[k]) + 2e-6, (k, losses[k], ref[k])
+            model.backward()
+            for n in names:
+                w[n].requires_grad_(True)
+            loss_o, _, losses_o = R.model_forward(w, d, o, batch, training=True)
+            R.total_loss(loss_o, losses_o).backward()
+            go = {n: w[n].grad.detach().double() for n in names}
+            for n in names:
+                w[n].requires_grad_(False)
+            gn = sorted(float(go[n].norm()) for n in names)
+            floor = gn[len(gn) // 2] * 1e-2
+            errs = {n: float((model.arena.grad(n).double().cpu() - go[n].reshape(model.arena.shapes[n])).norm() / max(float(go[n].norm()), floor)) for n in names}
+            a = torch.cat([model.arena.grad(n).reshape(-1).double().cpu() for n in names])
+            b = torch.cat([go[n].reshape(-1) for n in names])
+            worst = max(errs, key=errs.get)
+            print("orca gca:", rec, "grads rel", float((a - b).norm() / b.norm()), "cos", float((a @ b) / (a.norm() * b.norm())), worst, errs[worst])
+            assert float((a - b).norm() / b.norm()) < 2e-2 and float((a @ b) / (a.norm() * b.norm())) > 0.9995
+            assert errs[worst] < 6.5e-2, (worst, errs[worst])
+            for k in g:
+                if k.startswith("grad::"):
+                    n = k[len("grad::"):]
+                    e = float((model.arena.grad(n).double().cpu() - g[k].double().reshape(model.arena.shapes[n])).norm() / max(float(g[k].double().norm()), floor))
+                    assert e < 6.5e-2, (n, e)
+        model.eval()
+        n_ctx, ref_ids = int(g["gen_ctx_len"]), g["gen_ids"]
+        T = ref_ids.shape[1]
+        inputs = {"context_input_ids": batch["input_ids"][:, :n_ctx], "context_attention_mask": batch["attention_mask"][:, :n_ctx],
+                  "context_batch_start_positions": batch["batch_start_positions"], "batch_features": batch["batch_features"],
+                  "batch_transcription_ids": batch["batch_transcription_ids"]}
+        ids_f, logits = model._generate_step(inputs, pad_token_id=0, max_new_tokens=T, do_sample=False, forced_tokens=ref_ids, collect_logits=True)
+        assert ids_f.cpu().tolist() == ref_ids.tolist()
+        with torch.no_grad():
+            lo = R.generate(w, d, o, inputs, T, 0, forced_tokens=ref_ids)[1]
+        assert logits.shape == lo.shape
+        es = [rel_err(logits[t].float(), lo[t]) for t in range(T)]
+        pick = logits.float().cpu().argmax(-1)
+        gap = lo.max(-1).values - lo.gather(-1, pick.unsqueeze(-1)).squeeze(-1)
+        print("orca generate (gca %s): per-step logits rel" % gca, [round(e, 4) for e in es], "gap/std", float((gap / lo.std(-1)).max()))
+        assert max(es) < 3e-2, es
+        assert float((gap / lo.std(-1)).max()) < 0.1 and float((pick == lo.argmax(-1)).float().mean()) >= 0.9
+        # without the injection the same prompt gives other logits: the hook is live in the decode steps, not only in the prompt pass
+        ids = model._generate_step(inputs, pad_token_id=0, max_new_tokens=T, do_sample=False).cpu()
+        print("   free-running agreement with the reference's tokens:", float((ids == ref_ids).float().mean()))
+        assert (ids[:, 0] == ref_ids[:, 0]).all()
+        with torch.no_grad():
+            lo2 = R.generate(w, d, o, inputs, T, 0, forced_tokens=ids)[1]
+        gap2 = lo2.max(-1).values - lo2.gather(-1, ids.t().unsqueeze(-1)).squeeze(-1)
+        assert float((gap2 / lo2.std(-1)).max()) < 0.1
+        saved = model.config.orca_deep_injection_enabled
+        model.config.orca_deep_injection_enabled = False
+        try:
+            _, logits_off = model._generate_step(inputs, pad_token_id=0, max_new_tokens=T, do_sample=False, forced_tokens=ref_ids, collect_logits=True)
+        finally:
+            model.config.orca_deep_injection_enabled = saved
+        assert min(rel_err(logits_off[t].float(), lo[t]) for t in range(1, T)) > 3 * max(es)
+    finally:
+        R.rope_whole_vector = orig

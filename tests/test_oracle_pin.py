@@ -246,14 +246,17 @@ def test_lora_restatement_is_self_consistent():
 
 
 # ------------------------------------------------------------------------------------------------ ORCA hybrid
-def _orca_case(golden_dir):
+def _orca_case(golden_dir, gca=False):
     import copy
     import orca_oracle as R
-    g = load_file(os.path.join(golden_dir, "ref_orca_tiny.safetensors"))
+    g = load_file(os.path.join(golden_dir, "ref_orca_tiny_gca.safetensors" if gca else "ref_orca_tiny.safetensors"))
+    if gca:                                   # the small second file does not repeat the inputs
+        g0 = load_file(os.path.join(golden_dir, "ref_orca_tiny.safetensors"))
+        g = {**g, "batch_features": g0["batch_features"]}
     kg, ds, ks, ntr = (int(x) for x in g["orca_dims"])
     d = O.tiny_dims(False)
     o = R.OrcaDims(global_num_tokens=kg, local_downsample=ds, local_kernel_size=ks, ortho_diversity_weight=0.05,
-                   ortho_weight_qformer_local=0.05, align_weight_local=0.05)
+                   ortho_weight_qformer_local=0.05, align_weight_local=0.05, global_cross_attn=gca)
     w = R.init_weights(d, o, seed=7)
     d = copy.copy(d)
     d.prompt_size = kg + ntr
@@ -310,3 +313,40 @@ def test_orca_oracle_matches_reference_golden(golden_dir):
 def rel_err(a, b):
     a, b = a.detach().double(), b.detach().double()
     return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("gca", [False, True])
+def test_orca_oracle_generation_and_global_cross_attn_variant(golden_dir, gca):
+    """(a) the `orca_global_cross_attn: true` variant of the shipped ORCA configs (global | local tokens in the injected sequence):
+    LM loss, auxiliary losses, logits and a representative subset of the gradients against a second, small golden made by the
+    reference's own classes; (b) greedy generation through the reference's ORCA `_generate_step` (injection at the prompt pass and at
+    every decode step) token for token, both variants."""
+    import orca_oracle
+    R, g, d, d_x, o, w, batch = _orca_case(golden_dir, gca)
+    orig = orca_oracle.rope_whole_vector
+    orca_oracle.rope_whole_vector = lambda x, theta, scale: orig(x, d_x.rope_theta, scale)
+    try:
+        if gca:
+            names = R.trainable_names(d, o)
+            for n in names:
+                w[n].requires_grad_(True)
+            loss, logits, losses = R.model_forward(w, d, o, batch, training=True)
+            R.total_loss(loss, losses).backward()
+            assert abs(float(loss.detach()) - float(g["loss"])) < 2e-5 and rel_err(logits, g["logits"]) < 2e-4
+            for k, v in losses.items():
+                assert abs(float(v.detach()) - float(g["orca_loss::" + k])) < 1e-6 + 1e-4 * abs(float(g["orca_loss::" + k])), k
+            sub = [k[len("grad::"):] for k in g if k.startswith("grad::")]
+            assert len(sub) >= 10
+            for n in sub:
+                assert rel_err(w[n].grad, g["grad::" + n]) < 2e-3, n
+            for n in names:
+                w[n].requires_grad_(False)
+        n_ctx = int(g["gen_ctx_len"])
+        inputs = {"context_input_ids": batch["input_ids"][:, :n_ctx], "context_attention_mask": batch["attention_mask"][:, :n_ctx],
+                  "context_batch_start_positions": batch["batch_start_positions"], "batch_transcription_ids": batch["batch_transcription_ids"],
+                  "batch_features": batch["batch_features"]}
+        with torch.no_grad():
+            toks, _ = R.generate(w, d, o, inputs, g["gen_ids"].shape[1], 0)
+        assert toks.tolist() == g["gen_ids"].tolist()
+    finally:
+        orca_oracle.rope_whole_vector = orig
