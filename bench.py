@@ -381,7 +381,7 @@ def main():
         H.attention_set_option(4, 0)
         model.connector.xattn_transposed = False
 
-    B, S = a.batch, a.ctx + cfg.prompt_size + a.tgt
+    B, S = a.batch, a.ctx + cfg.audio_tokens + a.tgt
     n_mels = cfg.encoder_config.num_mel_bins
     # two alternating synthetic batches per rank, resident in HBM (seed 1234 + rank)
     waves = [synthetic_waveform(B, dev, seed=1234 + rank + 97 * i) for i in range(2)]
@@ -584,7 +584,8 @@ def main():
             "data": "synthetic" if a.data == "synthetic" else f"synthetic WAVE files through the real data path: {data_note}",
             "config": {"workload": f"{a.config}: {os.path.basename(cfg.encoder_model_id)} + {os.path.basename(cfg.llm_model_id)}, "
                                    f"Q-Former {cfg.qformer_num_hidden_layers}L, per-GPU batch {B} x 30 s clips, "
-                                   f"S={S} ({a.ctx} ctx + {cfg.prompt_size} audio + {a.tgt} target tokens), random-init weights at true shapes"
+                                   f"S={S} ({a.ctx} ctx + {cfg.audio_tokens} audio + {a.tgt} target tokens), random-init weights at true shapes"
+                                   + (" + ORCA hybrid (gated cross-attention behind every decoder layer trainable: NOT the headline config)" if cfg.connector_mode == "orca_hybrid" else "")
                                    + (" + use_lora (rank-16 q/k/v adapters trainable: NOT the headline config)" if a.lora else ""),
                        "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}",
                        "step_definition": "one optimizer step of the node: every GPU runs the hot path over its own batch of "
@@ -637,7 +638,10 @@ def main():
             out["wait_update_stall_ms"] = sum(st) / max(1, len(st))        # main stream idle in front of the connector forward, waiting for the side-stream tail (connector backward + all-reduce + Adafactor + re-cast) of the previous step
             out["comm_hidden"] = bool(st) and out["wait_update_stall_ms"] < 0.05
             out["comm_backend"] = dist.get_backend() if dist.is_initialized() else None
-        if not a.no_cpu_baseline and world == 1:
+        if cfg.connector_mode == "orca_hybrid" and not a.no_cpu_baseline:
+            out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": 0, "kind": "port",
+                                   "sample": "not timed for the ORCA-hybrid side configs (the host leg restates the qformer_1 headline step)"}
+        elif not a.no_cpu_baseline and world == 1:
             del trainer, model                                            # the host legs below need none of it
             torch.cuda.empty_cache()
             try:

@@ -669,7 +669,7 @@ def target_rows(labels, batch, seq, idx, compact_labels, count, s_major=False):
     check(_target_rows(p(labels), batch, seq, p(idx), p(compact_labels), p(count), int(s_major), stream()), "desta_target_rows")
 
 
-# ----------------------------------------------------------------------------- ORCA hybrid (forward only, ABI 6)
+# ----------------------------------------------------------------------------- ORCA hybrid (ABI 6)
 _orca_local_mix = _sig("desta_orca_local_mix", vp, vp, i32, i64, i32, vp, vp)
 _orca_rope = _sig("desta_orca_rope", vp, vp, i32, i32, i32, C.c_float, C.c_float, i32, vp)
 _orca_gate_residual = _sig("desta_orca_gate_residual", vp, i64, vp, vp, vp, vp, i64, i32, i32, vp, vp)

@@ -134,8 +134,8 @@ class DeSTA25Config:
                                       "is not implemented")
         if connector_mode == "orca_hybrid" and (orca_use_all_layers or not orca_local_enabled):
             raise NotImplementedError("orca_hybrid: orca_use_all_layers / orca_local_enabled=False ablations are not implemented")
-        # ORCA hybrid, FIRST SLICE: the forward (connector, deep injection, auxiliary losses) runs on the device and
-        # is pinned to the reference's golden; the backward is not built (training raises).  Field names and defaults: :645-692.
+        # ORCA hybrid: connector, deep injection, auxiliary losses — forward, backward and generation run on the device
+        # and are pinned to the reference's goldens.  Field names and defaults: :645-692.
         self.orca_enabled = bool(orca_enabled) or connector_mode == "orca_hybrid"
         self.orca_use_all_layers, self.orca_local_enabled = bool(orca_use_all_layers), bool(orca_local_enabled)
         self.orca_global_cross_attn, self.orca_deep_injection_enabled = bool(orca_global_cross_attn), bool(orca_deep_injection_enabled)
@@ -171,6 +171,12 @@ class DeSTA25Config:
                 raise NotImplementedError(f"model_id {encoder_model_id} not implemented")
         self.info = "Ｄｅｓｔａ２。５ Ａｕｄｉｏ"
         self.extra = dict(kwargs)
+
+    @property
+    def audio_tokens(self) -> int:
+        """Placeholder tokens one audio clip occupies in the text stream: `prompt_size`, or the global tokens of the ORCA hybrid
+        (modeling_desta25.py:1574-1578; the local tokens never enter the sequence)."""
+        return self.orca_global_num_tokens if self.connector_mode == "orca_hybrid" else self.prompt_size
 
     @staticmethod
     def _llm_from_dict(c: dict) -> LLMConfig:
@@ -943,9 +949,9 @@ class QformerConnectorHIP:
         self._join_dw()
 
 
-# =========================================================================================== ORCA hybrid (forward only)
+# =========================================================================================== ORCA hybrid
 class OrcaHIP:
-    """ORCA hybrid, FIRST SLICE: forward of the local branch of `ORCAHybridConnector` (modeling_desta25.py:336-352),
+    """ORCA hybrid: forward of the local branch of `ORCAHybridConnector` (modeling_desta25.py:336-352),
     of `ORCAGatedCrossAttention` behind every decoder layer (:395-490, installed by `_enable_orca_deep_injection` :1052-1143) and of
     `compute_orca_losses` (:1159-1206), composed from the C-ABI entry points of the qformer_1 path (GEMM, flash attention, LayerNorm)
     plus the row-wise `desta_orca_*` kernels.  The global branch is `QformerConnectorHIP` under the ORCA tensor names.
@@ -961,8 +967,15 @@ class OrcaHIP:
         self.h, self.d, self.nt = c.hidden_size, cfg.encoder_config.d_model, len(cfg.target_layer_ids)
         self.heads, self.L = c.num_attention_heads, c.num_hidden_layers
         self.hd = self.h // self.heads
-        if self.hd not in (64, 128):
-            raise NotImplementedError(f"orca_hybrid: cross-attention head size {self.hd} (hidden {self.h} / {self.heads} heads); 64 and 128 are built")
+        if self.hd > 128 or self.hd * self.heads != self.h:
+            raise NotImplementedError(f"orca_hybrid: cross-attention head size {self.hd} (hidden {self.h} / {self.heads} heads); up to 128 is built")
+        # nn.MultiheadAttention(embed_dim = hidden, num_heads = the LLM's): head size hidden / heads, e.g. 2560 / 32 = 80 for Qwen3-4B.  The
+        # flash kernels are built for 64 and 128: other sizes run zero-padded to the next of the two (`hdp`): padded q / k columns add
+        # nothing to a score, padded v columns give zero outputs that meet zero out-proj columns; the softmax scale stays hd ** -0.5.
+        # The padded bf16 operands are rebuilt with the other bf16 copies (`refresh_weights`), weight gradients are un-padded into the arena.
+        self.hdp = 64 if self.hd <= 64 else 128
+        self.hp, self.padded = self.heads * self.hdp, self.hdp != self.hd
+        self.wp: List[dict] = []
         self.k, self.stride = cfg.orca_local_kernel_size, cfg.orca_local_downsample
         self.pad = self.k // 2
         assert self.h % 64 == 0 and (self.h // 4) % 4 == 0
@@ -976,6 +989,29 @@ class OrcaHIP:
         """bf16 operand of the Conv1d as an im2col GEMM: [out, in, k] -> [out, k * in] (tap-major rows of the padded token stream)."""
         w = self.con.arena.param(CON + "local_conv.weight")
         self.conv_w = w.permute(0, 2, 1).reshape(self.h, self.k * self.h).to(BF16).contiguous()
+        if self.padded and self.cfg.orca_deep_injection_enabled:
+            con, h, hp, nh, hd, hdp, dev = self.con, self.h, self.hp, self.heads, self.hd, self.hdp, self.dev
+            if not self.wp:
+                self.wp = [dict(wq=torch.zeros(hp, h, dtype=BF16, device=dev), wkv=torch.zeros(2 * hp, h, dtype=BF16, device=dev),
+                                wo=torch.zeros(h, hp, dtype=BF16, device=dev), bq=torch.zeros(hp, dtype=F32, device=dev),
+                                bkv=torch.zeros(2 * hp, dtype=F32, device=dev)) for _ in range(self.L)]
+            for l, t in enumerate(self.wp):
+                q = f"orca_cross_attns.{l}."
+                w_in, b_in = con.W16(q + "cross_attn.in_proj_weight"), con.P32(q + "cross_attn.in_proj_bias")
+                t["wq"].view(nh, hdp, h)[:, :hd].copy_(w_in[:h].view(nh, hd, h))
+                t["wkv"].view(2 * nh, hdp, h)[:, :hd].copy_(w_in[h:].view(2 * nh, hd, h))
+                t["bq"].view(nh, hdp)[:, :hd].copy_(b_in[:h].view(nh, hd))
+                t["bkv"].view(2 * nh, hdp)[:, :hd].copy_(b_in[h:].view(2 * nh, hd))
+                t["wo"].view(h, nh, hdp)[:, :, :hd].copy_(con.W16(q + "cross_attn.out_proj.weight").view(h, nh, hd))
+
+    def _attn_weights(self, l: int):
+        """(W_q [hp, h], W_k|v [2 hp, h], b_q, b_k|v, W_o [h, hp]) of layer l's cross-attention in the width the attention kernel runs at."""
+        if self.padded:
+            t = self.wp[l]
+            return t["wq"], t["wkv"], t["bq"], t["bkv"], t["wo"]
+        con, h, q = self.con, self.h, f"orca_cross_attns.{l}."
+        w_in, b_in = con.W16(q + "cross_attn.in_proj_weight"), con.P32(q + "cross_attn.in_proj_bias")
+        return w_in[:h], w_in[h:], b_in[:h], b_in[h:], con.W16(q + "cross_attn.out_proj.weight")
 
     def _alloc(self, B: int, T: int) -> None:
         dev, h = self.dev, self.h
@@ -1056,8 +1092,11 @@ class OrcaHIP:
         self.audio = torch.empty(B * Ta, h, dtype=BF16, device=dev)
         H.orca_rope(a, self.audio, B, Ta, h, self.rope_theta, cfg.orca_audio_position_scale, round_cos_sin=True)
         M = B * S
-        self.q16, self.att16 = torch.empty(M, h, dtype=BF16, device=dev), torch.empty(M, h, dtype=BF16, device=dev)
-        self.kv16 = torch.empty(B * Ta, 2 * h, dtype=BF16, device=dev)
+        hp = self.hp
+        if self.padded and not self.wp:
+            self.refresh_weights()
+        self.q16, self.att16 = torch.empty(M, hp, dtype=BF16, device=dev), torch.empty(M, hp, dtype=BF16, device=dev)
+        self.kv16 = torch.empty(B * Ta, 2 * hp, dtype=BF16, device=dev)
         self.lse = torch.empty(B, self.heads, S, dtype=F32, device=dev)
         self.cross32, self.cross16 = torch.empty(M, h, dtype=F32, device=dev), torch.empty(M, h, dtype=BF16, device=dev)
         self.g1 = torch.empty(M, h // 4, dtype=BF16, device=dev)
@@ -1077,7 +1116,7 @@ class OrcaHIP:
             return
         B, h, dev = self.Bq, self.h, self.dev
         self.M, self.S, self.decoding = B, 1, True
-        self.q16, self.att16 = torch.empty(B, h, dtype=BF16, device=dev), torch.empty(B, h, dtype=BF16, device=dev)
+        self.q16, self.att16 = torch.empty(B, self.hp, dtype=BF16, device=dev), torch.empty(B, self.hp, dtype=BF16, device=dev)
         self.lse = torch.empty(B, self.heads, 1, dtype=F32, device=dev)
         self.cross32, self.cross16 = torch.empty(B, h, dtype=F32, device=dev), torch.empty(B, h, dtype=BF16, device=dev)
         self.g1 = torch.empty(B, h // 4, dtype=BF16, device=dev)
@@ -1088,7 +1127,8 @@ class OrcaHIP:
             return
         con, h, M, B, S, Ta, dev = self.con, self.h, self.M, self.Bq, self.S, self.Ta, self.dev
         p = f"orca_cross_attns.{l}."
-        w_in, b_in = con.W16(p + "cross_attn.in_proj_weight"), con.P32(p + "cross_attn.in_proj_bias")
+        hp = self.hp
+        w_q, w_kv, b_q, b_kv, w_o = self._attn_weights(l)
         if self.spans is not None and self.spans is not False:
             n = min(B, self.spans.shape[0])                                      # "audio_pooled may have different batch size, align by taking first N"
             out = torch.empty(n, dtype=F32, device=dev)
@@ -1100,7 +1140,7 @@ class OrcaHIP:
             # its normalised form, the gate MLP's pre-activation / activation, the gate (fp32)
             s = self.sv[l]
             s["xpre"] = x.clone()
-            q16, kv16, att16 = torch.empty(M, h, dtype=BF16, device=dev), torch.empty(B * Ta, 2 * h, dtype=BF16, device=dev), torch.empty(M, h, dtype=BF16, device=dev)
+            q16, kv16, att16 = torch.empty(M, hp, dtype=BF16, device=dev), torch.empty(B * Ta, 2 * hp, dtype=BF16, device=dev), torch.empty(M, hp, dtype=BF16, device=dev)
             lse, cross32, cross16 = torch.empty(B, self.heads, S, dtype=F32, device=dev), torch.empty(M, h, dtype=F32, device=dev), torch.empty(M, h, dtype=BF16, device=dev)
             g1, g1pre = torch.empty(M, h // 4, dtype=BF16, device=dev), torch.empty(M, h // 4, dtype=BF16, device=dev)
             st, gate = torch.empty(M, 2, dtype=F32, device=dev), torch.empty(M, dtype=F32, device=dev)
@@ -1108,17 +1148,17 @@ class OrcaHIP:
         else:
             q16, kv16, att16, lse, cross32, cross16, g1, g1pre, st, gate = (self.q16, self.kv16, self.att16, self.lse, self.cross32, self.cross16, self.g1,
                                                                             None, None, None)
-        H.gemm(x, w_in[:h], q16, M, h, h, bias=b_in[:h])
+        H.gemm(x, w_q, q16, M, hp, h, bias=b_q)
         if self.decoding:
             kv16 = self.kv_layers[l]                                             # projected in the prompt pass
         else:
             if self.kv_layers is not None:
-                kv16 = self.kv_layers[l] = torch.empty(B * Ta, 2 * h, dtype=BF16, device=dev)
-            H.gemm(self.audio, w_in[h:], kv16, B * Ta, 2 * h, h, bias=b_in[h:])
-        ad = H.attn_desc(q16, kv16, kv16, att16, lse, batch=B, hq=self.heads, hkv=self.heads, sq=S, sk=Ta, hd=self.hd,
-                         scale=self.hd ** -0.5, q_off=0, k_off=0, v_off=h)
+                kv16 = self.kv_layers[l] = torch.empty(B * Ta, 2 * hp, dtype=BF16, device=dev)
+            H.gemm(self.audio, w_kv, kv16, B * Ta, 2 * hp, h, bias=b_kv)
+        ad = H.attn_desc(q16, kv16, kv16, att16, lse, batch=B, hq=self.heads, hkv=self.heads, sq=S, sk=Ta, hd=self.hdp,
+                         scale=self.hd ** -0.5, q_off=0, k_off=0, v_off=hp)
         H.attention_fwd(ad)
-        H.gemm(att16, con.W16(p + "cross_attn.out_proj.weight"), cross32, M, h, h, bias=con.P32(p + "cross_attn.out_proj.bias"))
+        H.gemm(att16, w_o, cross32, M, h, hp, bias=con.P32(p + "cross_attn.out_proj.bias"))
         H.layernorm_fwd(cross32, con.P32(p + "ln.weight"), con.P32(p + "ln.bias"), 1e-5, y16=cross16, stats=st)
         H.gemm(x, con.W16(p + "gate_proj.0.weight"), g1, M, h // 4, h, bias=con.P32(p + "gate_proj.0.bias"), act=1, preact=g1pre)
         H.orca_gate_residual(x, h, cross16, g1, con.P32(p + "gate_proj.2.weight"), con.P32(p + "gate_proj.2.bias"), M, h, h // 4, gate_out=gate)
@@ -1141,8 +1181,15 @@ class OrcaHIP:
             return
         con, h, M, B, S, Ta, dev, s = self.con, self.h, self.M, self.Bq, self.S, self.Ta, self.dev, self.sv[l]
         p = f"orca_cross_attns.{l}."
-        w_in = con.W16(p + "cross_attn.in_proj_weight")
+        hp, nh, hd, hdp = self.hp, self.heads, self.hd, self.hdp
+        w_q, w_kv, _, _, w_o = self._attn_weights(l)
         gw_in, gb_in = self.Gw(p + "cross_attn.in_proj_weight"), self.G32(p + "cross_attn.in_proj_bias")
+        gw_o = self.Gw(p + "cross_attn.out_proj.weight")
+        if self.padded:                                                       # weight gradients at the padded width, un-padded into the arena below
+            gq_p, gkv_p = torch.empty(hp, h, dtype=F32, device=dev), torch.empty(2 * hp, h, dtype=F32, device=dev)
+            gbq_p, gbkv_p, go_p = torch.empty(hp, dtype=F32, device=dev), torch.empty(2 * hp, dtype=F32, device=dev), torch.empty(h, hp, dtype=F32, device=dev)
+        else:
+            gq_p, gkv_p, gbq_p, gbkv_p, go_p = gw_in[:h], gw_in[h:], gb_in[:h], gb_in[h:], gw_o
 
         def b16(*sh):
             return torch.empty(*sh, dtype=BF16, device=dev)
@@ -1156,19 +1203,25 @@ class OrcaHIP:
         # LayerNorm(cross) -> out_proj -> attention -> q / k|v projections
         dcross16 = b16(M, h)
         H.layernorm_bwd(dc16, s["cross32"], con.P32(p + "ln.weight"), s["st"], dx16=dcross16, dgamma=self.G32(p + "ln.weight"), dbeta=self.G32(p + "ln.bias"))
-        self._dW(dcross16, s["att16"], M, h, h, self.Gw(p + "cross_attn.out_proj.weight"), self.G32(p + "cross_attn.out_proj.bias"))
-        datt16, dq16, dkv16 = b16(M, h), b16(M, h), b16(B * Ta, 2 * h)
-        H.gemm(dcross16, con.W16(p + "cross_attn.out_proj.weight"), datt16, M, h, h, trans_b=True, ldb=h)
-        H.attention_bwd(s["ad"], datt16, dq16, dkv16, dkv16, dk_off=0, dv_off=h)
-        self._dW(dq16, s["xpre"], M, h, h, gw_in[:h], gb_in[:h])
-        self._dW(dkv16, self.audio, B * Ta, 2 * h, h, gw_in[h:], gb_in[h:])
-        H.gemm(dkv16, w_in[h:], self.d_audio32, B * Ta, h, 2 * h, trans_b=True, ldb=h, residual=self.d_audio32)
+        self._dW(dcross16, s["att16"], M, h, hp, go_p, self.G32(p + "cross_attn.out_proj.bias"))
+        datt16, dq16, dkv16 = b16(M, hp), b16(M, hp), b16(B * Ta, 2 * hp)
+        H.gemm(dcross16, w_o, datt16, M, hp, h, trans_b=True, ldb=hp)
+        H.attention_bwd(s["ad"], datt16, dq16, dkv16, dkv16, dk_off=0, dv_off=hp)
+        self._dW(dq16, s["xpre"], M, hp, h, gq_p, gbq_p)
+        self._dW(dkv16, self.audio, B * Ta, 2 * hp, h, gkv_p, gbkv_p)
+        if self.padded:
+            gw_in[:h].view(nh, hd, h).copy_(gq_p.view(nh, hdp, h)[:, :hd])
+            gw_in[h:].view(2 * nh, hd, h).copy_(gkv_p.view(2 * nh, hdp, h)[:, :hd])
+            gb_in[:h].view(nh, hd).copy_(gbq_p.view(nh, hdp)[:, :hd])
+            gb_in[h:].view(2 * nh, hd).copy_(gbkv_p.view(2 * nh, hdp)[:, :hd])
+            gw_o.view(h, nh, hd).copy_(go_p.view(h, nh, hdp)[:, :, :hd])
+        H.gemm(dkv16, w_kv, self.d_audio32, B * Ta, h, 2 * hp, trans_b=True, ldb=h, residual=self.d_audio32)
         # into the layer output's gradient: the alignment loss of this layer (on the hidden states the injection READ), q path, gate path
         if self.spans is not None and self.spans is not False and self.aligns:
             n = min(B, self.spans.shape[0])
             coef = self.cfg.orca_align_weight_local / (len(self.aligns) * n)
             H.orca_align_bwd(self.audio, Ta, s["xpre"], h, S * h, h, self.spans, n, coef, dx, h, S * h)
-        H.gemm(dq16, w_in[:h], dx, M, h, h, trans_b=True, ldb=h, residual=dx)
+        H.gemm(dq16, w_q, dx, M, h, hp, trans_b=True, ldb=h, residual=dx)
         H.gemm(dpre16, con.W16(p + "gate_proj.0.weight"), dx, M, h, h // 4, trans_b=True, ldb=h, residual=dx)
         self.sv[l] = {}                                                        # activations of this layer are dead
 
@@ -2201,7 +2254,7 @@ class DeSTA25AudioModel:
                 texts[i] = t.strip()
         feats = self.processor(waves, sampling_rate=16000, return_tensors="pt").input_features
         n = len(waves)
-        audio_sizes, tr_sizes = [self.config.prompt_size] * n, [len(tok.tokenize(t, add_special_tokens=False)) for t in texts]
+        audio_sizes, tr_sizes = [self.audio_tokens] * n, [len(tok.tokenize(t, add_special_tokens=False)) for t in texts]       # (:1574-1578)
         contexts, starts = [], []
         for conv in conversations:
             ctx = tok.apply_chat_template(conv, tokenize=False, add_generation_prompt=True)

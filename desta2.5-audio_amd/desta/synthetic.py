@@ -87,7 +87,7 @@ def synthetic_inputs(cfg: DeSTA25Config, B: int, S_ctx: int, S_tgt: int, device,
     """Token side of a collated batch on `device`: context ‖ prompt_size placeholders ‖ targets, no
     padding, labels -100 on the first S_ctx + prompt_size positions."""
     g = torch.Generator(device=device).manual_seed(seed)
-    K, V = cfg.prompt_size, cfg.llm_config.vocab_size
+    K, V = cfg.audio_tokens, cfg.llm_config.vocab_size
     S = S_ctx + K + S_tgt
     ids = torch.randint(3, V, (B, S), generator=g, device=device)
     labels = torch.full((B, S), -100, dtype=torch.long, device=device)
@@ -143,6 +143,26 @@ FULL_CONFIGS = {
         qformer_num_hidden_layers=6, prompt_size=64, placeholder_token="<|video_pad|>",
         llm_config=_qwen3(1024, 28, 16, 8, 3072, True), encoder_config=_ENC_LARGE_V3),
 }
+# the three ORCA-hybrid configs the reference ships (examples/train/config/desta25_{llama31-8B,qwen3-0.6b,qwen3-4b}_ORCAHybrid.yaml):
+# global + local tokens in the gated cross-attention behind every decoder layer, 0.05 loss weights, whisper-large-v3
+_ORCA = dict(connector_mode="orca_hybrid", orca_enabled=True, orca_local_enabled=True, orca_global_cross_attn=True,
+             orca_deep_injection_enabled=True, orca_local_downsample=4, orca_local_kernel_size=5, orca_gate_init=0.1,
+             orca_audio_position_scale=2.5, orca_ortho_weight_global=0.05, orca_ortho_diversity_weight=0.05,
+             orca_ortho_weight_qformer_local=0.05, orca_align_weight_local=0.05)
+FULL_CONFIGS.update({
+    "desta25_llama31-8B_ORCAHybrid": dict(
+        llm_model_id="DeSTA-ntu/Llama-3.1-8B-Instruct", encoder_model_id="openai/whisper-large-v3", qformer_num_hidden_layers=6,
+        prompt_size=64, orca_global_num_tokens=8, llm_config=_LLAMA31_8B, encoder_config=_ENC_LARGE_V3, **_ORCA),
+    "desta25_qwen3-0.6b_ORCAHybrid": dict(
+        llm_model_id="Qwen/Qwen3-0.6B", encoder_model_id="openai/whisper-large-v3", qformer_num_hidden_layers=6, prompt_size=64,
+        placeholder_token="<|video_pad|>", orca_global_num_tokens=64, llm_config=_qwen3(1024, 28, 16, 8, 3072, True),
+        encoder_config=_ENC_LARGE_V3, **_ORCA),
+    # hidden 2560 / 32 heads: cross-attention head size 80, run zero-padded to 128 (OrcaHIP)
+    "desta25_qwen3-4b_ORCAHybrid": dict(
+        llm_model_id="Qwen/Qwen3-4B", encoder_model_id="openai/whisper-large-v3", qformer_num_hidden_layers=6, prompt_size=64,
+        placeholder_token="<|video_pad|>", orca_global_num_tokens=64, llm_config=_qwen3(2560, 36, 32, 8, 9728, True),
+        encoder_config=_ENC_LARGE_V3, **_ORCA),
+})
 
 
 # ------------------------------------------------------------------------------------------------ real-data-path stand-ins (bench.py --data wav)

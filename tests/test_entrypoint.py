@@ -38,10 +38,20 @@ def test_full_configs_parse_and_map_to_model_config():
     from desta.models.modeling_desta25 import DeSTA25Config
     from desta.synthetic import FULL_CONFIGS
     assert set(FULL_CONFIGS) == {os.path.splitext(f)[0] for f in os.listdir(os.path.join(ROOT, "examples", "train", "config"))
-                                 if f.endswith("Qformer6L.yaml")}, "every shipped *_Qformer6L.yaml has its true-shape dims"
+                                 if f.endswith("Qformer6L.yaml") or f.endswith("ORCAHybrid.yaml")}, "every shipped model YAML has its true-shape dims"
     for name in FULL_CONFIGS:
         cfg = m.load_config(["--config-name", name, "+dataset=synthetic", "exp_dir=/tmp/x"])
         assert cfg.model.connector.num_hidden_layers == 6 and cfg.model.connector.prompt_size == 64
+        if name.endswith("ORCAHybrid"):
+            # the three ORCA configs the reference ships: the model config the ENTRY POINT builds from the YAML equals the dims
+            # bench.py / the full-size tests use under the same name, field by field
+            assert cfg.model.connector.mode == "orca_hybrid" and cfg.model.orca.global_cross_attn and cfg.model.orca.deep_injection_enabled
+            want = DeSTA25Config(**FULL_CONFIGS[name]).to_dict()
+            assert want["connector_mode"] == "orca_hybrid" and want["orca_global_num_tokens"] == cfg.model.orca.global_num_tokens
+            for k in ("local_enabled", "global_cross_attn", "deep_injection_enabled", "local_downsample", "local_kernel_size", "gate_init",
+                      "audio_position_scale", "ortho_weight_global", "ortho_diversity_weight", "ortho_weight_qformer_local", "align_weight_local"):
+                assert want["orca_" + k] == cfg.model.orca[k], k
+            assert DeSTA25Config(**FULL_CONFIGS[name]).audio_tokens == cfg.model.orca.global_num_tokens
         assert cfg.optim.sched.warmup_steps == 5000 and cfg.trainer.accumulate_grad_batches == 1
         assert cfg.dataset.train_ds.batch_size == 8
         mc = DeSTA25Config(**FULL_CONFIGS[name])           # the dims bench.py uses for the same names
@@ -49,10 +59,10 @@ def test_full_configs_parse_and_map_to_model_config():
         assert mc.to_dict()["model_type"] == "desta25"
         assert mc.llm_model_id == cfg.model.llm.model_id and mc.encoder_model_id == cfg.model.encoder.model_id
         assert mc.placeholder_token == cfg.model.placeholder_token
-        assert mc.llm_config.tie_word_embeddings == ("qwen3-4B" in name or "0.6b" in name)
+        assert mc.llm_config.tie_word_embeddings == ("qwen3-4B" in name or "qwen3-4b" in name or "0.6b" in name)
         args = m.create_training_args(cfg)                 # epochs-only: 5 x (256 // 8) steps from the synthetic stream
         assert args.max_steps == -1 and args.steps_per_epoch == 32 and args.save_strategy == "epoch"
-    # orca_hybrid is accepted since round 4 (forward-only first slice, tests/test_gpu_orca.py); an unknown mode raises like the reference (:627)
+    # orca_hybrid is accepted since round 4 (tests/test_gpu_orca.py); an unknown mode raises like the reference (:627)
     oc = DeSTA25Config(connector_mode="orca_hybrid", orca_global_num_tokens=64, llm_config=FULL_CONFIGS[name]["llm_config"],
                        encoder_config=FULL_CONFIGS[name]["encoder_config"])
     assert oc.orca_enabled and oc.to_dict()["orca_global_num_tokens"] == 64 and oc.to_dict()["connector_mode"] == "orca_hybrid"

@@ -271,3 +271,113 @@ def test_orca_generation_and_global_cross_attn_variant(golden_dir, gca):
         assert min(rel_err(logits_off[t].float(), lo[t]) for t in range(1, T)) > 3 * max(es)
     finally:
         R.rope_whole_vector = orig
+
+
+def test_orca_cross_attention_head_size_80_vs_oracle():
+    """`nn.MultiheadAttention(hidden, llm heads)` has head size hidden / heads — 80 for the shipped Qwen3-4B ORCA config (2560 / 32),
+    which the flash kernels (64 / 128) run zero-padded to 128 (`OrcaHIP.hdp`): loss, logits, EVERY gradient (un-padded back into the
+    arena) and teacher-forced generation logits against the oracle at hidden 1280 / 16 heads (head size 80; the decoder's own q width
+    16 x 64 = 1024 != hidden, as in Qwen3-4B), global | local tokens injected, left padding, a transcription span in one row."""
+    from desta.models.modeling_desta25 import DeSTA25AudioModel
+    d = copy.copy(O.tiny_dims(False))
+    d.llm_h, d.llm_hq, d.llm_hkv, d.llm_hd, d.llm_inter = 1280, 16, 4, 64, 768
+    kg = 6
+    o = R.OrcaDims(global_num_tokens=kg, local_downsample=4, local_kernel_size=5, ortho_diversity_weight=0.05, ortho_weight_qformer_local=0.05,
+                   align_weight_local=0.05, global_cross_attn=True)
+    w = R.init_weights(d, o, seed=11)
+    d.prompt_size = kg
+    batch = O.synthetic_batch(d, B=2, S_ctx=9, S_tgt=14, seed=4, pad=[3, 0])
+    cfg = cfg_from_dims(d, connector_mode="orca_hybrid", orca_enabled=True, orca_global_num_tokens=kg, orca_local_downsample=4, orca_local_kernel_size=5,
+                        orca_ortho_diversity_weight=0.05, orca_ortho_weight_qformer_local=0.05, orca_align_weight_local=0.05, orca_global_cross_attn=True)
+    model = DeSTA25AudioModel(cfg, weights=w)
+    assert model.orca.hd == 80 and model.orca.hdp == 128 and model.orca.padded
+    names = R.trainable_names(d, o)
+    model.train()
+    out = model(**batch, keep_logits=True)
+    for n in names:
+        w[n].requires_grad_(True)
+    loss_o, logits_o, losses_o = R.model_forward(w, d, o, batch, training=True)
+    R.total_loss(loss_o, losses_o).backward()
+    m = batch["attention_mask"].bool()
+    rec = dict(dloss=abs(float(out.loss) - float(loss_o)), logits=rel_err(out.logits.float().cpu()[m], logits_o.detach()[m]))
+    for k, v in losses_o.items():
+        assert abs(float(out.orca_losses[k]) - float(v)) < 2e-2 * abs(float(v)) + 2e-6, (k, float(out.orca_losses[k]), float(v))
+    model.backward()
+    go = {n: w[n].grad.detach().double() for n in names}
+    for n in names:
+        w[n].requires_grad_(False)
+    gn = sorted(float(go[n].norm()) for n in names)
+    floor = gn[len(gn) // 2] * 1e-2
+    errs = {n: float((model.arena.grad(n).double().cpu() - go[n].reshape(model.arena.shapes[n])).norm() / max(float(go[n].norm()), floor)) for n in names}
+    a = torch.cat([model.arena.grad(n).reshape(-1).double().cpu() for n in names])
+    b = torch.cat([go[n].reshape(-1) for n in names])
+    worst = max(errs, key=errs.get)
+    rec.update(grad=float((a - b).norm() / b.norm()), cos=float((a @ b) / (a.norm() * b.norm())), worst=(worst, round(errs[worst], 4)))
+    print("orca head size 80:", rec)
+    assert rec["dloss"] < 3e-3 and rec["logits"] < 2e-2, rec
+    assert rec["grad"] < 2e-2 and rec["cos"] > 0.9995 and errs[worst] < 6.5e-2, rec
+    model.eval()
+    n_ctx = 9 + 3 + kg
+    inputs = {"context_input_ids": batch["input_ids"][:, :n_ctx], "context_attention_mask": batch["attention_mask"][:, :n_ctx],
+              "context_batch_start_positions": batch["batch_start_positions"], "batch_features": batch["batch_features"],
+              "batch_transcription_ids": batch["batch_transcription_ids"]}
+    with torch.no_grad():
+        ref_ids, lo = R.generate(w, d, o, inputs, 5, 0)
+    _, logits = model._generate_step(inputs, pad_token_id=0, max_new_tokens=5, do_sample=False, forced_tokens=ref_ids, collect_logits=True, eos_token_id=[])
+    es = [rel_err(logits[t].float(), lo[t]) for t in range(5)]
+    assert max(es) < 3e-2, es
+
+
+@pytest.mark.parametrize("name", ["desta25_qwen3-0.6b_ORCAHybrid", "desta25_qwen3-4b_ORCAHybrid", "desta25_llama31-8B_ORCAHybrid"])
+def test_orca_full_size_step_properties(name):
+    """The three ORCA configs the reference ships at their TRUE shapes (whisper-large-v3, 6-layer global Q-Former, 28 / 36 / 32 decoder
+    layers each followed by a trainable gated cross-attention over 64 | 8 global + 375 local tokens), through size-independent
+    properties like tests/test_gpu_fullsize.py: CE ~ ln V at random init, finite non-zero gradients in every tensor family, a
+    bit-identical rerun, loss descent over a few optimizer steps on a repeated batch, greedy generation rerun-stable."""
+    import math
+    from desta import _hip as H
+    from desta.models.modeling_desta25 import DeSTA25AudioModel, DeSTA25Config
+    from desta.synthetic import FULL_CONFIGS, RandomWeights, synthetic_inputs, synthetic_waveform
+    from desta.trainer.desta_trainer import DeSTA25Trainer, TrainingArguments
+    cfg = DeSTA25Config(**FULL_CONFIGS[name])
+    model = DeSTA25AudioModel(cfg, weights=RandomWeights(cfg, "cuda:0", seed=0), device="cuda:0")
+    c = cfg.llm_config
+    per_layer = 4 * c.hidden_size ** 2 + 4 * c.hidden_size + (c.hidden_size // 4) * (c.hidden_size + 2) + 1 + 2 * c.hidden_size
+    assert sum(math.prod(model.arena.shapes[n]) for n in model.arena.names if n.startswith("orca_cross_attns.")) == c.num_hidden_layers * per_layer
+    assert model.orca.hd == c.hidden_size // c.num_attention_heads and model.orca.padded == ("4b" in name)
+    B = 4
+    batch = synthetic_inputs(cfg, B, 40, 216, "cuda:0", seed=3)
+    assert batch["input_ids"].shape[1] == 40 + cfg.orca_global_num_tokens + 216
+    batch["batch_features"] = H.logmel(synthetic_waveform(B, "cuda:0", seed=3), 128)
+    model.train()
+    model._fwd_count = 0
+    out = model(**batch)
+    loss0 = float(out.loss)
+    assert abs(loss0 - math.log(c.vocab_size)) < 1.0, loss0
+    assert sorted(out.orca_losses) == ["L_align_layerwise", "L_ortho_diversity", "L_ortho_qformer_local"]
+    aux0 = {k: float(v) for k, v in out.orca_losses.items()}
+    assert all(math.isfinite(v) and v >= 0 for v in aux0.values()), aux0
+    assert out.audio_local.shape == (B, 375, c.hidden_size) and out.audio_global.shape == (B, cfg.orca_global_num_tokens, c.hidden_size)
+    model.backward()
+    g1 = model.arena.grads.clone()
+    assert torch.isfinite(g1).all()
+    for fam in ("perception.connector.global_qformer.", "perception.connector.local_conv.weight", "perception.connector.global_queries.",
+                "orca_cross_attns.0.cross_attn.in_proj_weight", f"orca_cross_attns.{c.num_hidden_layers - 1}.gate_proj.0.weight",
+                f"orca_cross_attns.{c.num_hidden_layers // 2}.cross_attn.out_proj.weight"):
+        assert any(float(model.arena.grad(n).abs().max()) > 0 for n in model.arena.names if n.startswith(fam)), fam
+    model.mark_weights_updated()
+    model._fwd_count = 0
+    out = model(**batch)
+    model.backward()
+    assert float(out.loss) == loss0 and torch.equal(model.arena.grads, g1)              # bit-identical rerun
+    del g1
+    tr = DeSTA25Trainer(model, args=TrainingArguments(learning_rate=1e-3, warmup_steps=0, max_steps=100, logging_steps=100))
+    losses = tr.train([batch] * 5)
+    print(name, "lm loss", round(loss0, 4), aux0, "total loss over 5 steps", [round(x, 4) for x in losses])
+    assert all(math.isfinite(x) for x in losses) and losses[-1] < losses[0] - 0.03, losses
+    model.eval()
+    t = synthetic_inputs(cfg, 2, 24, 8, "cuda:0", seed=9)
+    inputs = {"context_input_ids": t["input_ids"], "context_attention_mask": t["attention_mask"], "context_batch_start_positions": t["batch_start_positions"],
+              "batch_features": batch["batch_features"][:2], "batch_transcription_ids": t["batch_transcription_ids"]}
+    ids = model._generate_step(inputs, pad_token_id=0, max_new_tokens=4, do_sample=False, eos_token_id=[])
+    assert ids.shape == (2, 4) and torch.equal(ids, model._generate_step(inputs, pad_token_id=0, max_new_tokens=4, do_sample=False, eos_token_id=[]))
