@@ -2254,7 +2254,7 @@ class DeSTA25AudioModel:
                 texts[i] = t.strip()
         feats = self.processor(waves, sampling_rate=16000, return_tensors="pt").input_features
         n = len(waves)
-        audio_sizes, tr_sizes = [self.audio_tokens] * n, [len(tok.tokenize(t, add_special_tokens=False)) for t in texts]       # (:1574-1578)
+        audio_sizes, tr_sizes = [getattr(self.config, "audio_tokens", self.config.prompt_size)] * n, [len(tok.tokenize(t, add_special_tokens=False)) for t in texts]       # (:1574-1578)
         contexts, starts = [], []
         for conv in conversations:
             ctx = tok.apply_chat_template(conv, tokenize=False, add_generation_prompt=True)

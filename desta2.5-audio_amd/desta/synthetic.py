@@ -83,18 +83,19 @@ def hash_name(name: str) -> int:
     return h
 
 
-def synthetic_inputs(cfg: DeSTA25Config, B: int, S_ctx: int, S_tgt: int, device, seed: int = 1234) -> Dict:
-    """Token side of a collated batch on `device`: context ‖ prompt_size placeholders ‖ targets, no
-    padding, labels -100 on the first S_ctx + prompt_size positions."""
+def synthetic_inputs(cfg: DeSTA25Config, B: int, S_ctx: int, S_tgt: int, device, seed: int = 1234, S_tr: int = 0) -> Dict:
+    """Token side of a collated batch on `device`: context ‖ audio placeholders (‖ S_tr transcription slots) ‖ targets, no
+    padding, labels -100 in front of the targets.  S_tr > 0: every clip carries S_tr transcription token ids, spliced
+    behind its audio tokens like the reference's collate lays them out (simple_dataset.py:248-264)."""
     g = torch.Generator(device=device).manual_seed(seed)
-    K, V = cfg.audio_tokens, cfg.llm_config.vocab_size
+    K, V = cfg.audio_tokens + S_tr, cfg.llm_config.vocab_size
     S = S_ctx + K + S_tgt
     ids = torch.randint(3, V, (B, S), generator=g, device=device)
     labels = torch.full((B, S), -100, dtype=torch.long, device=device)
     labels[:, S_ctx + K:] = ids[:, S_ctx + K:]
     return {"input_ids": ids, "attention_mask": torch.ones(B, S, dtype=torch.long, device=device), "labels": labels,
             "batch_start_positions": [(b, S_ctx) for b in range(B)],
-            "batch_transcription_ids": [torch.zeros(1, 0, dtype=torch.long, device=device) for _ in range(B)]}
+            "batch_transcription_ids": [ids[b:b + 1, S_ctx + cfg.audio_tokens:S_ctx + K].clone() for b in range(B)]}
 
 
 def synthetic_waveform(B: int, device, seed: int = 1234, n: int = 480000) -> torch.Tensor:

@@ -346,8 +346,8 @@ def test_orca_full_size_step_properties(name):
     assert sum(math.prod(model.arena.shapes[n]) for n in model.arena.names if n.startswith("orca_cross_attns.")) == c.num_hidden_layers * per_layer
     assert model.orca.hd == c.hidden_size // c.num_attention_heads and model.orca.padded == ("4b" in name)
     B = 4
-    batch = synthetic_inputs(cfg, B, 40, 216, "cuda:0", seed=3)
-    assert batch["input_ids"].shape[1] == 40 + cfg.orca_global_num_tokens + 216
+    batch = synthetic_inputs(cfg, B, 40, 200, "cuda:0", seed=3, S_tr=16)        # 16 transcription tokens per clip: the alignment loss reads their span
+    assert batch["input_ids"].shape[1] == 40 + cfg.orca_global_num_tokens + 16 + 200
     batch["batch_features"] = H.logmel(synthetic_waveform(B, "cuda:0", seed=3), 128)
     model.train()
     model._fwd_count = 0
