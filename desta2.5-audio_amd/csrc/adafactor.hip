@@ -133,6 +133,7 @@ __global__ __launch_bounds__(256) void af_stats(Tab tb, Ws ws, const float* __re
             float rsum = 0.f;
 #pragma unroll
             for (int s = 0; s < MAXSEG; ++s) {
+                if (s * 256 >= Cn) continue;        // (a Conv1d weight has 3..7 columns: one segment)
                 const int c0 = s * 256 + lane * 4;
                 float x[4];
 #pragma unroll
@@ -345,12 +346,35 @@ __global__ __launch_bounds__(256, 3) void af_apply(Tab tb, Ws ws, const float* _
     }
 }
 
-// unit-based update (round-1 structure): plans with ragged rows (cols % 4 != 0)
+// sum u^2 of a whole tensor from its unit sums, in place: unit_usq[first unit] <- total (fixed order: thread-strided partials, then
+// the block tree).  One block per tensor (`t0 + blockIdx.x`).  [Rounds 1-3 summed the units serially in EVERY block of the apply
+// kernel: quadratic in the unit count, 2.3 s for a [4096, 4096, 5] Conv1d weight = 262 144 units.]
+__global__ __launch_bounds__(256) void k34_totals(Tab tb, int t0, float* __restrict__ unit_usq) {
+    __shared__ float red[4];
+    const long* tt = tb.ten + (long)(t0 + blockIdx.x) * 8;
+    const int unit0 = (int)tt[6], nun = (int)tt[7];
+    float s = 0.f;
+    for (int k = threadIdx.x; k < nun; k += 256) s += unit_usq[unit0 + k];
+    s = block_sum<256>(s, red);
+    __syncthreads();
+    if (threadIdx.x == 0) unit_usq[unit0] = s;
+}
+
+__global__ __launch_bounds__(256) void k34_totals_range(int unit0, int nun, float* __restrict__ unit_usq) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int k = threadIdx.x; k < nun; k += 256) s += unit_usq[unit0 + k];
+    s = block_sum<256>(s, red);
+    __syncthreads();
+    if (threadIdx.x == 0) unit_usq[unit0] = s;
+}
+
+// unit-based update (round-1 structure): tensors with ragged rows (cols % 4 != 0); unit = unit_base + blockIdx.x
 template <bool APPLY>
 __global__ __launch_bounds__(256) void k34_update(Tab tb, Ws ws, const float* __restrict__ g, float* __restrict__ p,
-                                                  float lr, float clip_thr, float* __restrict__ unit_usq) {
+                                                  float lr, float clip_thr, float* __restrict__ unit_usq, int unit_base) {
     __shared__ float red[4];
-    const int u = blockIdx.x;
+    const int u = unit_base + blockIdx.x;
     const int t = tb.unit[u * 4 + 0], b = tb.unit[u * 4 + 1], row0 = tb.unit[u * 4 + 2], nrows = tb.unit[u * 4 + 3];
     const long* tt = tb.ten + (long)t * 8;
     const int nb = (int)tt[1], R = (int)tt[2], Cn = (int)tt[3];
@@ -362,9 +386,7 @@ __global__ __launch_bounds__(256) void k34_update(Tab tb, Ws ws, const float* __
     const bool vec4 = (Cn % 4 == 0);
     float scale = 0.f, decay = 1.f;
     if (APPLY) {
-        const int unit0 = (int)tt[6], nun = (int)tt[7];
-        float s = 0.f;
-        for (int k = 0; k < nun; ++k) s += unit_usq[unit0 + k];         // fixed order, same in every block
+        const float s = unit_usq[(int)tt[6]];                             // the tensor's total (k34_totals)
         const float rms = sqrtf(s / ((float)nb * (float)R * (float)Cn));
         scale = lr / fmaxf(1.0f, rms / clip_thr);
         decay = 1.0f - tb.ten_wd[t] * lr;
@@ -432,8 +454,9 @@ extern "C" int desta_clip_adafactor_step(const desta_opt_plan* pl, float* params
     DESTA_CHECK_ARG(pl->n_tensors >= 0 && pl->n_units >= 0 && pl->n_vec >= 0, "adafactor: bad plan");
     DESTA_CHECK_ARG(pl->max_cols <= MAXSEG * 256, "adafactor: factored tensor with %d columns > %d unsupported",
                     pl->max_cols, MAXSEG * 256);
-    DESTA_CHECK_ARG(pl->n_tensors == 0 || (pl->chunks && pl->ten_chunks && pl->fin && pl->n_chunks > 0 && pl->n_fin > 0),
+    DESTA_CHECK_ARG(pl->n_tensors == 0 || (pl->chunks && pl->ten_chunks && pl->fin && pl->n_fin > 0 && (pl->n_chunks > 0 || pl->n_ragged > 0)),
                     "adafactor: plan without chunk / finalize tables (ABI 3)");
+    DESTA_CHECK_ARG(pl->n_ragged >= 0 && (pl->n_ragged == 0 || pl->ragged_units), "adafactor: bad ragged-tensor table");
     Tab tb;
     tb.ten = (const long*)pl->tensors; tb.ten_wd = pl->tensor_wd; tb.T = pl->n_tensors;
     tb.unit = pl->units; tb.unit_col_off = (const long*)pl->unit_col_off; tb.U = pl->n_units;
@@ -457,7 +480,18 @@ extern "C" int desta_clip_adafactor_step(const desta_opt_plan* pl, float* params
     DESTA_CHECK_ARG(tb.T > 0, "adafactor: a plan without any factored (>= 2-D) tensor is not supported");
     hipLaunchKernelGGL(af_stats, dim3(tb.U + tb.V), dim3(256), 0, st, tb, ws, grads);
     hipLaunchKernelGGL(af_finalize, dim3(pl->n_fin), dim3(256), 0, st, tb, ws, pl->fin, state, beta2t, eps1, max_grad_norm);
-    if (pl->cols_multiple_of_4) {
+    // tensors with ragged rows (ABI 7): unit kernels over their own unit ranges; their unit sums live in chunk_usq[first unit ...]
+    // while the chunk sums of the other tensors live in chunk_usq[chunk index]: disjoint in TIME (this loop ends before af_usq starts)
+    for (int r = 0; r < pl->n_ragged; ++r) {
+        const int u0 = pl->ragged_units[2 * r], n = pl->ragged_units[2 * r + 1];
+        DESTA_CHECK_ARG(u0 >= 0 && n > 0 && u0 + n <= tb.U, "adafactor: ragged unit range [%d, %d) outside [0, %d)", u0, u0 + n, tb.U);
+        hipLaunchKernelGGL(k34_update<false>, dim3(n), dim3(256), 0, st, tb, ws, grads, params, lr, clip_threshold, ws.chunk_usq, u0);
+        hipLaunchKernelGGL(k34_totals_range, dim3(1), dim3(256), 0, st, u0, n, ws.chunk_usq);
+        hipLaunchKernelGGL(k34_update<true>, dim3(n), dim3(256), 0, st, tb, ws, grads, params, lr, clip_threshold, ws.chunk_usq, u0);
+    }
+    if (pl->n_ragged > 0 && tb.NC == 0) {
+        if (tb.V > 0) hipLaunchKernelGGL(v2_update, dim3(tb.V), dim3(256), 0, st, tb, ws, grads, params, state, beta2t, eps1, lr, clip_threshold);
+    } else if (pl->cols_multiple_of_4) {
         DESTA_CHECK_ARG(pl->group_bounds && pl->n_groups > 0 && pl->group_bounds[0] == 0 && pl->group_bounds[pl->n_groups] == tb.NC,
                         "adafactor: bad group table");
         for (int gi = 0; gi < pl->n_groups; ++gi) {
@@ -472,8 +506,10 @@ extern "C" int desta_clip_adafactor_step(const desta_opt_plan* pl, float* params
                                c0, n, c1, n1);
         }
     } else {
-        hipLaunchKernelGGL(k34_update<false>, dim3(tb.U), dim3(256), 0, st, tb, ws, grads, params, lr, clip_threshold, ws.chunk_usq);
-        hipLaunchKernelGGL(k34_update<true>, dim3(tb.U), dim3(256), 0, st, tb, ws, grads, params, lr, clip_threshold, ws.chunk_usq);
+        DESTA_CHECK_ARG(pl->n_ragged == 0, "adafactor: a ragged-tensor table needs cols_multiple_of_4 = 1 for the tensors with chunks");
+        hipLaunchKernelGGL(k34_update<false>, dim3(tb.U), dim3(256), 0, st, tb, ws, grads, params, lr, clip_threshold, ws.chunk_usq, 0);
+        hipLaunchKernelGGL(k34_totals, dim3(tb.T), dim3(256), 0, st, tb, 0, ws.chunk_usq);
+        hipLaunchKernelGGL(k34_update<true>, dim3(tb.U), dim3(256), 0, st, tb, ws, grads, params, lr, clip_threshold, ws.chunk_usq, 0);
         if (tb.V > 0) hipLaunchKernelGGL(v2_update, dim3(tb.V), dim3(256), 0, st, tb, ws, grads, params, state, beta2t, eps1, lr, clip_threshold);
     }
     DESTA_CHECK_LAUNCH("clip_adafactor_step");

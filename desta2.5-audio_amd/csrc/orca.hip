@@ -158,26 +158,36 @@ __global__ __launch_bounds__(256) void gate_mlp_bwd_k(const float* __restrict__ 
         dpre[i] = f2bf(dg2[m] * w2[k] * gelu_erf_grad(bf2f(pre[i])));
     }
 }
-// dw2[k] = sum_m dg2[m] * g1[m,k]  (g1 = the bf16 GELU output the forward fed to the dot),  db2 = sum_m dg2[m]; block = 64 columns x 4 row lanes
-__global__ __launch_bounds__(256) void gate_w2_grad_k(const float* __restrict__ dg2, const bf16_t* __restrict__ g1, long M, int Hq, float* __restrict__ dw2,
-                                                      float* __restrict__ db2) {
+// dw2[k] = sum_m dg2[m] * g1[m,k]  (g1 = the bf16 GELU output the forward fed to the dot),  db2 = sum_m dg2[m].  Two launches, fixed order:
+// block (x, y) = 64 columns x 4 row lanes over row slice y of W2_SPLIT -> part[y][0 .. Hq) and part[y][Hq] (the bias term); then the
+// slices are added in slice order.  [One launch of Hq / 64 blocks walking all rows took 0.5 ms per layer at 5120 x 1024.]
+constexpr int W2_SPLIT = 64;
+__global__ __launch_bounds__(256) void gate_w2_grad_k(const float* __restrict__ dg2, const bf16_t* __restrict__ g1, long M, int Hq, float* __restrict__ part) {
     __shared__ float sh[4][64];
-    const int c = threadIdx.x & 63, r4 = threadIdx.x >> 6, col = blockIdx.x * 64 + c;
+    const int c = threadIdx.x & 63, r4 = threadIdx.x >> 6, col = blockIdx.x * 64 + c, y = blockIdx.y;
+    const long per = (M + W2_SPLIT - 1) / W2_SPLIT, m0 = y * per, m1 = m0 + per < M ? m0 + per : M;
     float acc = 0.f, accb = 0.f;
-    for (long m = r4; m < M; m += 4) {
+    for (long m = m0 + r4; m < m1; m += 4) {
         const float d = dg2[m];
         if (col < Hq) acc += d * bf2f(g1[m * Hq + col]);
         if (blockIdx.x == 0 && c == 0) accb += d;
     }
     sh[r4][c] = acc;
     __syncthreads();
-    if (r4 == 0 && col < Hq) dw2[col] = sh[0][c] + sh[1][c] + sh[2][c] + sh[3][c];
+    if (r4 == 0 && col < Hq) part[(long)y * (Hq + 1) + col] = sh[0][c] + sh[1][c] + sh[2][c] + sh[3][c];
     __syncthreads();
     if (blockIdx.x == 0) {
         if (c == 0) sh[r4][0] = accb;
         __syncthreads();
-        if (threadIdx.x == 0) db2[0] = sh[0][0] + sh[1][0] + sh[2][0] + sh[3][0];
+        if (threadIdx.x == 0) part[(long)y * (Hq + 1) + Hq] = sh[0][0] + sh[1][0] + sh[2][0] + sh[3][0];
     }
+}
+__global__ __launch_bounds__(256) void gate_w2_fin_k(const float* __restrict__ part, int Hq, float* __restrict__ dw2, float* __restrict__ db2) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col > Hq) return;
+    float s = 0.f;
+    for (int y = 0; y < W2_SPLIT; ++y) s += part[(long)y * (Hq + 1) + col];
+    if (col < Hq) dw2[col] = s; else db2[0] = s;
 }
 
 // per-layer alignment loss, gradient w.r.t. the hidden rows of the span: L = coef * sum_e (1 - cos(a_e, t_e)), t_e = mean_{s in span} hs[row, s, :]
@@ -378,12 +388,14 @@ extern "C" int desta_orca_gate_residual_bwd(const void* d_out, int64_t ld, const
 }
 
 extern "C" int desta_orca_gate_mlp_bwd(const float* d_gate_pre, const void* gate_preact, const void* gate_hidden, const float* gate_w2, int64_t rows, int gate_width,
-                                       void* d_preact, float* d_w2, float* d_b2, void* stream) {
-    DESTA_CHECK_ARG(d_gate_pre && gate_preact && gate_hidden && gate_w2 && d_preact && d_w2 && d_b2 && rows > 0 && gate_width > 0, "orca_gate_mlp_bwd: bad argument");
+                                       void* d_preact, float* d_w2, float* d_b2, float* workspace, void* stream) {
+    DESTA_CHECK_ARG(d_gate_pre && gate_preact && gate_hidden && gate_w2 && d_preact && d_w2 && d_b2 && workspace && rows > 0 && gate_width > 0,
+                    "orca_gate_mlp_bwd: bad argument");
     hipLaunchKernelGGL(gate_mlp_bwd_k, dim3(nblk(rows * gate_width)), dim3(256), 0, (hipStream_t)stream, d_gate_pre, (const bf16_t*)gate_preact, gate_w2, (long)rows,
                        gate_width, (bf16_t*)d_preact);
-    hipLaunchKernelGGL(gate_w2_grad_k, dim3((unsigned)((gate_width + 63) / 64)), dim3(256), 0, (hipStream_t)stream, d_gate_pre, (const bf16_t*)gate_hidden, (long)rows,
-                       gate_width, d_w2, d_b2);
+    hipLaunchKernelGGL(gate_w2_grad_k, dim3((unsigned)((gate_width + 63) / 64), W2_SPLIT), dim3(256), 0, (hipStream_t)stream, d_gate_pre, (const bf16_t*)gate_hidden,
+                       (long)rows, gate_width, workspace);
+    hipLaunchKernelGGL(gate_w2_fin_k, dim3((unsigned)((gate_width + 1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, gate_width, d_w2, d_b2);
     DESTA_CHECK_LAUNCH("orca_gate_mlp_bwd");
     return DESTA_OK;
 }

@@ -40,7 +40,7 @@ class GemmDesc(C.Structure):
 
 lib.desta_abi_version.restype = i32
 lib.desta_last_error.restype = C.c_char_p
-ABI_VERSION = 6
+ABI_VERSION = 7
 if lib.desta_abi_version() != ABI_VERSION:
     raise ImportError(f"libdesta_hip.so has ABI version {lib.desta_abi_version()}, this binding needs {ABI_VERSION}: "
                       "rebuild with `python desta2.5-audio_amd/build.py`")
@@ -229,7 +229,7 @@ class OptPlan(C.Structure):
                 ("sum_rows", i64), ("sum_cols", i64), ("max_batch", i32), ("max_cols", i32),
                 ("chunks", vp), ("ten_chunks", vp), ("n_chunks", i32), ("max_chunks_per_tensor", i32),
                 ("fin", vp), ("n_fin", i32), ("colpart_floats", i64), ("cols_multiple_of_4", i32),
-                ("group_bounds", vp), ("n_groups", i32)]
+                ("group_bounds", vp), ("n_groups", i32), ("ragged_units", vp), ("n_ragged", i32)]
 
 
 lib.desta_adafactor_workspace_floats.restype = C.c_size_t
@@ -699,7 +699,7 @@ def orca_align(audio, tokens, hidden, row_stride, batch_stride, hidden_size, spa
 
 
 _orca_gate_residual_bwd = _sig("desta_orca_gate_residual_bwd", vp, i64, vp, vp, i64, i32, vp, vp, vp)
-_orca_gate_mlp_bwd = _sig("desta_orca_gate_mlp_bwd", vp, vp, vp, vp, i64, i32, vp, vp, vp, vp)
+_orca_gate_mlp_bwd = _sig("desta_orca_gate_mlp_bwd", vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp)
 _orca_align_bwd = _sig("desta_orca_align_bwd", vp, i32, vp, i64, i64, i32, vp, i32, C.c_float, vp, i64, i64, vp)
 _orca_rope_bwd = _sig("desta_orca_rope_bwd", vp, i32, i32, i32, C.c_float, C.c_float, i32, i32, vp, vp, vp)
 _orca_col2im_add = _sig("desta_orca_col2im_add", vp, i32, i32, i32, i32, i32, i32, vp, vp)
@@ -711,9 +711,15 @@ def orca_gate_residual_bwd(d_out, ld, cross, gate, rows, hidden_size, d_cross, d
     check(_orca_gate_residual_bwd(p(d_out), ld, p(cross), p(gate), rows, hidden_size, p(d_cross), p(d_gate_pre), stream()), "desta_orca_gate_residual_bwd")
 
 
+_gate_ws: dict = {}
+
+
 def orca_gate_mlp_bwd(d_gate_pre, gate_preact, gate_hidden, gate_w2, rows, gate_width, d_preact, d_w2, d_b2):
-    check(_orca_gate_mlp_bwd(p(d_gate_pre), p(gate_preact), p(gate_hidden), p(gate_w2), rows, gate_width, p(d_preact), p(d_w2), p(d_b2), stream()),
-          "desta_orca_gate_mlp_bwd")
+    key = (d_gate_pre.device, gate_width)
+    if key not in _gate_ws:                                                   # 64 row slices x (gate_width + 1) partial sums
+        _gate_ws[key] = torch.empty(64 * (gate_width + 1), dtype=torch.float32, device=d_gate_pre.device)
+    check(_orca_gate_mlp_bwd(p(d_gate_pre), p(gate_preact), p(gate_hidden), p(gate_w2), rows, gate_width, p(d_preact), p(d_w2), p(d_b2), p(_gate_ws[key]),
+                             stream()), "desta_orca_gate_mlp_bwd")
 
 
 def orca_align_bwd(audio, tokens, hidden, row_stride, batch_stride, hidden_size, spans, n_spans, coef, d_hidden, d_row_stride, d_batch_stride):

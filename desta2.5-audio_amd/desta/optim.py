@@ -139,9 +139,14 @@ class FusedAdafactor:
         # work items of the update kernels: <= CHUNK contiguous elements of one [rows, cols] matrix; tensors in DESCENDING
         # arena order (the update pass starts where the statistics pass ended: that tail is still in the Infinity Cache),
         # the chunks of one tensor contiguous
+        # Tensors with ragged rows (cols % 4 != 0: the ORCA Conv1d weight [h, h, 5]) get no chunks: the unit-based kernels update them
+        # over their own unit range (`ragged_units`, ABI 7)
         chunks, ten_chunks, fin = [], [[0, 0] for _ in tensors], []
+        ragged = [ti for ti, t in enumerate(tensors) if t[3] % 4 != 0]
         for ti in reversed(range(len(tensors))):
             _, nb, R, Cn = tensors[ti][:4]
+            if ti in ragged:
+                continue
             ten_chunks[ti][0] = len(chunks)
             for b in range(nb):
                 for e0 in range(0, R * Cn, CHUNK):
@@ -156,10 +161,15 @@ class FusedAdafactor:
         pl.chunks, pl.ten_chunks, pl.n_chunks = self._chunks.data_ptr(), self._ten_chunks.data_ptr(), len(chunks)
         pl.max_chunks_per_tensor = max([c[1] for c in ten_chunks] or [0])
         pl.fin, pl.n_fin, pl.colpart_floats = self._fin.data_ptr(), len(fin), col_ws_off
-        pl.cols_multiple_of_4 = int(all(t[3] % 4 == 0 for t in tensors))
+        pl.cols_multiple_of_4 = 1
+        rag = [v for ti in ragged for v in (tensors[ti][6], tensors[ti][7])]
+        self._ragged = (ctypes.c_int32 * max(len(rag), 1))(*rag)                # HOST array, kept alive with the plan
+        pl.ragged_units, pl.n_ragged = ctypes.cast(self._ragged, ctypes.c_void_p), len(ragged)
         # launch groups: cut the chunk list at tensor boundaries (a tensor's rms needs all of its chunk sums before its apply)
         bounds, acc = [0], 0
         for ti in reversed(range(len(tensors))):
+            if ti in ragged:
+                continue
             n = tensors[ti][1] * tensors[ti][2] * tensors[ti][3]
             if acc and acc + n > GROUP_FLOATS:
                 bounds.append(ten_chunks[ti][0])

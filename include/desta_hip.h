@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DESTA_ABI_VERSION 6
+#define DESTA_ABI_VERSION 7
 
 int desta_abi_version(void);
 /* sizeof of the descriptor structs as this library was compiled (0 = desta_gemm_desc, 1 = desta_attn_desc,
@@ -159,8 +159,13 @@ typedef struct desta_opt_plan {
     const int32_t* chunks; const int32_t* ten_chunks; int n_chunks, max_chunks_per_tensor;
     const int32_t* fin; int n_fin;
     int64_t colpart_floats;
-    int cols_multiple_of_4;          /* every factored tensor has cols % 4 == 0 (16-B row accesses in the chunk kernels) */
+    int cols_multiple_of_4;          /* every factored tensor WITH CHUNKS has cols % 4 == 0 (16-B row accesses in the chunk kernels) */
     const int32_t* group_bounds; int n_groups;
+    /* ABI 7: factored tensors with ragged rows (cols % 4 != 0, e.g. a Conv1d weight [out, in, 5]) carry NO chunks
+     * (ten_chunks = (0, 0)) and are updated by the unit-based kernels: ragged_units = HOST array [n_ragged][2] of
+     * (first unit, unit count), one entry per such tensor.  n_ragged == 0 with cols_multiple_of_4 == 0 is the ABI <= 6
+     * behaviour (EVERY tensor on the unit-based kernels). */
+    const int32_t* ragged_units; int n_ragged;
 } desta_opt_plan;
 size_t desta_adafactor_workspace_floats(int n_units, int n_vec, int64_t sum_rows, int64_t sum_cols,
                                         int64_t colpart_floats);      /* ABI <= 2 layout, kept for old callers */
@@ -278,6 +283,7 @@ int desta_tap_mix_bwd(const float* x, const float* layer_weights, const float* d
 /* Backward pieces (autograd of the modules above; gradients of the trainer's total loss = LM loss + sum of the ORCA losses):
  *   desta_orca_gate_residual_bwd  d_cross[m,:] = gate[m] d_out[m,:];  d_gate_pre[m] = (d_out[m,:] . cross[m,:]) gate[m] (1 - gate[m])
  *   desta_orca_gate_mlp_bwd       d_preact = d_gate_pre (x) w2 * gelu'(preact);  d_w2 = sum_m d_gate_pre[m] gate_hidden[m,:];  d_b2 = sum_m d_gate_pre[m]
+ *                                 (workspace: 64 x (gate_width + 1) floats, ABI 7: row slices summed in a fixed order)
  *   desta_orca_align_bwd          d_hidden[row, s, :] += coef * d(1 - cos)/d(mean over the span) / span length   (audio pooled under no_grad, :461-462)
  *   desta_orca_rope_bwd           rotation by the negative angle of the fp32 gradient of the rotated tokens, ADDED to d_first (tokens [0, n_first)
  *                                 of every clip: the global tokens under orca_global_cross_attn) resp. d_rest (the local tokens)
@@ -296,7 +302,7 @@ int desta_orca_align(const void* audio, int tokens, const void* hidden, int64_t 
 int desta_orca_gate_residual_bwd(const void* d_out, int64_t ld, const void* cross, const float* gate, int64_t rows, int hidden_size, void* d_cross,
                                  float* d_gate_pre, void* stream);
 int desta_orca_gate_mlp_bwd(const float* d_gate_pre, const void* gate_preact, const void* gate_hidden, const float* gate_w2, int64_t rows, int gate_width,
-                            void* d_preact, float* d_w2, float* d_b2, void* stream);
+                            void* d_preact, float* d_w2, float* d_b2, float* workspace, void* stream);
 int desta_orca_align_bwd(const void* audio, int tokens, const void* hidden, int64_t hidden_row_stride, int64_t hidden_batch_stride, int hidden_size,
                          const int32_t* spans, int n_spans, float coef, void* d_hidden, int64_t d_row_stride, int64_t d_batch_stride, void* stream);
 int desta_orca_rope_bwd(const float* d_rotated, int batch, int tokens, int hidden, float theta, float position_scale, int round_cos_sin, int n_first,

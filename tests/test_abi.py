@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/desta_hip.h but not exported"
     lib.desta_abi_version.restype = ctypes.c_int
-    assert lib.desta_abi_version() == 6
+    assert lib.desta_abi_version() == 7
 
 
 def test_host_side_table_helper_runs_without_gpu():

@@ -476,10 +476,17 @@ def test_adafactor_connector_shapes(hip):
     assert opt.plan.n_groups >= 1 and opt.plan.max_chunks_per_tensor == 320
 
 
-def test_adafactor_ragged_rows_take_the_two_launch_path(hip):
-    """cols % 4 != 0 (no 16-B row accesses): the plan is routed to the two-launch update; same numbers."""
+def test_adafactor_ragged_rows_take_the_unit_kernels(hip):
+    """cols % 4 != 0 (no 16-B row accesses): such tensors carry no chunks and are updated by the unit-based kernels over their own
+    unit range (ABI 7: `ragged_units`), the others stay on the chunk kernels; same numbers.  Cases: a mix, a plan whose factored
+    tensors are ALL ragged (no chunk launch at all, 1-D tensors on their own launch), and a Conv1d-like [out, in, 5] weight
+    (ORCA's local_conv: batch = out, 5 columns, hundreds of units whose sums `k34_totals_range` adds up once per tensor)."""
     _, opt = _run_adafactor_case(hip, [(33, 7), (5, 3, 9), (11,), (40, 64)], steps=3, gscale=[0.5, 4.0])
-    assert opt.plan.cols_multiple_of_4 == 0
+    assert opt.plan.cols_multiple_of_4 == 1 and opt.plan.n_ragged == 2 and opt.plan.n_chunks == 1
+    _, opt = _run_adafactor_case(hip, [(33, 7), (9,), (5, 3, 9)], steps=3, gscale=[0.5, 4.0])
+    assert opt.plan.n_ragged == 2 and opt.plan.n_chunks == 0
+    _, opt = _run_adafactor_case(hip, [(64, 4), (192, 130, 5), (192,), (256, 192)], steps=2, gscale=[0.05, 3.0])
+    assert opt.plan.n_ragged == 1 and opt.plan.n_units >= 192 * 3
 
 
 def test_adafactor_many_chunk_tensor_and_full_arena_order(hip):
