@@ -101,12 +101,16 @@ class FusedAdafactor:
                 st_off += _al(nb * R, 4)
                 col_off = st_off
                 st_off += _al(nb * Cn, 4)
-                upb = (R + UNIT_ROWS - 1) // UNIT_ROWS
+                # rows per statistics unit: 64; a tensor with ragged rows (cols % 4 != 0, in practice a Conv1d weight [out, in, k]: `in` rows of
+                # k columns per batch item) takes up to 32 K elements per unit instead — 64 x 5 elements per block would mean 262 144 blocks
+                # for ORCA's [4096, 4096, 5] local_conv.weight
+                ur = UNIT_ROWS if Cn % 4 == 0 else max(UNIT_ROWS, min(R, 32768 // Cn))
+                upb = (R + ur - 1) // ur
                 unit0 = len(units)
                 for b in range(nb):
                     for k in range(upb):
-                        r0 = k * UNIT_ROWS
-                        units.append([len(tensors), b, r0, min(UNIT_ROWS, R - r0)])
+                        r0 = k * ur
+                        units.append([len(tensors), b, r0, min(ur, R - r0)])
                         ucol.append(col_ws_off)
                         col_ws_off += _al(Cn, 4)
                 tensors.append([arena.offsets[name], nb, R, Cn, row_off, col_off, unit0, nb * upb])

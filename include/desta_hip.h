@@ -138,7 +138,8 @@ int desta_gemm_set_option(int option, int value);
  * DEVICE arrays built once by the caller:
  *   tensors  int64 [n_tensors][8] : arena offset, batch, rows, cols, row_state_off, col_state_off,
  *                                   first unit, number of units   (offsets in floats, multiples of 4)
- *   units    int32 [n_units][4]   : tensor index, batch index, first row, number of rows (<= 64)
+ *   units    int32 [n_units][4]   : tensor index, batch index, first row, number of rows (64 on the chunk path; any count for a
+ *                                   tensor with ragged rows, ABI 7)
  *   unit_col_off int64 [n_units]  : offset of the unit's column partial sums in the workspace
  *   vecs     int64 [n_vec][3]     : arena offset, length, state offset
  * `state` holds exp_avg_sq_row / exp_avg_sq_col / exp_avg_sq.  workspace[0] = pre-clip global
