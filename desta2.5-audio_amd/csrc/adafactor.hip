@@ -37,6 +37,7 @@ constexpr int UNIT_ROWS = 64;      // rows per stats unit (4 waves x 16 rows)
 constexpr int MAXSEG = 16;         // 256-column segments per row handled in registers (cols <= 4096)
 constexpr int CHUNK_V4 = 16;       // float4 per thread and chunk in the update kernel
 constexpr int CHUNK = 256 * 4 * CHUNK_V4;
+constexpr int NARROW = 16;         // ragged tensors with <= 16 columns: one thread per row in the unit kernels
 
 struct Tab {
     const long* ten;               // [T][8]: offset, batch, rows, cols, row_state_off, col_state_off, unit0, nunits
@@ -127,6 +128,34 @@ __global__ __launch_bounds__(256) void af_stats(Tab tb, Ws ws, const float* __re
         if (nseg <= 5) stats_rows<5, 4>(gt, Cn, row0, nrows, wave, lane, cacc, rowsum_out, tot);
         else if (nseg <= 12) stats_rows<12, 2>(gt, Cn, row0, nrows, wave, lane, cacc, rowsum_out, tot);
         else stats_rows<MAXSEG, 1>(gt, Cn, row0, nrows, wave, lane, cacc, rowsum_out, tot);
+    } else if (Cn <= NARROW) {
+        // a few columns per row (Conv1d weight [out, in, k]: k columns): one THREAD per row — a wave reads 64 consecutive rows, and the
+        // column sums are k block reductions at the end (fixed order)
+        float ca[NARROW];
+#pragma unroll
+        for (int c = 0; c < NARROW; ++c) ca[c] = 0.f;
+        for (int rr = threadIdx.x; rr < nrows; rr += 256) {
+            const float* gr = gt + (long)(row0 + rr) * Cn;
+            float rsum = 0.f;
+#pragma unroll
+            for (int c = 0; c < NARROW; ++c) {
+                if (c < Cn) { float x = gr[c]; x *= x; ca[c] += x; rsum += x; }
+            }
+            rowsum_out[row0 + rr] = rsum;
+            tot += rsum;
+        }
+        float* cpn = ws.colpart + tb.unit_col_off[u];
+#pragma unroll
+        for (int c = 0; c < NARROW; ++c) {
+            if (c < Cn) {
+                const float s = block_sum<256>(ca[c], red);
+                if (threadIdx.x == 0) cpn[c] = s;
+                __syncthreads();
+            }
+        }
+        tot = block_sum<256>(tot, red);
+        if (threadIdx.x == 0) ws.unit_sumsq[u] = tot;
+        return;
     } else {                                        // ragged rows: scalar loads
         for (int rr = wave; rr < nrows; rr += 4) {
             const float* gr = gt + (long)(row0 + rr) * Cn;
@@ -392,6 +421,30 @@ __global__ __launch_bounds__(256) void k34_update(Tab tb, Ws ws, const float* __
         decay = 1.0f - tb.ten_wd[t] * lr;
     }
     float tot = 0.f;
+    if (!vec4 && Cn <= NARROW) {                    // one thread per row (see af_stats)
+        float cf[NARROW];
+#pragma unroll
+        for (int cc = 0; cc < NARROW; ++cc) cf[cc] = cc < Cn ? cfac[cc] : 0.f;
+        for (int rr = threadIdx.x; rr < nrows; rr += 256) {
+            const int r = row0 + rr;
+            const float rf = rfac[r] * c;
+            const float* gr = g + base + (long)r * Cn;
+            float* pr = p + base + (long)r * Cn;
+#pragma unroll
+            for (int cc = 0; cc < NARROW; ++cc) {
+                if (cc < Cn) {
+                    const float uv = gr[cc] * rf * cf[cc];
+                    if (APPLY) pr[cc] = pr[cc] * decay - scale * uv;
+                    else tot += uv * uv;
+                }
+            }
+        }
+        if (!APPLY) {
+            tot = block_sum<256>(tot, red);
+            if (threadIdx.x == 0) unit_usq[u] = tot;
+        }
+        return;
+    }
     for (int rr = wave; rr < nrows; rr += 4) {
         const int r = row0 + rr;
         const float rf = rfac[r] * c;

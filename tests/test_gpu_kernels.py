@@ -487,6 +487,9 @@ def test_adafactor_ragged_rows_take_the_unit_kernels(hip):
     assert opt.plan.n_ragged == 2 and opt.plan.n_chunks == 0
     _, opt = _run_adafactor_case(hip, [(64, 4), (192, 130, 5), (192,), (256, 192)], steps=2, gscale=[0.05, 3.0])
     assert opt.plan.n_ragged == 1 and opt.plan.n_units == 1 + 192 + 4          # one unit per [130, 5] batch item of the ragged tensor
+    # ragged AND wider than the one-thread-per-row form (<= 16 columns): the wave-per-row scalar form
+    _, opt = _run_adafactor_case(hip, [(20, 30), (3, 70, 259), (5,), (8, 12)], steps=2, gscale=[0.05, 3.0])
+    assert opt.plan.n_ragged == 2
 
 
 def test_adafactor_many_chunk_tensor_and_full_arena_order(hip):
