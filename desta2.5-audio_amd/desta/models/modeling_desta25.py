@@ -984,6 +984,7 @@ class OrcaHIP:
         self.rope_theta = float(cfg.extra.get("orca_rope_theta", c.rope_theta))
         self.conv_w = None
         self.B = 0
+        self._tb: Dict[tuple, torch.Tensor] = {}
 
     def refresh_weights(self) -> None:
         """bf16 operand of the Conv1d as an im2col GEMM: [out, in, k] -> [out, k * in] (tap-major rows of the padded token stream)."""
@@ -1029,19 +1030,37 @@ class OrcaHIP:
     def Gw(self, name):
         return self.con.arena.grad(name)
 
-    def _dW(self, dY: torch.Tensor, X: torch.Tensor, M: int, N: int, Kin: int, gw: torch.Tensor, gb: Optional[torch.Tensor]) -> None:
-        """gw [N, Kin] (fp32, written) = dY[M, N]^T X[M, Kin];  gb [N] = column sums of dY.  Both operands in transposed storage (the
-        token index is the reduction index); a token count that is not a multiple of 64 goes through zero-padded copies."""
-        if M % 64 != 0:
+    def _tbuf(self, tag: str, rows: int, Mp: int) -> torch.Tensor:
+        """Zero-initialised [rows, Mp] bf16 scratch for a transposed operand (columns past the token count stay zero: only [0, M) is written)."""
+        key = (tag, rows, Mp)
+        if key not in self._tb:
+            self._tb[key] = torch.zeros(rows, Mp, dtype=BF16, device=self.dev)
+        return self._tb[key]
+
+    def _transposed(self, tag: str, X: torch.Tensor, M: int, cols: int) -> torch.Tensor:
+        t = self._tbuf(tag, cols, _r64(M))
+        H.transpose_to_bf16(X, M, cols, t, t.shape[1], ld_in=X.shape[-1])
+        return t
+
+    def _dW(self, dY: torch.Tensor, X: torch.Tensor, M: int, N: int, Kin: int, gw: torch.Tensor, gb: Optional[torch.Tensor],
+            xT: Optional[torch.Tensor] = None) -> None:
+        """gw [N, Kin] (fp32, written) = dY[M, N]^T X[M, Kin];  gb [N] = column sums of dY.  Large products (the 4096-wide projections of a
+        full-size decoder): explicit bf16 transposes + the 256x256 NT kernel (217 -> 167 us at 4096 x 4096 x 5120, 152 with X^T shared:
+        tools/orca_dw_bench.py; `xT` = an X^T [Kin, r64(M)] the caller already holds).  Small ones: both operands in transposed storage
+        (the token index is the reduction index) on the 128x128 kernel, a token count that is not a multiple of 64 through zero-padded copies."""
+        if N * Kin >= (1 << 23) and M >= 1024:
+            tA = self._transposed("dY", dY, M, N)
+            tB = xT if xT is not None else self._transposed("X", X, M, Kin)
+            H.gemm(tA, tB, gw, N, Kin, tA.shape[1])
+        elif M % 64 != 0:
             Mp = _r64(M)
             dYp = torch.zeros(Mp, N, dtype=BF16, device=self.dev)
             Xp = torch.zeros(Mp, Kin, dtype=BF16, device=self.dev)
             dYp[:M].copy_(dY[:M])
             Xp[:M].copy_(X[:M])
-            dY_, X_, M_ = dYp, Xp, Mp
+            H.gemm(dYp, Xp, gw, N, Kin, Mp, trans_a=True, trans_b=True, lda=N, ldb=Kin)
         else:
-            dY_, X_, M_ = dY, X, M
-        H.gemm(dY_, X_, gw, N, Kin, M_, trans_a=True, trans_b=True, lda=N, ldb=Kin)
+            H.gemm(dY, X, gw, N, Kin, M, trans_a=True, trans_b=True, lda=N, ldb=Kin)
         if gb is not None:
             H.colsum(dY, M, N, N, gb)
 
@@ -1171,8 +1190,11 @@ class OrcaHIP:
         Kg = self.cfg.orca_global_num_tokens
         self.dglobal32 = torch.zeros(self.B * Kg, h, dtype=F32, device=dev)
         self.dlocal32 = torch.zeros(self.B * self.Tl, h, dtype=F32, device=dev)
+        self.audioT = None
         if self.audio is not None:
             self.d_audio32 = torch.zeros(self.Bq * self.Ta, h, dtype=F32, device=dev)
+            if 2 * self.hp * h >= (1 << 23) and self.Bq * self.Ta >= 1024:        # X^T of every layer's k|v weight gradient (`_dW`)
+                self.audioT = self._transposed("audio", self.audio, self.Bq * self.Ta, h)
 
     def inject_bwd(self, l: int, dx: torch.Tensor) -> None:
         """dx [B*S, h] bf16 = d(loss) / d(output of decoder layer l AFTER its injection), updated IN PLACE to the gradient w.r.t. the output
@@ -1208,7 +1230,7 @@ class OrcaHIP:
         H.gemm(dcross16, w_o, datt16, M, hp, h, trans_b=True, ldb=hp)
         H.attention_bwd(s["ad"], datt16, dq16, dkv16, dkv16, dk_off=0, dv_off=hp)
         self._dW(dq16, s["xpre"], M, hp, h, gq_p, gbq_p)
-        self._dW(dkv16, self.audio, B * Ta, 2 * hp, h, gkv_p, gbkv_p)
+        self._dW(dkv16, self.audio, B * Ta, 2 * hp, h, gkv_p, gbkv_p, xT=self.audioT)
         if self.padded:
             gw_in[:h].view(nh, hd, h).copy_(gq_p.view(nh, hdp, h)[:, :hd])
             gw_in[h:].view(2 * nh, hd, h).copy_(gkv_p.view(2 * nh, hdp, h)[:, :hd])

@@ -381,3 +381,26 @@ def test_orca_full_size_step_properties(name):
               "batch_features": batch["batch_features"][:2], "batch_transcription_ids": t["batch_transcription_ids"]}
     ids = model._generate_step(inputs, pad_token_id=0, max_new_tokens=4, do_sample=False, eos_token_id=[])
     assert ids.shape == (2, 4) and torch.equal(ids, model._generate_step(inputs, pad_token_id=0, max_new_tokens=4, do_sample=False, eos_token_id=[]))
+
+
+def test_orca_weight_gradient_gemm_forms_agree():
+    """`OrcaHIP._dW` picks explicit transposes + the 256x256 NT kernel for the large projections of a full-size decoder (no tiny-model
+    test reaches that branch) and transposed-storage operands otherwise: both against fp32 matmul, with a token count that is not a
+    multiple of 64 (zero pad columns of the scratch), a caller-held X^T, and a second call that reuses the scratch."""
+    from desta.models.modeling_desta25 import OrcaHIP
+    o = OrcaHIP.__new__(OrcaHIP)
+    o._tb, o.dev = {}, torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(5)
+    for M, N, K in ((1100, 4096, 2048), (1100, 4096, 2048), (1100, 512, 256), (1088, 512, 256)):
+        dY = torch.randn(M, N, generator=gen).to(torch.bfloat16).cuda()
+        X = torch.randn(M, K, generator=gen).to(torch.bfloat16).cuda()
+        gw, gb = torch.empty(N, K, device="cuda"), torch.empty(N, device="cuda")
+        o._dW(dY, X, M, N, K, gw, gb)
+        ref = dY.float().T @ X.float()
+        assert rel_err(gw.cpu(), ref.cpu()) < 2e-5, (M, N, K)
+        assert rel_err(gb.cpu(), dY.float().sum(0).cpu()) < 1e-5
+        if N * K >= 1 << 23:
+            assert ("dY", N, 1152) in o._tb                                     # the transposed form ran (r64(1100) = 1152 columns)
+            gw2 = torch.empty_like(gw)
+            o._dW(dY, X, M, N, K, gw2, None, xT=o._transposed("audio", X, M, K))
+            assert torch.equal(gw, gw2)
