@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void ce_finish_k(const float* __restrict__ row
     if (threadIdx.x == 0) loss[0] = s * scal[1];
 }
 
-constexpr int MAXT = 8;
+constexpr int MAXT = 32;           // tapped encoder layers (4 in the shipped configs; 32 = every layer of whisper-large with orca_use_all_layers)
 
 // out[n][c] = sum_j softmax(lw[k])[j] * x[j][n][c],  n = b*K + k;  x: [taps][N][d] f32
 __global__ __launch_bounds__(256) void mix_fwd_k(const float* __restrict__ x, const float* __restrict__ lw, int taps, int N,

@@ -25,10 +25,11 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {        // 256 t
     return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+constexpr int MAX_TAPS = 32;       // tapped encoder layers: 4 in the shipped configs, every layer of whisper-large with orca_use_all_layers
 // out[r, :] = sum_l softmax(w)[l] * x[l, r, :]   (x bf16 [taps][rows][d], out bf16)
 __global__ __launch_bounds__(256) void local_mix_k(const bf16_t* __restrict__ x, const float* __restrict__ w, int taps, long rows, int d,
                                                    bf16_t* __restrict__ out) {
-    float wl[8], mx = -INFINITY, den = 0.f;
+    float wl[MAX_TAPS], mx = -INFINITY, den = 0.f;
     for (int l = 0; l < taps; ++l) mx = fmaxf(mx, w[l]);
     for (int l = 0; l < taps; ++l) { wl[l] = __expf(w[l] - mx); den += wl[l]; }
     for (int l = 0; l < taps; ++l) wl[l] /= den;
@@ -268,25 +269,33 @@ __global__ __launch_bounds__(256) void col2im_add_k(const bf16_t* __restrict__ d
 // d(local_layer_weights): dots[l] = sum_{r,c} dfused[r,c] * x[l,r,c] (per-block partials, fixed-order finish), then the softmax Jacobian
 __global__ __launch_bounds__(256) void local_mix_bwd_k(const bf16_t* __restrict__ dfused, const bf16_t* __restrict__ x, int taps, long rows, int d, float* __restrict__ part) {
     __shared__ float sh[4];
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float acc[MAX_TAPS];
+#pragma unroll
+    for (int l = 0; l < MAX_TAPS; ++l) acc[l] = 0.f;
     const long n8 = rows * (d / 8);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
         const u16x8 g = *(const u16x8*)(dfused + i * 8);
-        for (int l = 0; l < taps; ++l) {
-            const u16x8 v = *(const u16x8*)(x + (long)l * rows * d + i * 8);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[l] += bf2f(g[e]) * bf2f(v[e]);
+        for (int l = 0; l < MAX_TAPS; ++l) {                                  // (static indices: the accumulators stay in registers)
+            if (l < taps) {
+                const u16x8 v = *(const u16x8*)(x + (long)l * rows * d + i * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[l] += bf2f(g[e]) * bf2f(v[e]);
+            }
         }
     }
-    for (int l = 0; l < taps; ++l) {
-        const float s = block_sum(acc[l], sh);
-        if (threadIdx.x == 0) part[(long)blockIdx.x * 8 + l] = s;
+#pragma unroll
+    for (int l = 0; l < MAX_TAPS; ++l) {
+        if (l < taps) {
+            const float s = block_sum(acc[l], sh);
+            if (threadIdx.x == 0) part[(long)blockIdx.x * MAX_TAPS + l] = s;
+        }
     }
 }
 __global__ void local_mix_bwd_fin_k(const float* __restrict__ part, int nblk, const float* __restrict__ w, int taps, float* __restrict__ dw) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float dots[8], p[8], mx = -INFINITY, den = 0.f, mean = 0.f;
-    for (int l = 0; l < taps; ++l) { float s = 0.f; for (int b = 0; b < nblk; ++b) s += part[(long)b * 8 + l]; dots[l] = s; mx = fmaxf(mx, w[l]); }
+    float dots[MAX_TAPS], p[MAX_TAPS], mx = -INFINITY, den = 0.f, mean = 0.f;
+    for (int l = 0; l < taps; ++l) { float s = 0.f; for (int b = 0; b < nblk; ++b) s += part[(long)b * MAX_TAPS + l]; dots[l] = s; mx = fmaxf(mx, w[l]); }
     for (int l = 0; l < taps; ++l) { p[l] = __expf(w[l] - mx); den += p[l]; }
     for (int l = 0; l < taps; ++l) { p[l] /= den; mean += p[l] * dots[l]; }
     for (int l = 0; l < taps; ++l) dw[l] = p[l] * (dots[l] - mean);
@@ -334,7 +343,7 @@ inline unsigned nblk(long n) { long b = (n + 255) / 256; return (unsigned)(b < 1
 }  // namespace
 
 extern "C" int desta_orca_local_mix(const void* x, const float* layer_weights, int taps, int64_t rows, int d, void* out, void* stream) {
-    DESTA_CHECK_ARG(x && layer_weights && out && taps > 0 && taps <= 8 && rows > 0 && d % 8 == 0, "orca_local_mix: bad argument");
+    DESTA_CHECK_ARG(x && layer_weights && out && taps > 0 && taps <= 32 && rows > 0 && d % 8 == 0, "orca_local_mix: bad argument");
     hipLaunchKernelGGL(local_mix_k, dim3(nblk(rows * (d / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, layer_weights, taps, (long)rows, d, (bf16_t*)out);
     DESTA_CHECK_LAUNCH("orca_local_mix");
     return DESTA_OK;
@@ -429,8 +438,8 @@ extern "C" int desta_orca_col2im_add(const void* d_col, int batch, int tokens_ou
 
 extern "C" int desta_orca_local_mix_bwd(const void* d_out, const void* x, const float* layer_weights, int taps, int64_t rows, int d, float* d_layer_weights,
                                         float* workspace, void* stream) {
-    DESTA_CHECK_ARG(d_out && x && layer_weights && d_layer_weights && workspace && taps > 0 && taps <= 8 && rows > 0 && d % 8 == 0, "orca_local_mix_bwd: bad argument");
-    const int nb = 256;                                                      /* workspace: 256 * 8 floats */
+    DESTA_CHECK_ARG(d_out && x && layer_weights && d_layer_weights && workspace && taps > 0 && taps <= 32 && rows > 0 && d % 8 == 0, "orca_local_mix_bwd: bad argument");
+    const int nb = 256;                                                      /* workspace: 256 * 32 floats */
     hipLaunchKernelGGL(local_mix_bwd_k, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)d_out, (const bf16_t*)x, taps, (long)rows, d, workspace);
     hipLaunchKernelGGL(local_mix_bwd_fin_k, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, nb, layer_weights, taps, d_layer_weights);
     DESTA_CHECK_LAUNCH("orca_local_mix_bwd");

@@ -737,7 +737,7 @@ def orca_col2im_add(d_col, batch, tokens_out, tokens_padded, hidden, kernel, str
 
 
 def orca_local_mix_bwd(d_out, x, layer_weights, taps, rows, d, d_layer_weights):
-    ws = scratch(2048, d_out.device, tag="orca_mix")
+    ws = scratch(256 * 32, d_out.device, tag="orca_mix")
     check(_orca_local_mix_bwd(p(d_out), p(x), p(layer_weights), taps, rows, d, p(d_layer_weights), p(ws), stream()), "desta_orca_local_mix_bwd")
 
 

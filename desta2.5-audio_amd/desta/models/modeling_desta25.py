@@ -132,8 +132,6 @@ class DeSTA25Config:
         if connector_mode == "qformer_1" and orca_enabled:
             raise NotImplementedError("orca_enabled with connector_mode 'qformer_1' (the Q-Former auxiliary losses, modeling_desta25.py:846-930) "
                                       "is not implemented")
-        if connector_mode == "orca_hybrid" and (orca_use_all_layers or not orca_local_enabled):
-            raise NotImplementedError("orca_hybrid: orca_use_all_layers / orca_local_enabled=False ablations are not implemented")
         # ORCA hybrid: connector, deep injection, auxiliary losses — forward, backward and generation run on the device
         # and are pinned to the reference's goldens.  Field names and defaults: :645-692.
         self.orca_enabled = bool(orca_enabled) or connector_mode == "orca_hybrid"
@@ -169,6 +167,8 @@ class DeSTA25Config:
                 self.target_layer_ids = list(_TAPS_BY_DEPTH[self.encoder_config.encoder_layers])
             else:
                 raise NotImplementedError(f"model_id {encoder_model_id} not implemented")
+        if connector_mode == "orca_hybrid" and self.orca_use_all_layers and target_layer_ids is None:
+            self.target_layer_ids = list(range(self.encoder_config.encoder_layers))       # ORCAHybridConnector.__init__ (:221-224)
         self.info = "Ｄｅｓｔａ２。５ Ａｕｄｉｏ"
         self.extra = dict(kwargs)
 
@@ -259,13 +259,14 @@ def connector_param_shapes(cfg: DeSTA25Config) -> "OrderedDict[str, Tuple[int, .
     if orca:
         # local branch (modeling_desta25.py:266-287) and the gated cross-attention of every decoder layer (:359-393, :1084-1098)
         k = cfg.orca_local_kernel_size
-        s[CON + "local_layer_weights"] = (nt,)
-        s[CON + "local_proj_in.weight"] = (h, d)
-        s[CON + "local_proj_in.bias"] = (h,)
-        s[CON + "local_conv.weight"] = (h, h, k)
-        s[CON + "local_conv.bias"] = (h,)
-        s[CON + "local_ln.weight"] = (h,)
-        s[CON + "local_ln.bias"] = (h,)
+        if cfg.orca_local_enabled:
+            s[CON + "local_layer_weights"] = (nt,)
+            s[CON + "local_proj_in.weight"] = (h, d)
+            s[CON + "local_proj_in.bias"] = (h,)
+            s[CON + "local_conv.weight"] = (h, h, k)
+            s[CON + "local_conv.bias"] = (h,)
+            s[CON + "local_ln.weight"] = (h,)
+            s[CON + "local_ln.bias"] = (h,)
         if cfg.orca_deep_injection_enabled:
             for l in range(cfg.llm_config.num_hidden_layers):
                 q = f"orca_cross_attns.{l}."
@@ -326,8 +327,9 @@ def reference_parameter_names(cfg: DeSTA25Config) -> List[str]:
     names += [CON + n_proj + "0.weight", CON + n_proj + "0.bias", CON + n_proj + "1.weight", CON + n_proj + "1.bias"]
     if orca:
         # ORCAHybridConnector.__init__ order (:266-287), then `orca_cross_attns` (registered after `perception`, :1084)
-        names += [CON + "local_layer_weights", CON + "local_proj_in.weight", CON + "local_proj_in.bias", CON + "local_conv.weight",
-                  CON + "local_conv.bias", CON + "local_ln.weight", CON + "local_ln.bias"]
+        if cfg.orca_local_enabled:
+            names += [CON + "local_layer_weights", CON + "local_proj_in.weight", CON + "local_proj_in.bias", CON + "local_conv.weight",
+                      CON + "local_conv.bias", CON + "local_ln.weight", CON + "local_ln.bias"]
         if cfg.orca_deep_injection_enabled:
             for l in range(cfg.llm_config.num_hidden_layers):
                 q = f"orca_cross_attns.{l}."
@@ -988,8 +990,9 @@ class OrcaHIP:
 
     def refresh_weights(self) -> None:
         """bf16 operand of the Conv1d as an im2col GEMM: [out, in, k] -> [out, k * in] (tap-major rows of the padded token stream)."""
-        w = self.con.arena.param(CON + "local_conv.weight")
-        self.conv_w = w.permute(0, 2, 1).reshape(self.h, self.k * self.h).to(BF16).contiguous()
+        if self.cfg.orca_local_enabled:
+            w = self.con.arena.param(CON + "local_conv.weight")
+            self.conv_w = w.permute(0, 2, 1).reshape(self.h, self.k * self.h).to(BF16).contiguous()
         if self.padded and self.cfg.orca_deep_injection_enabled:
             con, h, hp, nh, hd, hdp, dev = self.con, self.h, self.hp, self.heads, self.hd, self.hdp, self.dev
             if not self.wp:
@@ -1068,6 +1071,9 @@ class OrcaHIP:
         """enc_all [taps, B*T, d] bf16 -> local tokens [B*T', h] bf16."""
         con, h, d = self.con, self.h, self.d
         T = enc_all.shape[1] // B
+        if not self.cfg.orca_local_enabled:                                     # ablation (:336, :352): global tokens only
+            self.B, self.T, self.Tl = B, T, 0
+            return None
         if (B, T) != (self.B, getattr(self, "T", -1)):
             self._alloc(B, T)
         if self.conv_w is None:
@@ -1189,7 +1195,7 @@ class OrcaHIP:
         h, dev = self.h, self.dev
         Kg = self.cfg.orca_global_num_tokens
         self.dglobal32 = torch.zeros(self.B * Kg, h, dtype=F32, device=dev)
-        self.dlocal32 = torch.zeros(self.B * self.Tl, h, dtype=F32, device=dev)
+        self.dlocal32 = torch.zeros(self.B * self.Tl, h, dtype=F32, device=dev) if self.Tl > 0 else None
         self.audioT = None
         if self.audio is not None:
             self.d_audio32 = torch.zeros(self.Bq * self.Ta, h, dtype=F32, device=dev)
@@ -1258,6 +1264,9 @@ class OrcaHIP:
             H.orca_rope_bwd(self.d_audio32, B, self.Ta, h, self.rope_theta, cfg.orca_audio_position_scale, True,
                             Kg if cfg.orca_global_cross_attn else 0, self.dglobal32, self.dlocal32)
         H.orca_sim_loss_bwd(g16, None, Kg, g16, None, Kg, B, Kg, Kg, h, True, cfg.orca_ortho_diversity_weight / (B * Kg * Kg), self.dglobal32)
+        if loc16 is None:                                                        # orca_local_enabled = False: only the global branch is left
+            con.backward((self.dglobal32 + d_af.float()).to(BF16))
+            return
         idx, ny = None, Tl
         if Tl > 100:
             idx = torch.linspace(0, Tl - 1, 100, dtype=torch.long).to(dev, torch.int32)

@@ -289,7 +289,7 @@ int desta_tap_mix_bwd(const float* x, const float* layer_weights, const float* d
  *   desta_orca_rope_bwd           rotation by the negative angle of the fp32 gradient of the rotated tokens, ADDED to d_first (tokens [0, n_first)
  *                                 of every clip: the global tokens under orca_global_cross_attn) resp. d_rest (the local tokens)
  *   desta_orca_col2im_add         gradient of the Conv1d's im2col view: d_padded[b,t,:] = sum of the d_col windows that cover row t (bf16)
- *   desta_orca_local_mix_bwd      d(local_layer_weights) through the softmax (workspace: 2048 floats)
+ *   desta_orca_local_mix_bwd      d(local_layer_weights) through the softmax (workspace: 256 x 32 floats; taps <= 32)
  *   desta_orca_sim_loss_bwd       d_x += gradient of coef * sum_ij (xhat_i . yhat_j - [identity])^2 w.r.t. the un-normalised rows of x (fp32, added;
  *                                 rows of x / d_x and of y picked through optional index lists; ny <= 128) */
 int desta_orca_local_mix(const void* x, const float* layer_weights, int taps, int64_t rows, int d, void* out, void* stream);

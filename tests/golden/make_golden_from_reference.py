@@ -206,7 +206,7 @@ def make_case(name, d, encoder_model_id="openai/whisper-tiny", with_generate=Tru
         print(name, "loss", float(out.loss), "->", path, os.path.getsize(path) // 1024, "KiB")
 
 
-def make_orca_case(gca: bool = False):
+def make_orca_case(gca: bool = False, local: bool = True):
     """ORCA hybrid: the reference's own `ORCAHybridConnector`, `ORCAGatedCrossAttention` (deep injection
     wrappers installed by `_enable_orca_deep_injection`), `_prepare_inputs_for_llm`, the ORCA branch of `forward` and
     `compute_orca_losses` on a tiny local-config model in TRAINING mode (alignment loss on), fp32, dropout 0, with a 3-token
@@ -221,7 +221,7 @@ def make_orca_case(gca: bool = False):
     d = O.tiny_dims(False)
     NTR = 3
     o = R.OrcaDims(global_num_tokens=8, local_downsample=4, local_kernel_size=5, gate_init=0.1, audio_position_scale=2.5,
-                   global_cross_attn=gca, ortho_diversity_weight=0.05, ortho_weight_qformer_local=0.05, align_weight_local=0.05)
+                   global_cross_attn=gca, local_enabled=local, ortho_diversity_weight=0.05, ortho_weight_qformer_local=0.05, align_weight_local=0.05)
     w = R.init_weights(d, o, seed=7)
     d.prompt_size = o.global_num_tokens + NTR                    # placeholders per audio in the token stream: global tokens + transcription
     base = {k: v for k, v in O.init_weights(d, seed=7).items()}
@@ -229,7 +229,7 @@ def make_orca_case(gca: bool = False):
     model, M = build_reference_model(d, {k: v for k, v in base.items() if not k.startswith("perception.connector.global") and not k.startswith("perception.connector.local")
                                           and not k.startswith("orca_cross_attns.")}, allow_missing_connector=True)
     cfg = model.config
-    for k, v in dict(connector_mode="orca_hybrid", orca_enabled=True, orca_use_all_layers=False, orca_local_enabled=True,
+    for k, v in dict(connector_mode="orca_hybrid", orca_enabled=True, orca_use_all_layers=False, orca_local_enabled=local,
                      orca_global_cross_attn=o.global_cross_attn, orca_deep_injection_enabled=True,
                      orca_audio_position_scale=o.audio_position_scale, orca_global_num_tokens=o.global_num_tokens,
                      orca_local_downsample=o.local_downsample, orca_local_kernel_size=o.local_kernel_size, orca_gate_init=o.gate_init,
@@ -289,7 +289,7 @@ def make_orca_case(gca: bool = False):
         gen = model._generate_step(gen_inputs, pad_token_id=0, max_new_tokens=8, do_sample=False)
     print("orca generate:", gen.tolist())
     blob = {"loss": out.loss.detach().reshape(1), "logits": out.logits.detach().contiguous(),
-            "global_tokens": out.audio_global.detach().contiguous(), "local_tokens": out.audio_local.detach().contiguous(),
+            "global_tokens": out.audio_global.detach().contiguous(), **({"local_tokens": out.audio_local.detach().contiguous()} if local else {}),
             "hidden_last": out.hidden_states[-1].detach().contiguous(), "hidden_1": out.hidden_states[1].detach().contiguous(),
             "input_ids": batch["input_ids"], "attention_mask": batch["attention_mask"], "labels": batch["labels"],
             "batch_features": batch["batch_features"], "starts": torch.tensor([[b, int(s)] for b, s in batch["batch_start_positions"]]),
@@ -299,7 +299,8 @@ def make_orca_case(gca: bool = False):
     for k, v in out.orca_losses.items():
         blob["orca_loss::" + k] = v.detach().reshape(1)
     keep_grad = names
-    if gca:
+    if gca or not local:
+        # `orca_local_enabled: false` (with gca: only the global tokens are injected) resp.
         # the `orca_global_cross_attn: true` variant of the shipped ORCA configs (global | local tokens in the injected sequence): a
         # SMALL second file — losses, logits, generation and a representative subset of the gradients
         sub = ("global_queries.0", "global_layer_weights", "global_qformer.layer.1.crossattention.self.query.weight", "global_proj.1.weight",
@@ -307,10 +308,10 @@ def make_orca_case(gca: bool = False):
                "orca_cross_attns.1.gate_proj.0.weight", "orca_cross_attns.1.ln.weight", "orca_cross_attns.0.cross_attn.out_proj.bias")
         keep_grad = [n for n in names if any(n.endswith(x) for x in sub)]
         for k in ("batch_features", "global_tokens", "local_tokens", "hidden_last", "hidden_1", "logits_eval"):
-            blob.pop(k)
+            blob.pop(k, None)
     for n in keep_grad:                        # (weights are not stored: orca_oracle.init_weights(d, o, seed=7) regenerates them)
         blob["grad::" + n] = grads[n].contiguous() if n in grads else torch.zeros_like(w[n])
-    path = os.path.join(HERE, "ref_orca_tiny_gca.safetensors" if gca else "ref_orca_tiny.safetensors")
+    path = os.path.join(HERE, "ref_orca_tiny_nolocal.safetensors" if not local else "ref_orca_tiny_gca.safetensors" if gca else "ref_orca_tiny.safetensors")
     save_file({k: v.contiguous() for k, v in blob.items()}, path)
     print("orca: lm loss", float(out.loss.detach()), {k: float(v.detach()) for k, v in out.orca_losses.items()}, "rope_theta read by the reference:", rope_theta_used,
           "->", path, os.path.getsize(path) // 1024, "KiB")
@@ -435,6 +436,8 @@ def main():
     if "orca" in which:
         make_orca_case(False)
         make_orca_case(True)
+    if "orca" in which or "orca_nolocal" in which:
+        make_orca_case(True, local=False)
     if "asr" in which:
         make_asr_case()
 

@@ -18,13 +18,16 @@ pytestmark = pytest.mark.gpu
 
 
 def _case(golden_dir, gca=False):
+    """gca: False = the base golden, True = `orca_global_cross_attn`, "nolocal" = that plus `orca_local_enabled: false`."""
+    local = gca != "nolocal"
+    gca = bool(gca)
     g = load_file(os.path.join(golden_dir, "ref_orca_tiny.safetensors"))
-    if gca:                                   # the second, small file (orca_global_cross_attn: true) does not repeat the inputs
-        g = {**load_file(os.path.join(golden_dir, "ref_orca_tiny_gca.safetensors")), "batch_features": g["batch_features"]}
+    if gca:                                   # the small files of the variants do not repeat the inputs
+        g = {**load_file(os.path.join(golden_dir, "ref_orca_tiny_gca.safetensors" if local else "ref_orca_tiny_nolocal.safetensors")), "batch_features": g["batch_features"]}
     kg, ds, ks, ntr = (int(x) for x in g["orca_dims"])
     d = O.tiny_dims(False)
     o = R.OrcaDims(global_num_tokens=kg, local_downsample=ds, local_kernel_size=ks, ortho_diversity_weight=0.05,
-                   ortho_weight_qformer_local=0.05, align_weight_local=0.05, global_cross_attn=gca)
+                   ortho_weight_qformer_local=0.05, align_weight_local=0.05, global_cross_attn=gca, local_enabled=local)
     w = R.init_weights(d, o, seed=7)
     d = copy.copy(d)
     d.prompt_size = kg + ntr
@@ -34,7 +37,7 @@ def _case(golden_dir, gca=False):
              "batch_transcription_ids": [g["transcription_ids"][i:i + 1] for i in range(n)]}
     cfg = cfg_from_dims(d, connector_mode="orca_hybrid", orca_enabled=True, orca_global_num_tokens=kg, orca_local_downsample=ds,
                         orca_local_kernel_size=ks, orca_ortho_diversity_weight=0.05, orca_ortho_weight_qformer_local=0.05,
-                        orca_align_weight_local=0.05, orca_rope_theta=float(g["rope_theta_used"]), orca_global_cross_attn=gca)
+                        orca_align_weight_local=0.05, orca_rope_theta=float(g["rope_theta_used"]), orca_global_cross_attn=gca, orca_local_enabled=local)
     return g, d, o, w, batch, cfg
 
 
@@ -191,7 +194,7 @@ def _oracle_with_theta(theta):
     return orig
 
 
-@pytest.mark.parametrize("gca", [False, True])
+@pytest.mark.parametrize("gca", [False, True, "nolocal"])
 def test_orca_generation_and_global_cross_attn_variant(golden_dir, gca):
     """(a) `orca_global_cross_attn: true` (global | local tokens in the injected sequence; the shipped ORCA configs carry the switch):
     forward against the reference-made golden, EVERY gradient against the oracle's autograd (the oracle is pinned to the golden's
@@ -404,3 +407,51 @@ def test_orca_weight_gradient_gemm_forms_agree():
             gw2 = torch.empty_like(gw)
             o._dW(dY, X, M, N, K, gw2, None, xT=o._transposed("audio", X, M, K))
             assert torch.equal(gw, gw2)
+
+
+def test_orca_use_all_layers_vs_oracle():
+    """`orca_use_all_layers: true` (ORCAHybridConnector.__init__ :221-224): EVERY encoder layer is tapped — here 10 of 10 (more than the
+    8-tap register arrays of rounds 1-3; whisper-large has 32) — one global query set and one Q-Former pass per layer, softmax mixes
+    over all of them in both branches.  Loss, the three ORCA losses and every gradient against the oracle."""
+    from desta.models.modeling_desta25 import DeSTA25AudioModel, DeSTA25Config
+    d = copy.copy(O.tiny_dims(False))
+    d.enc_layers, d.taps = 10, tuple(range(10))
+    kg = 4
+    o = R.OrcaDims(global_num_tokens=kg, local_downsample=4, local_kernel_size=5, ortho_diversity_weight=0.05, ortho_weight_qformer_local=0.05,
+                   align_weight_local=0.05, global_cross_attn=True)
+    w = R.init_weights(d, o, seed=13)
+    d.prompt_size = kg + 2
+    batch = O.synthetic_batch(d, B=2, S_ctx=6, S_tgt=10, seed=8, pad=[0, 2])
+    g = torch.Generator().manual_seed(2)
+    batch["batch_transcription_ids"] = [torch.randint(3, d.vocab, (1, 2), generator=g) for _ in range(2)]
+    kw = dict(connector_mode="orca_hybrid", orca_enabled=True, orca_use_all_layers=True, orca_global_num_tokens=kg, orca_local_downsample=4,
+              orca_local_kernel_size=5, orca_ortho_diversity_weight=0.05, orca_ortho_weight_qformer_local=0.05, orca_align_weight_local=0.05,
+              orca_global_cross_attn=True)
+    cfg = cfg_from_dims(d, **kw)
+    # the config derives the tap list itself when none is given (encoder depth from the encoder config)
+    c2 = DeSTA25Config(llm_model_id="x", encoder_model_id="openai/whisper-tiny", llm_config=cfg.to_dict()["llm_config"],
+                       encoder_config=cfg.to_dict()["encoder_config"], **kw)
+    assert c2.target_layer_ids == list(range(10)) and cfg.target_layer_ids == list(range(10))
+    model = DeSTA25AudioModel(cfg, weights=w)
+    names = R.trainable_names(d, o)
+    assert sorted(model.trainable_parameter_names) == sorted(names)
+    model.train()
+    out = model(**batch, keep_logits=True)
+    for n in names:
+        w[n].requires_grad_(True)
+    loss_o, logits_o, losses_o = R.model_forward(w, d, o, batch, training=True)
+    R.total_loss(loss_o, losses_o).backward()
+    m = batch["attention_mask"].bool()
+    assert abs(float(out.loss) - float(loss_o)) < 3e-3 and rel_err(out.logits.float().cpu()[m], logits_o.detach()[m]) < 2e-2
+    for k, v in losses_o.items():
+        assert abs(float(out.orca_losses[k]) - float(v)) < 2e-2 * abs(float(v)) + 2e-6, (k, float(out.orca_losses[k]), float(v))
+    model.backward()
+    go = {n: w[n].grad.detach().double() for n in names}
+    gn = sorted(float(go[n].norm()) for n in names)
+    floor = gn[len(gn) // 2] * 1e-2
+    errs = {n: float((model.arena.grad(n).double().cpu() - go[n].reshape(model.arena.shapes[n])).norm() / max(float(go[n].norm()), floor)) for n in names}
+    a = torch.cat([model.arena.grad(n).reshape(-1).double().cpu() for n in names])
+    b = torch.cat([go[n].reshape(-1) for n in names])
+    worst = max(errs, key=errs.get)
+    print("orca all layers: grads rel", float((a - b).norm() / b.norm()), "cos", float((a @ b) / (a.norm() * b.norm())), worst, errs[worst])
+    assert float((a - b).norm() / b.norm()) < 2e-2 and float((a @ b) / (a.norm() * b.norm())) > 0.9995 and errs[worst] < 6.5e-2

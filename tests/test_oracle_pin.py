@@ -247,16 +247,19 @@ def test_lora_restatement_is_self_consistent():
 
 # ------------------------------------------------------------------------------------------------ ORCA hybrid
 def _orca_case(golden_dir, gca=False):
+    """gca: False = the base golden, True = `orca_global_cross_attn`, "nolocal" = that plus `orca_local_enabled: false`."""
     import copy
     import orca_oracle as R
-    g = load_file(os.path.join(golden_dir, "ref_orca_tiny_gca.safetensors" if gca else "ref_orca_tiny.safetensors"))
-    if gca:                                   # the small second file does not repeat the inputs
+    local = gca != "nolocal"
+    gca = bool(gca)
+    g = load_file(os.path.join(golden_dir, "ref_orca_tiny_nolocal.safetensors" if not local else "ref_orca_tiny_gca.safetensors" if gca else "ref_orca_tiny.safetensors"))
+    if gca:                                   # the small files do not repeat the inputs
         g0 = load_file(os.path.join(golden_dir, "ref_orca_tiny.safetensors"))
         g = {**g, "batch_features": g0["batch_features"]}
     kg, ds, ks, ntr = (int(x) for x in g["orca_dims"])
     d = O.tiny_dims(False)
     o = R.OrcaDims(global_num_tokens=kg, local_downsample=ds, local_kernel_size=ks, ortho_diversity_weight=0.05,
-                   ortho_weight_qformer_local=0.05, align_weight_local=0.05, global_cross_attn=gca)
+                   ortho_weight_qformer_local=0.05, align_weight_local=0.05, global_cross_attn=gca, local_enabled=local)
     w = R.init_weights(d, o, seed=7)
     d = copy.copy(d)
     d.prompt_size = kg + ntr
@@ -315,7 +318,7 @@ def rel_err(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-@pytest.mark.parametrize("gca", [False, True])
+@pytest.mark.parametrize("gca", [False, True, "nolocal"])
 def test_orca_oracle_generation_and_global_cross_attn_variant(golden_dir, gca):
     """(a) the `orca_global_cross_attn: true` variant of the shipped ORCA configs (global | local tokens in the injected sequence):
     LM loss, auxiliary losses, logits and a representative subset of the gradients against a second, small golden made by the
@@ -336,7 +339,7 @@ def test_orca_oracle_generation_and_global_cross_attn_variant(golden_dir, gca):
             for k, v in losses.items():
                 assert abs(float(v.detach()) - float(g["orca_loss::" + k])) < 1e-6 + 1e-4 * abs(float(g["orca_loss::" + k])), k
             sub = [k[len("grad::"):] for k in g if k.startswith("grad::")]
-            assert len(sub) >= 10
+            assert len(sub) >= 8
             for n in sub:
                 assert rel_err(w[n].grad, g["grad::" + n]) < 2e-3, n
             for n in names:
