@@ -455,3 +455,66 @@ def test_orca_use_all_layers_vs_oracle():
     worst = max(errs, key=errs.get)
     print("orca all layers: grads rel", float((a - b).norm() / b.norm()), "cos", float((a @ b) / (a.norm() * b.norm())), worst, errs[worst])
     assert float((a - b).norm() / b.norm()) < 2e-2 and float((a @ b) / (a.norm() * b.norm())) > 0.9995 and errs[worst] < 6.5e-2
+
+
+def test_orca_checkpoint_resume_and_hf_adafactor_interop(golden_dir, tmp_path):
+    """ORCA through the checkpoint wire format: `checkpoint-<step>/model.safetensors` holds exactly the reference's trainable ORCA keys,
+    a resumed run reproduces the uninterrupted one bit for bit, `optimizer.pt` loads into a REAL `transformers.Adafactor` (decay / no-decay
+    groups in named_parameters order — incl. the 3-D Conv1d weight, whose factored state has the shapes HF gives it) and both take the
+    same next step, and a checkpoint written under the reference's old `ocar_cross_attns` prefix (:1300-1309) loads."""
+    from safetensors.torch import load_file, save_file
+    from transformers.optimization import Adafactor
+    from desta.models.modeling_desta25 import DeSTA25AudioModel, reference_parameter_names
+    from desta.trainer.desta_trainer import DeSTA25Trainer, TrainingArguments
+    g, d, o, w, batch, cfg = _case(golden_dir, True)
+    batches = [batch] * 4
+    args = TrainingArguments(learning_rate=1e-3, warmup_steps=2, max_steps=10, logging_steps=1, overlap_comm=False)
+
+    def fresh():
+        m = DeSTA25AudioModel(cfg, weights=w)
+        return m, DeSTA25Trainer(m, args=args)
+    m_a, t_a = fresh()
+    la = t_a.train(batches)
+    m_b, t_b = fresh()
+    lb = t_b.train(batches[:2])
+    ck = str(tmp_path / "checkpoint-2")
+    t_b.save_checkpoint(ck)
+    sd = load_file(os.path.join(ck, "model.safetensors"))
+    names = reference_parameter_names(m_b.config)
+    assert sorted(sd) == sorted(R.trainable_names(d, o)) == sorted(names)
+    m_c, t_c = fresh()
+    t_c.resume_from_checkpoint(ck)
+    lc = t_c.train(batches[2:])
+    assert lb + lc == la and torch.equal(m_c.arena.params, m_a.arena.params)
+    # HF interop
+    params = {n: torch.nn.Parameter(sd[n].clone()) for n in names}
+    dm = dict(zip(names, O.decay_mask(names)))
+    hf = Adafactor([{"params": [params[n] for n in names if dm[n]], "weight_decay": 0.01},
+                    {"params": [params[n] for n in names if not dm[n]], "weight_decay": 0.0}], lr=1e-3, scale_parameter=False, relative_step=False)
+    hf.load_state_dict(torch.load(os.path.join(ck, "optimizer.pt"), weights_only=True))
+    conv = hf.state[params["perception.connector.local_conv.weight"]]
+    h = d.llm_h
+    assert tuple(conv["exp_avg_sq_row"].shape) == (h, h) and tuple(conv["exp_avg_sq_col"].shape) == (h, o.local_kernel_size)
+    m_d, t_d = fresh()
+    t_d.resume_from_checkpoint(ck)
+    gen = torch.Generator().manual_seed(9)
+    for n in names:
+        gr = 0.01 * torch.randn(params[n].shape, generator=gen)
+        params[n].grad = gr.clone()
+        m_d.arena.grad(n).copy_(gr)
+    torch.nn.utils.clip_grad_norm_(list(params.values()), 1.0)
+    lr = O.linear_warmup_lr(2, 1e-3, 2, 10)
+    for gq in hf.param_groups:
+        gq["lr"] = lr
+    hf.step()
+    t_d.optimizer.step(lr)
+    for n in names:
+        torch.testing.assert_close(m_d.arena.param(n).cpu(), params[n].detach(), rtol=1e-5, atol=1e-6)
+    # old checkpoints spell the cross-attention prefix `ocar_cross_attns`
+    old = str(tmp_path / "old")
+    os.makedirs(old)
+    save_file({k.replace("orca_cross_attns.", "ocar_cross_attns."): v for k, v in sd.items()}, os.path.join(old, "model.safetensors"))
+    m_b.config.save_pretrained(old)
+    m_e = DeSTA25AudioModel.from_pretrained(old, weights={k: v for k, v in w.items() if not (k.startswith("perception.connector.") or k.startswith("orca_cross_attns."))})
+    for n in names:
+        assert torch.equal(m_e.arena.param(n).cpu(), sd[n].reshape(m_e.arena.shapes[n])), n
