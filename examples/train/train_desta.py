@@ -78,9 +78,12 @@ def load_config(argv, config_dir=None) -> Cfg:
         if "=" not in tok:
             raise ValueError(f"unrecognised argument '{tok}' (expected key=value or +group=name)")
         k, v = tok.split("=", 1)
-        if k.startswith("+"):                                  # +dataset=NAME -> merge config/dataset/NAME.yaml under 'dataset'
-            with open(os.path.join(config_dir, k[1:], v + ".yaml")) as f:
+        group = os.path.join(config_dir, k[1:], v + ".yaml") if k.startswith("+") and "." not in k else None
+        if group is not None:                                  # +dataset=NAME -> merge config/dataset/NAME.yaml under 'dataset'
+            with open(group) as f:
                 cfg[k[1:]] = yaml.safe_load(f)
+        elif k.startswith("+"):                                # Hydra's append syntax: +model.orca.enabled=true adds a key the YAML does not have
+            _set_dotted(cfg, k[1:], yaml.safe_load(v))
         else:
             _set_dotted(cfg, k, yaml.safe_load(v))
     cfg = _numify(cfg)

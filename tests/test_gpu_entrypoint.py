@@ -160,3 +160,27 @@ def test_init_from_pretrained_weights_lightning_style_file(tmp_path):
     m.load_pretrained_weights(fresh.model, str(tmp_path / "flat.ckpt"))
     for n in picked:
         assert torch.equal(fresh.model.arena.param(n).detach().cpu(), new[n]), n
+
+
+def test_orca_hybrid_through_main(tmp_path):
+    """`model.connector.mode=orca_hybrid` + the `model.orca.*` keys of the reference's ORCA YAMLs through the entry point: the dataset
+    sizes every audio span by `global_num_tokens` placeholders (simple_dataset.py: `orca_global_num_tokens` in ORCA mode), the trainer
+    optimises LM loss + the ORCA losses, the checkpoint holds the ORCA state-dict keys, and resuming continues bit for bit."""
+    m = _mod()
+    orca = ["model.connector.mode=orca_hybrid", "+model.orca.enabled=true", "+model.orca.local_enabled=true", "+model.orca.global_cross_attn=true",
+            "+model.orca.deep_injection_enabled=true", "+model.orca.global_num_tokens=8", "+model.orca.local_downsample=4", "+model.orca.local_kernel_size=5",
+            "+model.orca.gate_init=0.1", "+model.orca.audio_position_scale=2.5", "+model.orca.ortho_weight_global=0.05",
+            "+model.orca.ortho_diversity_weight=0.05", "+model.orca.ortho_weight_qformer_local=0.05", "+model.orca.align_weight_local=0.05"]
+    common = ["--config-name", "desta25_debug", "+dataset=debug", "trainer.max_steps=-1", "trainer.max_epochs=2", "dataset.train_ds.num_samples=8",
+              "optim.sched.warmup_steps=2", "optim.lr=1e-3"] + orca
+    a = m.main(common + [f"exp_dir={tmp_path}/a"])
+    assert a.global_step == 8 and a.model.config.connector_mode == "orca_hybrid" and a.model.orca is not None
+    assert a.model.config.orca_global_num_tokens == 8 and a.model.config.orca_global_cross_attn and a.model.config.audio_tokens == 8
+    sd = load_file(tmp_path / "a" / "checkpoint-8" / "model.safetensors")
+    assert any(k.startswith("orca_cross_attns.1.cross_attn.") for k in sd) and "perception.connector.local_conv.weight" in sd
+    assert "perception.connector.global_queries.3" in sd and not any("layer_prompts" in k for k in sd)
+    b = m.main(common + [f"exp_dir={tmp_path}/b", f"resume_from_checkpoint={tmp_path}/a/checkpoint-4"])
+    pb = load_file(tmp_path / "b" / "checkpoint-8" / "model.safetensors")
+    assert sd.keys() == pb.keys() and all(torch.equal(sd[k], pb[k]) for k in sd)
+    p4 = load_file(tmp_path / "a" / "checkpoint-4" / "model.safetensors")
+    assert any(not torch.equal(p4[k], sd[k]) for k in sd)
