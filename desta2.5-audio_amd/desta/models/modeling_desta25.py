@@ -20,6 +20,7 @@ parameters / gradients / optimizer state fp32.
 from __future__ import annotations
 
 import json
+import logging
 import math
 import os
 from collections import OrderedDict
@@ -171,6 +172,17 @@ class DeSTA25Config:
             self.target_layer_ids = list(range(self.encoder_config.encoder_layers))       # ORCAHybridConnector.__init__ (:221-224)
         self.info = "Ｄｅｓｔａ２。５ Ａｕｄｉｏ"
         self.extra = dict(kwargs)
+
+    def align_orca_layers(self, n_layers: int) -> bool:
+        """A checkpoint whose `global_layer_weights` is [K, n_layers] decides how many encoder layers the ORCA connector taps
+        (modeling_desta25.py:1311-1345: a model trained with `orca_use_all_layers` loads into a default-configured one).  n_layers = encoder
+        depth -> every layer; any other count -> the first n_layers (the reference names that fallback and then rebuilds its connector
+        from the unchanged config, which cannot load; here the fallback is what it says).  -> True when the config changed."""
+        if self.connector_mode != "orca_hybrid" or n_layers == len(self.target_layer_ids):
+            return False
+        self.orca_use_all_layers = n_layers == self.encoder_config.encoder_layers
+        self.target_layer_ids = list(range(n_layers))
+        return True
 
     @property
     def audio_tokens(self) -> int:
@@ -1934,6 +1946,25 @@ class DeSTA25AudioModel:
 
     def load_state_dict(self, state_dict, strict=True, assign=False):
         sd = {k.replace("ocar_cross_attns", "orca_cross_attns"): v for k, v in state_dict.items()}
+        glw = sd.get(CON + "global_layer_weights")
+        if glw is not None and self.orca is not None and int(glw.shape[1]) != len(self.config.target_layer_ids):
+            # layer-count mismatch (:1311-1345): re-tap the encoder and rebuild the trainable half (arena, connector, injection) before
+            # copying — an optimizer made for the old arena must be re-created, exactly as with the reference's new connector module
+            self.config.align_orca_layers(int(glw.shape[1]))
+            logging.warning("checkpoint taps %d encoder layers: rebuilding the ORCA connector (orca_use_all_layers=%s)", glw.shape[1], self.config.orca_use_all_layers)
+            shapes = connector_param_shapes(self.config)
+            shapes.update(lora_param_shapes(self.config))
+            self.arena = ParamArena(list(shapes.items()), self.device)
+            self.trainable_parameter_names = list(shapes.keys())
+            with torch.cuda.device(self.device):
+                self.connector = QformerConnectorHIP(self.config, self.arena, self.device)
+                if self.config.use_lora:
+                    self.llm.attach_lora(self.arena, self.config.lora_r, self.config.lora_alpha, self.config.lora_dropout)
+                self.orca = OrcaHIP(self.config, self.connector, self.device)
+            self._init_connector({})
+            self.drop_prefetched()
+            self.encoder.B = 0                                                 # the tap buffer changes its leading dimension
+            self.enc_all, self._enc_bufs = None, [None, None]
         missing = [n for n in self.trainable_parameter_names if n not in sd]
         unexpected = [k for k in sd if k not in self.arena.shapes]
         if strict and (missing or unexpected):
@@ -1956,10 +1987,15 @@ class DeSTA25AudioModel:
         """Config + base models from local dirs, then trainable-only model.safetensors (strict=False)."""
         from safetensors.torch import load_file
         config = cls.config_class.from_pretrained(pretrained_model_name_or_path)
-        model = cls(config, **{k: v for k, v in kwargs.items() if k in ("weights", "device")})
         if not os.path.isdir(pretrained_model_name_or_path):
             raise FileNotFoundError(f"'{pretrained_model_name_or_path}' is not a local directory (no hub access)")
-        model.load_state_dict(load_file(os.path.join(pretrained_model_name_or_path, "model.safetensors")), strict=False)
+        sd = load_file(os.path.join(pretrained_model_name_or_path, "model.safetensors"))
+        glw = sd.get(CON + "global_layer_weights")
+        if glw is not None and config.align_orca_layers(int(glw.shape[1])):     # before anything is built (the reference rebuilds its connector)
+            logging.warning("checkpoint taps %d encoder layers: orca_use_all_layers=%s, target_layer_ids=%s", glw.shape[1], config.orca_use_all_layers,
+                            config.target_layer_ids if len(config.target_layer_ids) <= 8 else f"0..{config.target_layer_ids[-1]}")
+        model = cls(config, **{k: v for k, v in kwargs.items() if k in ("weights", "device")})
+        model.load_state_dict(sd, strict=False)
         return model
 
     def train(self, mode=True):

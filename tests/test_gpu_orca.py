@@ -518,3 +518,48 @@ def test_orca_checkpoint_resume_and_hf_adafactor_interop(golden_dir, tmp_path):
     m_e = DeSTA25AudioModel.from_pretrained(old, weights={k: v for k, v in w.items() if not (k.startswith("perception.connector.") or k.startswith("orca_cross_attns."))})
     for n in names:
         assert torch.equal(m_e.arena.param(n).cpu(), sd[n].reshape(m_e.arena.shapes[n])), n
+
+
+def test_checkpoint_with_all_layers_reconfigures_a_default_model(tmp_path):
+    """The reference's layer-count alignment (modeling_desta25.py:1311-1345; its `test_layer_alignment.py` loads an all-layers checkpoint
+    into a default-configured model): `global_layer_weights` [K, L] of the checkpoint decides how many encoder layers are tapped.
+    Both doors: `from_pretrained` (config.json says 4 taps, the tensors say 10 = every encoder layer) and `load_state_dict` on a live
+    default model, which rebuilds its trainable half.  The reloaded models reproduce the all-layers model's forward bit for bit."""
+    import json
+    from safetensors.torch import load_file
+    from desta.models.modeling_desta25 import DeSTA25AudioModel
+    d = copy.copy(O.tiny_dims(False))
+    d.enc_layers, d.taps = 10, tuple(range(10))
+    kg = 4
+    o = R.OrcaDims(global_num_tokens=kg, local_downsample=4, local_kernel_size=5, global_cross_attn=True)
+    w = R.init_weights(d, o, seed=21)
+    kw = dict(connector_mode="orca_hybrid", orca_enabled=True, orca_global_num_tokens=kg, orca_local_downsample=4, orca_local_kernel_size=5,
+              orca_global_cross_attn=True)
+    m_all = DeSTA25AudioModel(cfg_from_dims(d, orca_use_all_layers=True, **kw), weights=w)
+    d.prompt_size = kg
+    batch = O.synthetic_batch(d, B=2, S_ctx=6, S_tgt=10, seed=8)
+    m_all.eval()
+    ref = m_all(**batch)
+    m_all.save_pretrained(str(tmp_path / "ck"))
+    # a config.json as a default (4-tap) run would have written it
+    d4 = copy.copy(d)
+    d4.taps = (0, 1, 2, 3)
+    cfg4 = cfg_from_dims(d4, **kw)
+    cfg4.save_pretrained(str(tmp_path / "ck"))
+    assert json.load(open(tmp_path / "ck" / "config.json"))["target_layer_ids"] == [0, 1, 2, 3]
+    base = {k: v for k, v in w.items() if not (k.startswith("perception.connector.") or k.startswith("orca_cross_attns."))}
+    m1 = DeSTA25AudioModel.from_pretrained(str(tmp_path / "ck"), weights=base)
+    assert m1.config.orca_use_all_layers and m1.config.target_layer_ids == list(range(10))
+    m1.eval()
+    out1 = m1(**batch)
+    assert float(out1.loss) == float(ref.loss) and torch.equal(out1.logits, ref.logits)
+    # the live-model door
+    m2 = DeSTA25AudioModel(cfg_from_dims(d4, **kw), weights=base)
+    assert m2.arena.shapes["perception.connector.global_layer_weights"] == (kg, 4)
+    m2.eval()
+    m2(**batch)                                                                  # buffers of the 4-tap shape exist before the reload
+    missing, unexpected = m2.load_state_dict(load_file(str(tmp_path / "ck" / "model.safetensors")), strict=True)
+    assert not missing and not unexpected and m2.arena.shapes["perception.connector.global_layer_weights"] == (kg, 10)
+    assert m2.config.orca_use_all_layers and len(m2.trainable_parameter_names) == len(m_all.trainable_parameter_names)
+    out2 = m2(**batch)
+    assert float(out2.loss) == float(ref.loss) and torch.equal(out2.logits, ref.logits)
