@@ -539,14 +539,17 @@ def main():
         # reference point measured on the same hardware with tools/hf_step_bench.py (the step composed from stock PyTorch-ROCm /
         # transformers modules, as the reference composes it); NOT `vs_baseline` (BASELINE.md publishes no number for this metric)
         torch_ref = None
-        rpath = os.path.join(ROOT, "profiles", "r02_hf_pytorch_step.json")
+        rpath = os.path.join(ROOT, "profiles", "r04_hf_pytorch_step.json")
+        if not os.path.isfile(rpath):
+            rpath = os.path.join(ROOT, "profiles", "r02_hf_pytorch_step.json")
         if a.config == "desta25_llama31-8B_Qformer6L" and world == 1 and os.path.isfile(rpath):
             with open(rpath) as f:
                 torch_ref = json.load(f)
             torch_ref["speedup_of_this_run"] = torch_ref["ms_per_step"] / ms_step
             torch_ref["measured_in_this_run"] = False
-            torch_ref["note"] = ("stored constant: tools/hf_step_bench.py measured once in round 2 on another box "
-                                 "(profiles/r02_hf_pytorch_step.log); only the ratio uses this run's ms_per_step")
+            torch_ref["note"] = (f"stored constant: tools/hf_step_bench.py measured once ({torch_ref.get('log')}; round 4: in the same lease as "
+                                 "profiles/r04_bench_driver_cmd.log, a box of gate_up calibration 1230 TFLOP/s where this bench ran 165.2 ms); only the "
+                                 "ratio uses this run's ms_per_step")
         mean_ps = sum(per_step) / max(1, len(per_step))
         sd_ps = (sum((x - mean_ps) ** 2 for x in per_step) / max(1, len(per_step) - 1)) ** 0.5
         # executed FLOP per step: every GEMM launch of a step (HIP-event records carry 2MNK) + the attention kernels'
