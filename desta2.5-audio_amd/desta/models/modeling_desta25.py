@@ -1419,6 +1419,9 @@ class CausalLMHIP:
             ly["a16"] = torch.zeros(self.LORA_KP, h, dtype=BF16, device=dev)
             ly["b16"] = torch.zeros(self.qkvw, self.LORA_KP, dtype=BF16, device=dev)
             ly["a16p"] = [torch.zeros(self.LORA_KP, h, dtype=BF16, device=dev) for _ in LORA_TARGETS]   # a16 with the rows of ONE projection (dropout backward)
+            # the pair-interleaved q|k|v copies only serve the fused rotary epilogue, which the adapter sum rules out (`forward`): free them
+            ly.pop("wqkv_il", None)
+            ly.pop("wqkvT_il", None)
         self.B = self.S = 0                                                    # re-allocate the activations with the adapter buffers
 
     def _lora_names(self, i: int, ab: str) -> List[str]:

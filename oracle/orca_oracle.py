@@ -203,13 +203,17 @@ def orca_losses(o: OrcaDims, g: Optional[Tensor], loc: Optional[Tensor], layer_a
     out: Dict[str, Tensor] = {}
     if g is not None:
         gn = F.normalize(g, dim=-1)
-        gram = torch.einsum("bkh,bqh->bkq", gn, gn)
+        if O._AC:                                        # (autocast policy: bmm / einsum operands are cast to bf16)
+            gn = gn.to(torch.bfloat16)
+        gram = torch.einsum("bkh,bqh->bkq", gn, gn).float()
         out["L_ortho_diversity"] = o.ortho_diversity_weight * ((gram - torch.eye(gram.shape[-1])) ** 2).mean()
     if g is not None and loc is not None:
         gn, ln_ = F.normalize(g, dim=-1), F.normalize(loc, dim=-1)
         if ln_.shape[1] > 100:
             ln_ = ln_[:, torch.linspace(0, ln_.shape[1] - 1, 100, dtype=torch.long), :]
-        out["L_ortho_qformer_local"] = o.ortho_weight_qformer_local * (torch.einsum("bgh,blh->bgl", gn, ln_) ** 2).mean()
+        if O._AC:
+            gn, ln_ = gn.to(torch.bfloat16), ln_.to(torch.bfloat16)
+        out["L_ortho_qformer_local"] = o.ortho_weight_qformer_local * (torch.einsum("bgh,blh->bgl", gn, ln_).float() ** 2).mean()
     if layer_align:
         out["L_align_layerwise"] = o.align_weight_local * torch.stack(layer_align).mean()
     return out
