@@ -291,7 +291,6 @@ def main():
     ap.add_argument("--main-priority", type=int, default=None, help="A/B: run the whole step on a non-default HIP stream of this priority (-1 = high) instead of torch's default stream")
     ap.add_argument("--side-priority", type=int, default=0, help="HIP priority of the encoder-prefetch / optimizer-tail streams (0 = same as the main stream: rounds 1-3; 1 = lower)")
     ap.add_argument("--no-gemm-tail-skip", action="store_true", help="A/B: the 256x256 GEMM re-loads dead LDS slots past its last K-tile (rounds 1-3) instead of stopping the half-tile stream there")
-    ap.add_argument("--gelu-poly", action="store_true", help="A/B: bf16-output GELU epilogues on the packed degree-12 polynomial instead of the A&S 7.1.26 form (measured equal)")
     ap.add_argument("--no-swiglu-fusion", action="store_true", help="A/B: silu(gate) * up and its backward as their own HBM passes instead of inside the gate|up / d(act) GEMM epilogues")
     ap.add_argument("--full-lm-head", action="store_true", help="A/B: lm_head / CE over the whole token grid, not only the target rows")
     a = ap.parse_args()
@@ -350,8 +349,6 @@ def main():
         H.gemm_set_option(6, a.small_gemm_ring)
     if a.splitk_inkernel:
         H.gemm_set_option(5, 1)
-    if a.gelu_poly:
-        H.gemm_set_option(9, 1)
     if a.no_gemm_tail_skip:
         H.gemm_set_option(10, 0)
     cfg = DeSTA25Config(**FULL_CONFIGS[a.config], use_lora=a.lora)

@@ -92,29 +92,6 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
     const float e = 1.0f - poly * t * __expf(-z * z);          // erf(|x|/sqrt2)
     return 0.5f * x * (1.0f + copysignf(e, x));
 }
-// GELU(erf) for bf16-rounded outputs, TWO values per instruction (round 4; OPT-IN, desta_gemm_set_option(9, 1)).  Hypothesis: with
-// one 256x256 tile per CU the bias + GELU epilogue of the Whisper fc1 GEMM is VALU-bound (128 outputs per lane at ~20 issue slots
-// each: v_rcp and v_exp are quarter rate and do not pack).  Measured: NO step-time difference against the A&S form in a same-box
-// alternating A/B (bench.py --gelu-rcp-exp, profiles/r04_ab_step.log) — the epilogue is not issue-bound — so the A&S form, which is
-// four times more accurate, stays the default.  The form: gelu(x) = x * (0.5 + xc * R(xc^2)), xc = clamp(x, +-5), R = the
-// degree-12 Chebyshev interpolant of (Phi(x) - 0.5) / x over x^2 in [0, 25], evaluated by Horner in u = 2 x^2 / 25 - 1 on
-// register PAIRS (v_pk_mul_f32 / v_pk_fma_f32: 17 packed instructions per two values, no transcendental) — ~9 issue slots per
-// value.  Host check (numpy, fp32 Horner, 2 M points in [-9, 9]): |error| < 1.9e-6 absolute (A&S 7.1.26 above: 4.7e-7), relative
-// error below 8e-6 for |x| < 2; beyond the clamp gelu(x) = x * (1 - 2.9e-7) resp. x * 2.9e-7.  After the bf16 store 0.65 % of
-// N(0, 1.5) inputs differ from the exactly rounded value by one ulp (A&S: 0.22 %).
-typedef float desta_f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ desta_f32x2 gelu_erf_poly2(desta_f32x2 x) {
-    const desta_f32x2 xc = {__builtin_amdgcn_fmed3f(x[0], -5.0f, 5.0f), __builtin_amdgcn_fmed3f(x[1], -5.0f, 5.0f)};
-    const desta_f32x2 u = __builtin_elementwise_fma(xc * xc, desta_f32x2{0.08f, 0.08f}, desta_f32x2{-1.0f, -1.0f});
-    desta_f32x2 r = {7.059529907e-04f, 7.059529907e-04f};
-#define DESTA_H2(c) r = __builtin_elementwise_fma(r, u, desta_f32x2{c, c})
-    DESTA_H2(-1.674030979e-03f); DESTA_H2(1.462631570e-03f); DESTA_H2(-2.534322338e-03f); DESTA_H2(6.667808951e-03f);
-    DESTA_H2(-1.129974343e-02f); DESTA_H2(1.628707023e-02f); DESTA_H2(-2.321634419e-02f); DESTA_H2(3.146487198e-02f);
-    DESTA_H2(-4.045071131e-02f); DESTA_H2(5.151894161e-02f); DESTA_H2(-7.029593721e-02f); DESTA_H2(1.413638045e-01f);
-#undef DESTA_H2
-    const desta_f32x2 t = xc * r;
-    return __builtin_elementwise_fma(x, t, x * desta_f32x2{0.5f, 0.5f});
-}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
     const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
     const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);

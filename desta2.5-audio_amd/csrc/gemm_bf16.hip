@@ -46,9 +46,7 @@ struct GemmArgs {
     int* tickets;                                       // per split tile: arrivals of its K-slices (in-kernel reduction) or null
     const float* rms_w; float rms_eps;                  // skinny kernel: RMSNorm(A rows; weight rms_w) applied on the fly
     const float* rope_cs; const int* rope_pos; int rope_cols, rope_hd;   // rotary embedding of output columns [0, rope_cols) in adjacent pairs
-    int desync;                                         // 256-kernel: first-round blocks start up to desync x 0.5 us apart (see gemm_bf16_nt_256_kernel)
     int tail_skip;                                      // 256-kernel, 2-phase schedule: past the last K-tile the half-tile stream STOPS (counted waits shrink) instead of re-loading dead slots (option 10)
-    int gelu_poly;                                      // bf16-output GELU epilogues: 0 = A&S 7.1.26 with v_rcp / v_exp (default), 1 = packed polynomial form (option 9)
 };
 
 // rotary embedding of 4 consecutive outputs (two adjacent pairs) of row m, columns n0 .. n0 + 3 (see desta_gemm_desc.rope_*)
@@ -63,14 +61,9 @@ __device__ __forceinline__ void rope4(const GemmArgs& p, int m, int n0, float (&
 }
 
 // bias + GELU of 4 adjacent outputs destined for a bf16 store: packed polynomial form (common.h), or the A&S form (option 9 = 0)
-__device__ __forceinline__ void gelu4_bf16(float (&v)[4], int poly) {
-    if (poly) {
-        const desta_f32x2 a = gelu_erf_poly2(desta_f32x2{v[0], v[1]}), b = gelu_erf_poly2(desta_f32x2{v[2], v[3]});
-        v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
-    } else {
+__device__ __forceinline__ void gelu4_bf16(float (&v)[4]) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_erf_fast(v[e]);
-    }
+    for (int e = 0; e < 4; ++e) v[e] = gelu_erf_fast(v[e]);
 }
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
@@ -104,7 +97,7 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& p, int z, int m, int n
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
         } else {                                           // bf16 store: the approximation error sits far below the rounding step
-            gelu4_bf16(v, p.gelu_poly);
+            gelu4_bf16(v);
         }
     }
     if (p.drop_thresh) {
@@ -132,13 +125,32 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& p, int z, int m, int n
     }
 }
 
+// out[m, n0 .. n0+4) (fp32) = alpha * acc + bias + residual (fp32): the Whisper encoder's out-proj / fc2 (fp32 residual stream), with
+// no run-time feature tests (the caller decides once per tile)
+__device__ __forceinline__ void epilogue4_f32_stream(const GemmArgs& p, int z, int m, int n0, const f32x4& a) {
+    const float4 b = *(const float4*)(p.bias + n0);
+    const float4 r = *(const float4*)((const float*)p.res + (long)z * p.sR + (long)m * p.ldr + n0);
+    *(float4*)((float*)p.C + (long)z * p.sC + (long)m * p.ldc + n0) =
+        make_float4((a[0] * p.alpha + b.x) + r.x, (a[1] * p.alpha + b.y) + r.y, (a[2] * p.alpha + b.z) + r.z, (a[3] * p.alpha + b.w) + r.w);
+}
+
 // Fast bf16 epilogue for two horizontally adjacent 16x16 tiles (bias / GELU / bf16 or fp32 residual):
 // v_permlane16_swap exchanges the odd 16-lane rows of tile j with the even rows of tile j+1, after which
 // every lane owns 8 CONTIGUOUS outputs of one row -> one 16-B store instead of two 8-B stores
 // (half the store instructions of the epilogue, which is issue-bound with one block per CU).
+// MODE: what the tile needs, decided ONCE per tile by the caller (bits: 1 bias, 2 GELU, 4 rotary, 8 residual); MODE < 0 keeps every
+// test at run time.  [Until round 4 every one of the 16 calls per wave tested bias / act / rope / residual itself: the 256x256
+// kernel's epilogue is ~30 000 instructions of mostly skipped code, and each feature added to it (rotary in round 3, a second GELU
+// form in round 4) made the PLAIN path slower — 4.7 -> 8 -> 14.5 us per tile, i.e. 104 -> 130 us on the Whisper q|k|v shape.]
+template <int MODE = -1>
 __device__ __forceinline__ void epilogue_pair_bf16(const GemmArgs& p, int z, int m, bool row_ok, int ncol0, int fq,
                                                    const f32x4& a0, const f32x4& a1) {
-    if (p.res && !p.res_f32 && (p.ldr & 7) == 0 && (p.sR & 7) == 0) {
+    constexpr bool DYN = MODE < 0;
+    const bool has_bias = DYN ? p.bias != nullptr : (MODE & 1) != 0;
+    const bool has_gelu = DYN ? p.act == 1 : (MODE & 2) != 0;
+    const bool has_rope = DYN ? true : (MODE & 4) != 0;                    // (rope4 tests the pointer itself)
+    const bool has_res = DYN ? p.res != nullptr : (MODE & 8) != 0;
+    if (has_res && !p.res_f32 && (p.ldr & 7) == 0 && (p.sR & 7) == 0) {
         // bf16 residual: swap the fp32 values first, so the lane's 8 contiguous outputs take ONE 16-byte residual load
         // (instead of two 8-byte loads before the swap); same arithmetic: add in fp32, round once.
         float v[2][4];
@@ -148,11 +160,11 @@ __device__ __forceinline__ void epilogue_pair_bf16(const GemmArgs& p, int z, int
             const int n0 = ncol0 + t * 16 + fq * 4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[t][e] = a[e] * p.alpha;
-            if (p.bias) {
+            if (has_bias) {
                 const float4 b = *(const float4*)(p.bias + n0);
                 v[t][0] += b.x; v[t][1] += b.y; v[t][2] += b.z; v[t][3] += b.w;
             }
-            if (p.act == 1) gelu4_bf16(v[t], p.gelu_poly);
+            if (has_gelu) gelu4_bf16(v[t]);
         }
         const int col = ncol0 + (fq & 1) * 16 + (fq >> 1) * 8;
         const u16x8 r = *(const u16x8*)((const bf16_t*)p.res + (long)z * p.sR + (long)m * p.ldr + col);
@@ -178,13 +190,13 @@ __device__ __forceinline__ void epilogue_pair_bf16(const GemmArgs& p, int z, int
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = a[e] * p.alpha;
-        if (p.bias) {
+        if (has_bias) {
             const float4 b = *(const float4*)(p.bias + n0);
             v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
         }
-        rope4(p, min(m, p.M - 1), n0, v);
-        if (p.act == 1) gelu4_bf16(v, p.gelu_poly);
-        if (p.res) {
+        if (has_rope) rope4(p, min(m, p.M - 1), n0, v);
+        if (has_gelu) gelu4_bf16(v);
+        if (has_res) {
             if (p.res_f32) {
                 const float4 r = *(const float4*)((const float*)p.res + (long)z * p.sR + (long)m * p.ldr + n0);
                 v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
@@ -680,17 +692,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
 
-    // De-synchronised start (multi-round grids only, host decides).  All tiles of a launch take the same time, so with one
-    // block per CU the 256 CUs reach their epilogues TOGETHER, round after round: 256 x 128 KB of stores (+ as much residual
-    // read) hit HBM as one burst — the 8-11 us (plain store) / 19-21 us (residual) per-tile overhead of the K-sweep cost model
-    // is that burst at ~3-4 TB/s — while nothing is written during the main loops.  Spreading the START of the first round's
-    // blocks over about one epilogue length keeps the CUs out of phase for the whole launch (a CU takes its next tile when it
-    // is done), so every epilogue runs beside 255 main loops.  Costs the average delay once per launch.
-    if (p.desync > 0 && (int)blockIdx.x < 256 && blockIdx.y == 0) {
-        const int n = (int)((((unsigned)blockIdx.x * 97u) & 255u) * (unsigned)p.desync) >> 8;
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);              // 16 x 64 cycles ~ 0.5 us
-    }
-
     // work item -> (tile, K-slice): the first `full_tiles` items are whole tiles; the remainder of the
     // tile grid (the tail round that would leave CUs idle) is cut into `split` K-slices per tile
     int L, slice = 0;
@@ -751,6 +752,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
     // counted wait in front of a barrier: all but the 4 youngest half-tiles of the UNCAPPED stream must have landed; `issued` = stream
     // position after this slot's stage() calls.  Steady state: 4 half-tiles x 2 ops = vmcnt(8); in the tail the stream is shorter by
     // the overshoot, so fewer ops may stay outstanding (wave-uniform branch on a scalar)
+    auto stage_steady = [&](int j) __attribute__((always_inline)) {       // j < 4 nk: no end-of-stream test, no clamp
+        const int t = j >> 2, q = j & 3;
+        const int kind = (q == 0) ? 0 : (q == 1) ? 2 : (q == 2) ? 3 : 1;
+        const long koff = (long)(kt0 + t) * BK;
+        char* dst = lds + ((t & 1) * 4 + kind) * HT;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            glds16(src[kind][i] + koff, dst + (i * 512 + wave * 64) * 16);
+    };
+    auto wait_steady = [&](int) __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); };
     auto tail_wait = [&](int issued) __attribute__((always_inline)) {
         const int ov = tskip ? issued - n_ht : 0;
         if (ov <= 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -804,45 +815,58 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
                     __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j][kk], a[i][kk], acc[ACC_I0 + i][ACC_J0 + j], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                                           \
     __builtin_amdgcn_sched_barrier(0);
+    // One K-tile of the two-phase schedule.  STAGE / WAIT are the half-tile issue and the counted wait in front of a barrier: the
+    // STEADY forms (no end-of-stream test, constant vmcnt(8)) for every K-tile whose slots stay inside the stream, the checked forms
+    // for the last two.  [Round 4 first shipped the checked forms for EVERY K-tile: the scalar compare / branch chains in front of the
+    // barriers cost the LLM shapes 4-5 % (gate_up 903 -> 955 us) — invisible to the same-binary A/B of the run-time switch.]
+#define KTILE_2PHASE(STAGE, WAIT)                                                                              \
+    {                                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
+            _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                 \
+                b0[i][kk] = *(const bf16x8*)(B0 + (offB[i] ^ (kk << 6)));                                      \
+                b1[i][kk] = *(const bf16x8*)(B1 + (offB[i] ^ (kk << 6)));                                      \
+            }                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
+            _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) a[i][kk] = *(const bf16x8*)(A0 + (offA[i] ^ (kk << 6))); \
+        STAGE(g + 7);                                                                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+        if (STAGGER) { WAIT(g + 8); __builtin_amdgcn_s_barrier(); }                                            \
+        MFMA_SLOT(0, 0, b0)                                                                                    \
+        MFMA_SLOT(0, 2, b1)                                                                                    \
+        WAIT(g + 8); __builtin_amdgcn_s_barrier();                                                             \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
+            _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) a[i][kk] = *(const bf16x8*)(A1 + (offA[i] ^ (kk << 6))); \
+        STAGE(g + 8);                                                                                          \
+        STAGE(g + 9);                                                                                          \
+        STAGE(g + 10);                                                                                         \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+        if (STAGGER) { WAIT(g + 11); __builtin_amdgcn_s_barrier(); }                                           \
+        MFMA_SLOT(4, 2, b1)                                                                                    \
+        MFMA_SLOT(4, 0, b0)                                                                                    \
+        WAIT(g + 11); __builtin_amdgcn_s_barrier();                                                            \
+    }
     if (STAGGER && wave >= 4) __builtin_amdgcn_s_barrier();
-    for (int t = 0; t < nk; ++t) {
+    // two-phase schedule: K-tiles [0, nk - 2) in the steady form (every slot they stage, <= 4 t + 10, lies inside the stream), the last
+    // two in the checked form — two loops, one body each
+    const int nk_steady = PHASES == 2 ? max(nk - 2, 0) : 0;
+    if constexpr (PHASES == 2) {
+        for (int t = 0; t < nk_steady; ++t) {
+            const char* base = lds + (t & 1) * 4 * HT;
+            const char* A0 = base, *A1 = base + HT, *B0 = base + 2 * HT, *B1 = base + 3 * HT;
+            const int g = 4 * t;
+            KTILE_2PHASE(stage_steady, wait_steady)
+        }
+        for (int t = nk_steady; t < nk; ++t) {
+            const char* base = lds + (t & 1) * 4 * HT;
+            const char* A0 = base, *A1 = base + HT, *B0 = base + 2 * HT, *B1 = base + 3 * HT;
+            const int g = 4 * t;
+            KTILE_2PHASE(stage, tail_wait)
+        }
+    }
+    for (int t = (PHASES == 2 ? nk : 0); t < nk; ++t) {
         const char* base = lds + (t & 1) * 4 * HT;
         const char* A0 = base, *A1 = base + HT, *B0 = base + 2 * HT, *B1 = base + 3 * HT;
         const int g = 4 * t;
-        if constexpr (PHASES == 2) {
-            // ---------------- P1: A0, B0, B1 -> Q00, Q01
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    b0[i][kk] = *(const bf16x8*)(B0 + (offB[i] ^ (kk << 6)));
-                    b1[i][kk] = *(const bf16x8*)(B1 + (offB[i] ^ (kk << 6)));
-                }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) a[i][kk] = *(const bf16x8*)(A0 + (offA[i] ^ (kk << 6)));
-            stage(g + 7);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (STAGGER) { tail_wait(g + 8); __builtin_amdgcn_s_barrier(); }
-            MFMA_SLOT(0, 0, b0)
-            MFMA_SLOT(0, 2, b1)
-            tail_wait(g + 8); __builtin_amdgcn_s_barrier();
-            // ---------------- P2: A1 (B in registers) -> Q11, Q10
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) a[i][kk] = *(const bf16x8*)(A1 + (offA[i] ^ (kk << 6)));
-            stage(g + 8);
-            stage(g + 9);
-            stage(g + 10);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (STAGGER) { tail_wait(g + 11); __builtin_amdgcn_s_barrier(); }
-            MFMA_SLOT(4, 2, b1)
-            MFMA_SLOT(4, 0, b0)
-            tail_wait(g + 11); __builtin_amdgcn_s_barrier();
-            continue;
-        }
         // ---------------- P1: A0, B0 -> Q00
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -884,6 +908,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
         SLOT_END()
     }
     if (STAGGER && wave < 4) __builtin_amdgcn_s_barrier();
+#undef KTILE_2PHASE
 #undef MFMA_SLOT
 #undef SLOT_END
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the dummy tail loads before LDS is released
@@ -965,15 +990,37 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
     // the permlane swap needs all 64 lanes, so row guards only predicate the store)
     const bool wide = !p.out_f32 && !p.preact && p.act <= 1 && !p.drop_thresh && (p.N % 32 == 0) && (p.ldc % 8 == 0);
     if (wide) {
+        // the tile's feature set, once (block-uniform): the combinations the training step uses get straight-line code
+#define DESTA_WIDE_TILE(MODE)                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                \
+            const int m = brow + wm * 128 + i * 16 + fr;                                                               \
+            const int mc = min(m, p.M - 1);                                                                            \
+            _Pragma("unroll") for (int j = 0; j < 4; j += 2) {                                                         \
+                const int ncol0 = bcol + wn * 64 + j * 16;                                                             \
+                if (ncol0 >= p.N) continue;                                   /* wave-uniform */                       \
+                epilogue_pair_bf16<MODE>(p, z, mc, m < p.M, ncol0, fq, acc[i][j], acc[i][j + 1]);   /* all lanes swap; rows >= M only skip the store */ \
+            }                                                                                                          \
+        }
+        const int mode = (p.bias ? 1 : 0) | (p.act == 1 ? 2 : 0) | (p.rope_cs ? 4 : 0) | (p.res ? 8 : 0);
+        if (mode == 0) { DESTA_WIDE_TILE(0) }                                 // dX GEMMs, lm_head, q|k|v without the fused rotary
+        else if (mode == 8) { DESTA_WIDE_TILE(8) }                            // o_proj / down_proj (+ residual)
+        else if (mode == 4) { DESTA_WIDE_TILE(4) }                            // q|k|v with the rotary epilogue
+        else if (mode == 1) { DESTA_WIDE_TILE(1) }                            // Whisper q|k|v, Q-Former K|V (bias)
+        else if (mode == 3) { DESTA_WIDE_TILE(3) }                            // Whisper fc1 (bias + GELU)
+        else { DESTA_WIDE_TILE(-1) }
+#undef DESTA_WIDE_TILE
+        return;
+    }
+    if (p.out_f32 && p.bias && p.res && p.res_f32 && !p.preact && p.act == 0 && !p.drop_thresh) {      // Whisper out-proj / fc2: fp32 residual stream
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int m = brow + wm * 128 + i * 16 + fr;
-            const int mc = min(m, p.M - 1);
+            if (m >= p.M) continue;
 #pragma unroll
-            for (int j = 0; j < 4; j += 2) {
-                const int ncol0 = bcol + wn * 64 + j * 16;
-                if (ncol0 >= p.N) continue;                                   // wave-uniform
-                epilogue_pair_bf16(p, z, mc, m < p.M, ncol0, fq, acc[i][j], acc[i][j + 1]);   // all lanes swap; rows >= M only skip the store
+            for (int j = 0; j < 4; ++j) {
+                const int n0 = bcol + wn * 64 + j * 16 + fq * 4;
+                if (n0 >= p.N) continue;
+                epilogue4_f32_stream(p, z, m, n0, acc[i][j]);
             }
         }
         return;
@@ -1227,6 +1274,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256p_kernel(GemmArgs p, i
     }
     if (STAGGER && wave < 4) __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the tail of the stream before LDS is released
+#undef KTILE_2PHASE
 #undef MFMA_SLOT
 #undef SLOT_END
 #undef STAGE_NEXT
@@ -1439,11 +1487,8 @@ static int g_small_ring = 1;      // option 6: 0 never, 1 the four-slot ring for
 static int g_phases2 = 1;         // automatic choice uses the 2-phase (32 MFMAs per phase) staggered schedule (+5-16 % on every shape)
 extern "C" int desta_gemm_set_persistent(int on) { g_persistent = on; return DESTA_OK; }
 static int g_skinny = 0;          // 0 auto, else COLS*10 + U of the skinny (M <= 16) kernel (tuning)
-static int g_desync = 0;          // option 7: spread of the first round's block starts in 0.5-us units, grids of >= g_desync_min_items
-static int g_desync_min = 640;    // option 8: items from which the spread is applied (2.5 rounds)
 static int g_skinny_blocks = 512;  // persistent grid of the skinny kernel (2 blocks per CU)
 static int g_tail_skip = 1;        // option 10: the 2-phase 256x256 kernel stops its half-tile stream at the last K-tile (1, default) or re-loads dead slots (0: rounds 1-3)
-static int g_gelu_poly = 0;        // option 9: bf16-output GELU epilogues on A&S 7.1.26 (0, default) or on the packed polynomial (1): same step time in the same-box A/B (163.0 / 163.3 vs 163.1 / 163.2 ms), so the more accurate form stays
 extern "C" int desta_gemm_set_option(int option, int value) {
     if (option == 0) g_persistent = value;
     else if (option == 1) g_stagger = value;
@@ -1457,9 +1502,8 @@ extern "C" int desta_gemm_set_option(int option, int value) {
     else if (option == 4) g_phases2 = value;
     else if (option == 5) g_inkernel_splitk = value;
     else if (option == 6) g_small_ring = value;
-    else if (option == 7) g_desync = value;
-    else if (option == 8) g_desync_min = value;
-    else if (option == 9) g_gelu_poly = value;
+    else if (option == 7 || option == 8) { /* (round 3's de-synchronised start: measured no gain, removed) */ }
+    else if (option == 9) { /* (round 4's packed-polynomial GELU: measured equal in the step, and its code in every epilogue fragment cost the PLAIN path 17 % at K = 1280: removed) */ }
     else if (option == 10) g_tail_skip = value;
     else if (option == 3) {
         if (value < 1 || value > 65535) { desta_set_error("gemm_set_option: skinny grid %d out of range", value); return DESTA_EINVAL; }
@@ -1490,7 +1534,7 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
     a.sA = d->stride_a; a.sB = d->stride_b; a.sC = d->stride_c;
     a.bias = d->bias;
     a.res = d->residual; a.ldr = d->ldr; a.sR = d->stride_r; a.res_f32 = d->residual_f32;
-    a.act = d->act; a.out_f32 = d->out_f32; a.gelu_poly = g_gelu_poly; a.tail_skip = g_tail_skip;
+    a.act = d->act; a.out_f32 = d->out_f32; a.tail_skip = g_tail_skip;
     a.preact = (bf16_t*)d->preact; a.ldp = d->ldp; a.sP = d->stride_p;
     a.alpha = d->alpha;
     a.aux = (bf16_t*)d->aux; a.lda_x = d->ld_aux;
@@ -1572,7 +1616,6 @@ extern "C" int desta_gemm_bf16_nt(const desta_gemm_desc* d, void* stream) {
         a.tilesM = tM; a.tilesN = tN;
         a.full_tiles = full; a.split = split; a.ws = (float*)d->workspace;
         const int items = full + (int)(T - full) * split;
-        a.desync = (g_desync > 0 && items >= g_desync_min && d->batch == 1) ? g_desync : 0;
         // tickets: the last 4 KiB of the workspace (<= 128 split tiles); zero at first use (the caller hands over a zeroed
         // workspace once) and self-resetting afterwards.  Only the plain (non-persistent) kernels carry the in-kernel reduce.
         const bool persistent_ = g_force_variant == 4 || g_force_variant == 8 || (g_force_variant == 0 && g_persistent && items > NCU);

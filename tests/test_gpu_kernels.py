@@ -304,11 +304,11 @@ def test_gemm_epilogues_and_batch(hip):
 
 
 @pytest.mark.parametrize("variant", [1, 2])
-def test_gemm_gelu_epilogue_polynomial_form(hip, variant):
-    """bf16-output GELU(erf) epilogue (Whisper fc1 / conv stem, Q-Former FFN; TF:activations.py GELUActivation = erf form):
-    the A&S 7.1.26 form (default) and the packed degree-12 polynomial form (csrc/common.h gelu_erf_poly2, option 9 = 1: measured
-    equal in step time, kept as an option) both land within ONE bf16 ulp of gelu(pre-activation) evaluated in float64 and then rounded, and on the exactly
-    rounded value for > 97 % of the elements; pre-activations cover |x| up to ~9 (beyond the polynomial's clamp at 5)."""
+def test_gemm_gelu_epilogue_within_one_ulp(hip, variant):
+    """bf16-output GELU(erf) epilogue (Whisper fc1 / conv stem, Q-Former FFN; TF:activations.py GELUActivation = erf form), the A&S 7.1.26
+    form: within ONE bf16 ulp of gelu(pre-activation) evaluated in float64 and then rounded, and on the exactly rounded value for
+    > 97 % of the elements; pre-activations cover |x| up to ~9.  (Round 4's second, packed-polynomial form measured equal in the step
+    and was removed: its code in every epilogue fragment slowed the plain-store path of the same kernel.)"""
     g = torch.Generator().manual_seed(77)
     M, N, K = 512, 768, 256
     A = _bf(torch.randn(M, K, generator=g) * 0.5).cuda()
@@ -319,20 +319,14 @@ def test_gemm_gelu_epilogue_polynomial_form(hip, variant):
     assert float(pre.abs().max()) > 6.0
     try:
         hip.gemm_force_variant(variant)
-        outs = {}
-        for poly in (1, 0):
-            hip.gemm_set_option(9, poly)
-            out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
-            hip.gemm(A, B, out, M, N, K, bias=bias, act=1)
-            outs[poly] = out
-            ulp = (out.view(torch.int16).int() - ref.view(torch.int16).int()).abs()
-            big = ref.float().abs() >= 2.0 ** -8                                # (the negative tail, |gelu| < 2^-8: compared absolutely; one bf16 ulp there is <= 1.5e-5)
-            assert int(ulp[big].max()) <= 1, (poly, int(ulp[big].max()))
-            assert float((out.float() - ref.float()).abs()[~big].max()) < (4e-5 if poly else 2e-5)
-            assert float((ulp[big] != 0).float().mean()) < (0.06 if poly else 0.03), (poly, float((ulp[big] != 0).float().mean()))
-        assert float((outs[0] != outs[1]).float().mean()) < 0.07
+        out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        hip.gemm(A, B, out, M, N, K, bias=bias, act=1)
+        ulp = (out.view(torch.int16).int() - ref.view(torch.int16).int()).abs()
+        big = ref.float().abs() >= 2.0 ** -8                                # (the negative tail, |gelu| < 2^-8: compared absolutely; one bf16 ulp there is <= 1.5e-5)
+        assert int(ulp[big].max()) <= 1, int(ulp[big].max())
+        assert float((out.float() - ref.float()).abs()[~big].max()) < 2e-5
+        assert float((ulp[big] != 0).float().mean()) < 0.03, float((ulp[big] != 0).float().mean())
     finally:
-        hip.gemm_set_option(9, 0)
         hip.gemm_force_variant(0)
 
 
