@@ -125,7 +125,10 @@ int desta_gemm_set_persistent(int on);   /* 1: the automatic choice uses the per
  * (0 auto, else COLS*10 + U: 162 164 322 641), 3 = persistent grid size of the skinny kernel (default 512 = 2 blocks per CU),
  * 4 = two-phase schedule of the 256x256 kernel (default 1; 0 = the four-phase schedule), 5 = K-slices of tail tiles reduced inside
  * the GEMM launch instead of by the fix-up launch (default 0), 6 = four-slot software-pipelined ring form of the 128x128 kernel:
- * 0 never, 1 (default) when the grid leaves one block per CU (<= 256 tiles), 2 always; bit-identical results in every setting */
+ * 0 never, 1 (default) when the grid leaves one block per CU (<= 256 tiles), 2 always; 10 = the two-phase 256x256 kernel stops its
+ * half-tile stream at the last K-tile (default 1; 0 = re-load dead slots as rounds 1-3 did); bit-identical results in every setting.
+ * Options 7, 8 (round 3's de-synchronised start) and 9 (round 4's polynomial GELU) are accepted and ignored: both measured equal and
+ * their code slowed every tile of the kernel (profiles/r04_gemm_regression_bisect.log). */
 int desta_gemm_set_option(int option, int value);
 
 /* ------------------------------------------------------------------------------------------
