@@ -150,6 +150,7 @@ __device__ __forceinline__ void epilogue_pair_bf16(const GemmArgs& p, int z, int
     const bool has_gelu = DYN ? p.act == 1 : (MODE & 2) != 0;
     const bool has_rope = DYN ? true : (MODE & 4) != 0;                    // (rope4 tests the pointer itself)
     const bool has_res = DYN ? p.res != nullptr : (MODE & 8) != 0;
+    const bool has_pre = DYN ? p.preact != nullptr : (MODE & 16) != 0;     // copy of the output in front of the (absent) activation: Qwen3's q|k|v before the q/k-norm
     if (has_res && !p.res_f32 && (p.ldr & 7) == 0 && (p.sR & 7) == 0) {
         // bf16 residual: swap the fp32 values first, so the lane's 8 contiguous outputs take ONE 16-byte residual load
         // (instead of two 8-byte loads before the swap); same arithmetic: add in fp32, round once.
@@ -213,7 +214,11 @@ __device__ __forceinline__ void epilogue_pair_bf16(const GemmArgs& p, int z, int
     const auto lo = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
     const auto hi = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
     const int col = ncol0 + (fq & 1) * 16 + (fq >> 1) * 8;
-    if (row_ok) *(uint4*)((bf16_t*)p.C + (long)z * p.sC + (long)m * p.ldc + col) = make_uint4(lo[0], hi[0], lo[1], hi[1]);
+    if (row_ok) {
+        const uint4 o = make_uint4(lo[0], hi[0], lo[1], hi[1]);
+        *(uint4*)((bf16_t*)p.C + (long)z * p.sC + (long)m * p.ldc + col) = o;
+        if (has_pre) *(uint4*)(p.preact + (long)z * p.sP + (long)m * p.ldp + col) = o;
+    }
 }
 
 // ---- fused SwiGLU epilogues over the BLOCKED gate|up layout (act 2 / act 3; round 4) ------------------------------------------
@@ -988,7 +993,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
     }
     // whole 32-column pairs inside N, bf16 output, no side outputs: wide-store epilogue (block-uniform choice;
     // the permlane swap needs all 64 lanes, so row guards only predicate the store)
-    const bool wide = !p.out_f32 && !p.preact && p.act <= 1 && !p.drop_thresh && (p.N % 32 == 0) && (p.ldc % 8 == 0);
+    const bool pre_ok = !p.preact || (p.act == 0 && !p.res && (p.ldp & 7) == 0 && (p.sP & 7) == 0);   // pre-activation copy == output: a second wide store
+    const bool wide = !p.out_f32 && pre_ok && p.act <= 1 && !p.drop_thresh && (p.N % 32 == 0) && (p.ldc % 8 == 0);
     if (wide) {
         // the tile's feature set, once (block-uniform): the combinations the training step uses get straight-line code
 #define DESTA_WIDE_TILE(MODE)                                                                                          \
@@ -1001,12 +1007,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256_kernel(GemmArgs p) {
                 epilogue_pair_bf16<MODE>(p, z, mc, m < p.M, ncol0, fq, acc[i][j], acc[i][j + 1]);   /* all lanes swap; rows >= M only skip the store */ \
             }                                                                                                          \
         }
-        const int mode = (p.bias ? 1 : 0) | (p.act == 1 ? 2 : 0) | (p.rope_cs ? 4 : 0) | (p.res ? 8 : 0);
+        const int mode = (p.bias ? 1 : 0) | (p.act == 1 ? 2 : 0) | (p.rope_cs ? 4 : 0) | (p.res ? 8 : 0) | (p.preact ? 16 : 0);
         if (mode == 0) { DESTA_WIDE_TILE(0) }                                 // dX GEMMs, lm_head, q|k|v without the fused rotary
         else if (mode == 8) { DESTA_WIDE_TILE(8) }                            // o_proj / down_proj (+ residual)
         else if (mode == 4) { DESTA_WIDE_TILE(4) }                            // q|k|v with the rotary epilogue
         else if (mode == 1) { DESTA_WIDE_TILE(1) }                            // Whisper q|k|v, Q-Former K|V (bias)
         else if (mode == 3) { DESTA_WIDE_TILE(3) }                            // Whisper fc1 (bias + GELU)
+        else if (mode == 16) { DESTA_WIDE_TILE(16) }                          // Qwen3 q|k|v (+ the copy its q/k-norm backward reads)
         else { DESTA_WIDE_TILE(-1) }
 #undef DESTA_WIDE_TILE
         return;
