@@ -545,7 +545,7 @@ def main():
             torch_ref["speedup_of_this_run"] = torch_ref["ms_per_step"] / ms_step
             torch_ref["measured_in_this_run"] = False
             torch_ref["note"] = (f"stored constant: tools/hf_step_bench.py measured once ({torch_ref.get('log')}; round 4: in the same lease as "
-                                 "profiles/r04_bench_driver_cmd.log, a box of gate_up calibration 1360 TFLOP/s where this bench ran 154.9 ms); only the "
+                                 "profiles/r04_bench_driver_cmd.log, a box of gate_up calibration 1355 TFLOP/s where this bench ran 154.7 ms); only the "
                                  "ratio uses this run's ms_per_step")
         mean_ps = sum(per_step) / max(1, len(per_step))
         sd_ps = (sum((x - mean_ps) ** 2 for x in per_step) / max(1, len(per_step) - 1)) ** 0.5
