@@ -429,8 +429,8 @@ class WhisperEncoderHIP:
         self.B = B
         self.melrows = torch.zeros(B, 2 * T + 2, self.Cp, dtype=BF16, device=dev)
         self.h1 = torch.zeros(B, 2 * T + 1, d, dtype=BF16, device=dev)          # row 0 of each clip stays 0 (conv2 left pad)
-        # residual stream in fp32 (three rotating buffers: layer input, post-attention, layer output)
-        self.xr = [torch.empty(B * T, d, dtype=F32, device=dev) for _ in range(3)]
+        # residual stream in fp32: ONE buffer, updated in place (see forward)
+        self.xr = [torch.empty(B * T, d, dtype=F32, device=dev)]
         self.hb = torch.empty(B * T, d, dtype=BF16, device=dev)
         self.qkv = torch.empty(B * T, 3 * d, dtype=BF16, device=dev)
         self.att = torch.empty(B * T, d, dtype=BF16, device=dev)
@@ -451,25 +451,27 @@ class WhisperEncoderHIP:
         H.gemm(self.melrows, self.conv1_w, self.h1[:, 1:], 2 * T, d, 3 * self.Cp, lda=self.Cp, ldc=d, bias=self.conv1_b,
                act=1, batch=B, stride_a=(2 * T + 2) * self.Cp, stride_c=(2 * T + 1) * d)
         # conv2 (k3,s2,p1) + GELU + positions
-        cur, mid, nxt = self.xr
-        H.gemm(self.h1, self.conv2_w, cur, T, d, 3 * d, lda=2 * d, ldc=d, bias=self.conv2_b, act=1,
+        # the fp32 residual stream lives in ONE buffer, updated in place by the out-proj / fc2 epilogues (x += ...: every element is read
+        # and written by the same lane): 61 MB that stay in the 256-MB Infinity Cache from layer to layer, where three rotating
+        # buffers (184 MB) did not
+        x = self.xr[0]
+        H.gemm(self.h1, self.conv2_w, x, T, d, 3 * d, lda=2 * d, ldc=d, bias=self.conv2_b, act=1,
                residual=self.pos, ldr=d, stride_r=0, batch=B, stride_a=(2 * T + 1) * d, stride_c=T * d)
         taps = self.cfg.target_layer_ids
         scale = 64 ** -0.5
         for i, ly in enumerate(self.layers):
-            H.layernorm_fwd(cur, ly["ln1_g"], ly["ln1_b"], 1e-5, y16=self.hb)
+            H.layernorm_fwd(x, ly["ln1_g"], ly["ln1_b"], 1e-5, y16=self.hb)
             H.gemm(self.hb, ly["wqkv"], self.qkv, M, 3 * d, d, bias=ly["bqkv"])
             ad = H.attn_desc(self.qkv, self.qkv, self.qkv, self.att, None, batch=B, hq=self.heads, hkv=self.heads, sq=T, sk=T,
                              hd=64, scale=scale, q_off=0, k_off=d, v_off=2 * d)
             H.attention_fwd(ad)
-            H.gemm(self.att, ly["wo"], mid, M, d, d, bias=ly["bo"], residual=cur)
-            H.layernorm_fwd(mid, ly["ln2_g"], ly["ln2_b"], 1e-5, y16=self.hb)
+            H.gemm(self.att, ly["wo"], x, M, d, d, bias=ly["bo"], residual=x)
+            H.layernorm_fwd(x, ly["ln2_g"], ly["ln2_b"], 1e-5, y16=self.hb)
             H.gemm(self.hb, ly["w1"], self.ff, M, self.ffn, d, bias=ly["b1"], act=1)
-            H.gemm(self.ff, ly["w2"], nxt, M, d, self.ffn, bias=ly["b2"], residual=mid)
+            H.gemm(self.ff, ly["w2"], x, M, d, self.ffn, bias=ly["b2"], residual=x)
             if i in taps:                                   # the Q-Former's K/V projections read the tapped state as a bf16 operand
-                H.cast_bf16(nxt, enc_all[taps.index(i)], M * d)
-            cur, nxt = nxt, cur
-        self.last32 = cur                                   # output of the last layer, fp32 [B*T, d] (the ASR decoder applies encoder.layer_norm to it)
+                H.cast_bf16(x, enc_all[taps.index(i)], M * d)
+        self.last32 = x                                   # output of the last layer, fp32 [B*T, d] (the ASR decoder applies encoder.layer_norm to it)
 
 
 # =========================================================================================== Whisper decoder (ASR leg of generate)
